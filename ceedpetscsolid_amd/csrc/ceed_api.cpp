@@ -1,0 +1,952 @@
+// ceed_api.cpp -- host side of the MI355X backend behind include/ceed.h.
+//
+// Resource "/gpu/hip/mi355x".  Objects are reference counted exactly as the
+// reference expects (operators keep their qfunction / restrictions / bases /
+// passive vectors alive after the creator destroys its handles, e.g.
+// setuplibceed.c:392-393).  A CeedOperator is lowered, at its first apply, to one
+// hand-written gfx950 kernel family by matching its field signature against the
+// operator graphs the reference builds:
+//
+//   fused_grad : GRAD active in, NONE qdata (+ NONE state in / out), GRAD active out
+//                -> opApply (setuplibceed.c:517-542) and opJacob per level (:817-839)
+//   setup_geo  : GRAD coords + WEIGHT -> NONE qdata             (:370-389)
+//   prolong    : Identity, INTERP in -> NONE out                (:857-862)
+//   restrict   : Identity, NONE in  -> INTERP out               (:849-854)
+//
+// There is NO host fallback: a graph outside these families, a QFunction without
+// a device functor, or a missing GPU is a loud error.
+#include <ceed.h>
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace cps;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static int g_err_return = 0;
+static thread_local char g_err_msg[1024] = "";
+
+static int ceed_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err_msg, sizeof g_err_msg, fmt, ap);
+  va_end(ap);
+  if (!g_err_return) {
+    fprintf(stderr, "[ceed mi355x] error: %s\n", g_err_msg);
+    abort();
+  }
+  return 1;
+}
+#define CHK(x) do { int ierr_ = (x); if (ierr_) return ierr_; } while (0)
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+  return ceed_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+extern "C" int CeedXSetErrorReturn(int enable) { g_err_return = enable; return 0; }
+extern "C" const char *CeedXLastError(void) { return g_err_msg; }
+
+// ---------------------------------------------------------------------------
+// object layouts
+// ---------------------------------------------------------------------------
+struct Ceed_private {
+  int refcount = 1;
+  std::string resource;
+  hipStream_t stream = nullptr;
+  int device = 0;
+};
+
+struct CeedVector_private {
+  Ceed ceed = nullptr;
+  int refcount = 1;
+  CeedInt length = 0;
+  double *h = nullptr, *d = nullptr;   // current host / device storage
+  bool h_owned = false, d_owned = false;
+  bool h_valid = false, d_valid = false;
+};
+
+struct CeedElemRestriction_private {
+  Ceed ceed = nullptr;
+  int refcount = 1;
+  CeedInt nelem = 0, elemsize = 0, ncomp = 0, compstride = 0, lsize = 0;
+  bool strided = false, backend_strides = true;
+  CeedInt strides[3] = {0, 0, 0};
+  std::vector<CeedInt> h_offsets;
+  uint32_t *d_offsets = nullptr;  // plain (unflagged)
+};
+
+struct CeedBasis_private {
+  Ceed ceed = nullptr;
+  int refcount = 1;
+  CeedInt dim = 3, ncomp = 0, P1d = 0, Q1d = 0;
+  CeedQuadMode qmode = CEED_GAUSS;
+  std::vector<double> interp1d, grad1d, qref1d, qweight1d, colo1d;
+};
+
+struct QFField { std::string name; CeedInt size; CeedEvalMode emode; };
+
+struct CeedQFunction_private {
+  Ceed ceed = nullptr;
+  int refcount = 1;
+  CeedQFunctionUser f = nullptr;  // kept, never called: device functors do the work
+  std::string source, name;
+  int kind = QF_NONE;
+  void *ctx = nullptr;
+  size_t ctxsize = 0;
+  CeedInt identity_size = 0;
+  std::vector<QFField> in, out;
+};
+
+struct OpField { bool set = false; CeedElemRestriction rstr = nullptr; CeedBasis basis = nullptr; CeedVector vec = nullptr; };
+
+enum PlanKind { PLAN_NONE = 0, PLAN_FUSED_GRAD, PLAN_SETUP_GEO, PLAN_PROLONG, PLAN_RESTRICT };
+
+struct CeedOperator_private {
+  Ceed ceed = nullptr;
+  int refcount = 1;
+  CeedQFunction qf = nullptr;
+  std::vector<OpField> in, out;
+  bool composite = false;
+  std::vector<CeedOperator> sub;
+  // lowering
+  int plan = PLAN_NONE;
+  int i_active = -1, i_qdata = -1, i_state = -1, i_weight = -1, o_active = -1, o_state = -1, o_qdata = -1;
+  BasisTables tables;
+  std::string kernel_name;
+  // Dirichlet flags
+  uint32_t *d_off_flagged_in = nullptr, *d_off_flagged_out = nullptr;  // same array unless transfer
+  int mask_mode = 0;
+  // optional fine-side scale for transfers
+  CeedVector scale = nullptr;
+  // timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  double ms_accum = 0.;
+  int64_t launches = 0;
+};
+
+// sentinels
+static CeedVector_private s_vec_active, s_vec_none;
+static CeedElemRestriction_private s_rstr_none;
+static CeedBasis_private s_basis_colloc;
+static CeedQFunction_private s_qf_none;
+static CeedRequest s_req_immediate, s_req_ordered;
+extern "C" {
+const CeedVector CEED_VECTOR_ACTIVE = &s_vec_active;
+const CeedVector CEED_VECTOR_NONE = &s_vec_none;
+const CeedElemRestriction CEED_ELEMRESTRICTION_NONE = &s_rstr_none;
+const CeedBasis CEED_BASIS_COLLOCATED = &s_basis_colloc;
+const CeedQFunction CEED_QFUNCTION_NONE = &s_qf_none;
+CeedRequest *const CEED_REQUEST_IMMEDIATE = &s_req_immediate;
+CeedRequest *const CEED_REQUEST_ORDERED = &s_req_ordered;
+const CeedInt CEED_STRIDES_BACKEND[3] = {-1, -1, -1};
+const char *const CeedMemTypes[] = {"host", "device"};
+}
+
+// ---------------------------------------------------------------------------
+// Ceed
+// ---------------------------------------------------------------------------
+extern "C" int CeedInit(const char *resource, Ceed *ceed) {
+  if (!resource || strncmp(resource, "/gpu/hip", 8))
+    return ceed_error("this library serves /gpu/hip/mi355x only (got '%s'); there is no CPU path",
+                      resource ? resource : "(null)");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1)
+    return ceed_error("no HIP device visible (%s): the MI355X backend cannot run",
+                      e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  Ceed c = new Ceed_private;
+  c->resource = "/gpu/hip/mi355x";
+  HIPCHK(hipGetDevice(&c->device));
+  *ceed = c;
+  return 0;
+}
+static void ceed_ref(Ceed c) { c->refcount++; }
+static void ceed_unref(Ceed c) { if (--c->refcount == 0) delete c; }
+extern "C" int CeedDestroy(Ceed *ceed) {
+  if (!ceed || !*ceed) return 0;
+  ceed_unref(*ceed);
+  *ceed = nullptr;
+  return 0;
+}
+extern "C" int CeedGetResource(Ceed ceed, const char **resource) { *resource = ceed->resource.c_str(); return 0; }
+extern "C" int CeedGetPreferredMemType(Ceed, CeedMemType *type) { *type = CEED_MEM_DEVICE; return 0; }
+extern "C" int CeedXSetStream(Ceed ceed, void *s) { ceed->stream = (hipStream_t)s; return 0; }
+extern "C" int CeedXSynchronize(Ceed ceed) { HIPCHK(hipStreamSynchronize(ceed->stream)); return 0; }
+
+// ---------------------------------------------------------------------------
+// CeedVector: host and device mirrors with validity flags
+// ---------------------------------------------------------------------------
+static size_t vbytes(CeedVector v) { return sizeof(double) * (size_t)(v->length > 0 ? v->length : 1); }
+static int vec_need_host(CeedVector v) {
+  if (!v->h) { v->h = (double *)calloc(vbytes(v), 1); v->h_owned = true; }
+  return 0;
+}
+static int vec_need_dev(CeedVector v) {
+  if (!v->d) { HIPCHK(hipMalloc((void **)&v->d, vbytes(v))); v->d_owned = true; }
+  return 0;
+}
+static int vec_sync_to(CeedVector v, CeedMemType m) {
+  hipStream_t s = v->ceed->stream;
+  if (m == CEED_MEM_HOST) {
+    CHK(vec_need_host(v));
+    if (!v->h_valid && v->d_valid) {
+      HIPCHK(hipMemcpyAsync(v->h, v->d, sizeof(double) * (size_t)v->length, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+    }
+    v->h_valid = true;
+  } else {
+    CHK(vec_need_dev(v));
+    if (!v->d_valid && v->h_valid) {
+      HIPCHK(hipMemcpyAsync(v->d, v->h, sizeof(double) * (size_t)v->length, hipMemcpyHostToDevice, s));
+      HIPCHK(hipStreamSynchronize(s));  // the host buffer may be reused by the caller
+    } else if (!v->d_valid && !v->h_valid) {
+      HIPCHK(hipMemsetAsync(v->d, 0, vbytes(v), s));
+    }
+    v->d_valid = true;
+  }
+  return 0;
+}
+// device pointer for kernels; write=true invalidates the host mirror
+static int vec_dev(CeedVector v, bool write, double **p) {
+  CHK(vec_sync_to(v, CEED_MEM_DEVICE));
+  if (write) v->h_valid = false;
+  *p = v->d;
+  return 0;
+}
+static void vec_drop_host(CeedVector v) { if (v->h_owned) free(v->h); v->h = nullptr; v->h_owned = false; v->h_valid = false; }
+static void vec_drop_dev(CeedVector v) { if (v->d_owned && v->d) (void)hipFree(v->d); v->d = nullptr; v->d_owned = false; v->d_valid = false; }
+
+extern "C" int CeedVectorCreate(Ceed ceed, CeedInt length, CeedVector *vec) {
+  CeedVector v = new CeedVector_private;
+  v->ceed = ceed; ceed_ref(ceed);
+  v->length = length;
+  *vec = v;
+  return 0;
+}
+extern "C" int CeedVectorSetArray(CeedVector v, CeedMemType mtype, CeedCopyMode cmode, CeedScalar *array) {
+  const size_t nb = sizeof(double) * (size_t)v->length;
+  if (mtype == CEED_MEM_HOST) {
+    if (cmode == CEED_COPY_VALUES) {
+      if (!v->h_owned) v->h = nullptr;
+      CHK(vec_need_host(v));
+      if (array) memcpy(v->h, array, nb);
+    } else {
+      vec_drop_host(v);
+      v->h = array; v->h_owned = (cmode == CEED_OWN_POINTER);
+    }
+    v->h_valid = true; v->d_valid = false;
+  } else {
+    if (cmode == CEED_COPY_VALUES) {
+      if (!v->d_owned) v->d = nullptr;
+      CHK(vec_need_dev(v));
+      if (array) HIPCHK(hipMemcpyAsync(v->d, array, nb, hipMemcpyDeviceToDevice, v->ceed->stream));
+    } else {
+      vec_drop_dev(v);
+      v->d = array; v->d_owned = (cmode == CEED_OWN_POINTER);
+    }
+    v->d_valid = true; v->h_valid = false;
+  }
+  return 0;
+}
+extern "C" int CeedVectorTakeArray(CeedVector v, CeedMemType mtype, CeedScalar **array) {
+  if (mtype == CEED_MEM_HOST) {
+    if (v->h || v->d_valid) CHK(vec_sync_to(v, CEED_MEM_HOST));
+    if (array) *array = v->h;
+    v->h = nullptr; v->h_owned = false; v->h_valid = false;
+  } else {
+    if (v->d || v->h_valid) CHK(vec_sync_to(v, CEED_MEM_DEVICE));
+    if (array) *array = v->d;
+    v->d = nullptr; v->d_owned = false; v->d_valid = false;
+  }
+  return 0;
+}
+extern "C" int CeedVectorSetValue(CeedVector v, CeedScalar value) {
+  CHK(vec_need_dev(v));
+  if (value == 0.) HIPCHK(hipMemsetAsync(v->d, 0, vbytes(v), v->ceed->stream));
+  else HIPCHK(launch_set_value(v->d, (size_t)v->length, value, v->ceed->stream));
+  v->d_valid = true; v->h_valid = false;
+  return 0;
+}
+extern "C" int CeedVectorSyncArray(CeedVector v, CeedMemType mtype) { return vec_sync_to(v, mtype); }
+extern "C" int CeedVectorGetArray(CeedVector v, CeedMemType mtype, CeedScalar **array) {
+  CHK(vec_sync_to(v, mtype));
+  if (mtype == CEED_MEM_HOST) { *array = v->h; v->d_valid = false; }
+  else { *array = v->d; v->h_valid = false; }
+  return 0;
+}
+extern "C" int CeedVectorGetArrayRead(CeedVector v, CeedMemType mtype, const CeedScalar **array) {
+  CHK(vec_sync_to(v, mtype));
+  *array = mtype == CEED_MEM_HOST ? v->h : v->d;
+  return 0;
+}
+extern "C" int CeedVectorRestoreArray(CeedVector, CeedScalar **array) { if (array) *array = nullptr; return 0; }
+extern "C" int CeedVectorRestoreArrayRead(CeedVector, const CeedScalar **array) { if (array) *array = nullptr; return 0; }
+extern "C" int CeedVectorGetLength(CeedVector v, CeedInt *length) { *length = v->length; return 0; }
+extern "C" int CeedVectorReciprocal(CeedVector v) {
+  double *p;
+  CHK(vec_dev(v, true, &p));
+  HIPCHK(launch_reciprocal(p, (size_t)v->length, v->ceed->stream));
+  return 0;
+}
+extern "C" int CeedVectorDestroy(CeedVector *vec) {
+  if (!vec || !*vec) return 0;
+  CeedVector v = *vec;
+  *vec = nullptr;
+  if (v == CEED_VECTOR_ACTIVE || v == CEED_VECTOR_NONE) return 0;
+  if (--v->refcount > 0) return 0;
+  vec_drop_host(v); vec_drop_dev(v);
+  ceed_unref(v->ceed);
+  delete v;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// CeedElemRestriction
+// ---------------------------------------------------------------------------
+extern "C" int CeedElemRestrictionCreate(Ceed ceed, CeedInt nelem, CeedInt elemsize, CeedInt ncomp,
+                                         CeedInt compstride, CeedInt lsize, CeedMemType mtype,
+                                         CeedCopyMode, const CeedInt *offsets, CeedElemRestriction *rstr) {
+  if (mtype != CEED_MEM_HOST) return ceed_error("restriction offsets are expected in host memory (setuplibceed.c:235)");
+  if ((uint32_t)lsize > OFF_MASK) return ceed_error("L-vector of %d entries exceeds the 2^29 offset range of this backend", lsize);
+  const size_t n = (size_t)nelem * elemsize;
+  for (size_t i = 0; i < n; i++) {
+    const long last = (long)offsets[i] + (long)(ncomp - 1) * compstride;
+    if (offsets[i] < 0 || last >= lsize)
+      return ceed_error("restriction offset %zu = %d out of range [0,%d)", i, offsets[i], lsize);
+  }
+  CeedElemRestriction r = new CeedElemRestriction_private;
+  r->ceed = ceed; ceed_ref(ceed);
+  r->nelem = nelem; r->elemsize = elemsize; r->ncomp = ncomp; r->compstride = compstride; r->lsize = lsize;
+  r->h_offsets.assign(offsets, offsets + n);
+  HIPCHK(hipMalloc((void **)&r->d_offsets, sizeof(uint32_t) * (n ? n : 1)));
+  HIPCHK(hipMemcpy(r->d_offsets, offsets, sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+  *rstr = r;
+  return 0;
+}
+extern "C" int CeedElemRestrictionCreateStrided(Ceed ceed, CeedInt nelem, CeedInt elemsize, CeedInt ncomp,
+                                                CeedInt lsize, const CeedInt strides[3], CeedElemRestriction *rstr) {
+  if ((long)nelem * elemsize * ncomp > lsize) return ceed_error("strided restriction larger than its L-vector");
+  CeedElemRestriction r = new CeedElemRestriction_private;
+  r->ceed = ceed; ceed_ref(ceed);
+  r->nelem = nelem; r->elemsize = elemsize; r->ncomp = ncomp; r->lsize = lsize;
+  r->strided = true;
+  // CEED_STRIDES_BACKEND (setuplibceed.c:304-318): this backend lays q-point data out as
+  // [element][component][point]: one contiguous run per wave-instruction in the fused kernels.
+  r->backend_strides = strides[0] < 0;
+  if (r->backend_strides) { r->strides[0] = 1; r->strides[1] = elemsize; r->strides[2] = elemsize * ncomp; }
+  else {
+    memcpy(r->strides, strides, sizeof r->strides);
+    if (!(strides[0] == 1 && strides[1] == elemsize && strides[2] == elemsize * ncomp))
+      return ceed_error("only the [elem][comp][node] strided layout is supported on /gpu/hip/mi355x");
+  }
+  *rstr = r;
+  return 0;
+}
+extern "C" int CeedElemRestrictionCreateVector(CeedElemRestriction r, CeedVector *lvec, CeedVector *evec) {
+  if (lvec) CHK(CeedVectorCreate(r->ceed, r->lsize, lvec));
+  if (evec) CHK(CeedVectorCreate(r->ceed, r->nelem * r->elemsize * r->ncomp, evec));
+  return 0;
+}
+extern "C" int CeedElemRestrictionApply(CeedElemRestriction r, CeedTransposeMode tmode, CeedVector u,
+                                        CeedVector ru, CeedRequest *) {
+  hipStream_t s = r->ceed->stream;
+  double *pu, *pv;
+  CHK(vec_dev(u, false, &pu));
+  CHK(vec_dev(ru, true, &pv));
+  if (r->strided) {  // identity layout: E == L
+    const size_t n = (size_t)r->nelem * r->elemsize * r->ncomp;
+    if (tmode == CEED_NOTRANSPOSE) HIPCHK(hipMemcpyAsync(pv, pu, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    else HIPCHK(launch_axpby(pv, 1., pu, 1., n, s));
+    return 0;
+  }
+  if (tmode == CEED_NOTRANSPOSE) HIPCHK(launch_rstr_gather(r->d_offsets, r->nelem, r->elemsize, r->ncomp, r->compstride, pu, pv, s));
+  else HIPCHK(launch_rstr_scatter_add(r->d_offsets, r->nelem, r->elemsize, r->ncomp, r->compstride, pu, pv, s));
+  return 0;
+}
+extern "C" int CeedElemRestrictionGetMultiplicity(CeedElemRestriction r, CeedVector mult) {
+  if (r->strided) return CeedVectorSetValue(mult, 1.);
+  CHK(CeedVectorSetValue(mult, 0.));
+  HIPCHK(launch_multiplicity(r->d_offsets, r->nelem, r->elemsize, r->ncomp, r->compstride, mult->d, r->ceed->stream));
+  return 0;
+}
+extern "C" int CeedElemRestrictionDestroy(CeedElemRestriction *rstr) {
+  if (!rstr || !*rstr) return 0;
+  CeedElemRestriction r = *rstr;
+  *rstr = nullptr;
+  if (r == CEED_ELEMRESTRICTION_NONE) return 0;
+  if (--r->refcount > 0) return 0;
+  if (r->d_offsets) (void)hipFree(r->d_offsets);
+  ceed_unref(r->ceed);
+  delete r;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// 1-D rules and tables; host side, set-up time only
+// ---------------------------------------------------------------------------
+static void legendre_pair(int n, double x, double *pn, double *pnm1) {
+  double p0 = 1., p1 = x;
+  if (n == 0) { *pn = 1.; *pnm1 = 0.; return; }
+  for (int j = 2; j <= n; j++) {
+    const double p2 = ((2. * j - 1.) * x * p1 - (j - 1.) * p0) / j;
+    p0 = p1; p1 = p2;
+  }
+  *pn = p1; *pnm1 = p0;
+}
+extern "C" int CeedGaussQuadrature(CeedInt Q, CeedScalar *qref1d, CeedScalar *qweight1d) {
+  for (int i = 0; i <= (Q - 1) / 2; i++) {
+    double x = std::cos(M_PI * (2. * i + 1.) / (2. * Q)), pq, pqm1, dp;
+    for (int it = 0; it < 100; it++) {
+      legendre_pair(Q, x, &pq, &pqm1);
+      dp = Q * (x * pq - pqm1) / (x * x - 1.);
+      x -= pq / dp;
+      if (it > 0 && std::fabs(pq) <= 10 * 2.220446049250313e-16) break;
+    }
+    legendre_pair(Q, x, &pq, &pqm1);
+    dp = Q * (x * pq - pqm1) / (x * x - 1.);
+    const double w = 2. / ((1. - x * x) * dp * dp);
+    qref1d[i] = -x; qref1d[Q - 1 - i] = x;
+    if (qweight1d) { qweight1d[i] = w; qweight1d[Q - 1 - i] = w; }
+  }
+  if (Q % 2) qref1d[Q / 2] = 0.;
+  return 0;
+}
+extern "C" int CeedLobattoQuadrature(CeedInt Q, CeedScalar *qref1d, CeedScalar *qweight1d) {
+  if (Q < 2) return ceed_error("Lobatto rule needs at least 2 points");
+  const int n = Q - 1;
+  qref1d[0] = -1.; qref1d[Q - 1] = 1.;
+  if (qweight1d) qweight1d[0] = qweight1d[Q - 1] = 2. / (Q * (Q - 1.));
+  for (int i = 1; i <= (Q - 1) / 2; i++) {
+    double x = std::cos(M_PI * i / (double)n), pn, pnm1;
+    for (int it = 0; it < 100; it++) {
+      legendre_pair(n, x, &pn, &pnm1);
+      const double dp = n * (x * pn - pnm1) / (x * x - 1.);
+      const double d2p = (2. * x * dp - n * (n + 1.) * pn) / (1. - x * x);
+      x -= dp / d2p;
+      if (it > 0 && std::fabs(dp) <= 10 * 2.220446049250313e-16) break;
+    }
+    legendre_pair(n, x, &pn, &pnm1);
+    const double w = 2. / (Q * (Q - 1.) * pn * pn);
+    qref1d[i] = -x; qref1d[Q - 1 - i] = x;
+    if (qweight1d) { qweight1d[i] = w; qweight1d[Q - 1 - i] = w; }
+  }
+  if (Q % 2) qref1d[Q / 2] = 0.;
+  return 0;
+}
+static void lagrange_at(int P, const double *nodes, double x, double *val, double *der) {
+  for (int j = 0; j < P; j++) {
+    double v = 1., d = 0.;
+    for (int m = 0; m < P; m++) {
+      if (m == j) continue;
+      const double inv = 1. / (nodes[j] - nodes[m]);
+      d = d * (x - nodes[m]) * inv + v * inv;
+      v *= (x - nodes[m]) * inv;
+    }
+    val[j] = v; der[j] = d;
+  }
+}
+extern "C" int CeedBasisCreateTensorH1Lagrange(Ceed ceed, CeedInt dim, CeedInt ncomp, CeedInt P, CeedInt Q,
+                                               CeedQuadMode qmode, CeedBasis *basis) {
+  if (dim != 3) return ceed_error("only dim = 3 bases are supported");
+  if (P < 2 || Q < 1 || P > MAXN1D || Q > MAXN1D) return ceed_error("basis sizes P=%d Q=%d outside [2,%d]", P, Q, MAXN1D);
+  CeedBasis b = new CeedBasis_private;
+  b->ceed = ceed; ceed_ref(ceed);
+  b->dim = dim; b->ncomp = ncomp; b->P1d = P; b->Q1d = Q; b->qmode = qmode;
+  b->interp1d.assign((size_t)P * Q, 0.); b->grad1d.assign((size_t)P * Q, 0.);
+  b->qref1d.assign(Q, 0.); b->qweight1d.assign(Q, 0.); b->colo1d.assign((size_t)Q * Q, 0.);
+  std::vector<double> nodes(P), tmp(Q);
+  CHK(CeedLobattoQuadrature(P, nodes.data(), nullptr));
+  if (qmode == CEED_GAUSS) CHK(CeedGaussQuadrature(Q, b->qref1d.data(), b->qweight1d.data()));
+  else CHK(CeedLobattoQuadrature(Q, b->qref1d.data(), b->qweight1d.data()));
+  for (int q = 0; q < Q; q++) {
+    lagrange_at(P, nodes.data(), b->qref1d[q], &b->interp1d[(size_t)q * P], &b->grad1d[(size_t)q * P]);
+    // collocated derivative: Lagrange basis ON the quadrature points, differentiated there
+    if (Q > 1) lagrange_at(Q, b->qref1d.data(), b->qref1d[q], tmp.data(), &b->colo1d[(size_t)q * Q]);
+  }
+  *basis = b;
+  return 0;
+}
+extern "C" int CeedBasisGetNumQuadraturePoints(CeedBasis b, CeedInt *Q) { *Q = b->Q1d * b->Q1d * b->Q1d; return 0; }
+extern "C" int CeedBasisGetNumNodes(CeedBasis b, CeedInt *P) { *P = b->P1d * b->P1d * b->P1d; return 0; }
+extern "C" int CeedBasisGetInterp1D(CeedBasis b, const CeedScalar **t) { *t = b->interp1d.data(); return 0; }
+extern "C" int CeedBasisGetGrad1D(CeedBasis b, const CeedScalar **t) { *t = b->grad1d.data(); return 0; }
+extern "C" int CeedBasisGetQWeights1D(CeedBasis b, const CeedScalar **t) { *t = b->qweight1d.data(); return 0; }
+extern "C" int CeedBasisApply(CeedBasis, CeedInt, CeedTransposeMode, CeedEvalMode, CeedVector, CeedVector) {
+  return ceed_error("standalone CeedBasisApply is not on the reference's path and is not provided by "
+                    "/gpu/hip/mi355x: bases are applied inside the fused operator kernels");
+}
+extern "C" int CeedBasisDestroy(CeedBasis *basis) {
+  if (!basis || !*basis) return 0;
+  CeedBasis b = *basis;
+  *basis = nullptr;
+  if (b == CEED_BASIS_COLLOCATED) return 0;
+  if (--b->refcount > 0) return 0;
+  ceed_unref(b->ceed);
+  delete b;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// CeedQFunction
+// ---------------------------------------------------------------------------
+static int resolve_qf(const std::string &name) {
+  static const struct { const char *n; int k; } tab[] = {
+      {"SetupGeo", QF_SETUP_GEO},    {"LinElasF", QF_LINELAS},       {"LinElasdF", QF_LINELAS},
+      {"HyperSSF", QF_HYPERSS_F},    {"HyperSSdF", QF_HYPERSS_DF},   {"HyperFSF", QF_HYPERFS_F},
+      {"HyperFSdF", QF_HYPERFS_DF},
+  };
+  for (auto &t : tab) if (name == t.n) return t.k;
+  return QF_NONE;
+}
+extern "C" int CeedQFunctionCreateInterior(Ceed ceed, CeedInt, CeedQFunctionUser f, const char *source,
+                                           CeedQFunction *qf) {
+  std::string src = source ? source : "";
+  const size_t colon = src.rfind(':');
+  std::string name = colon == std::string::npos ? src : src.substr(colon + 1);
+  const int kind = resolve_qf(name);
+  if (kind == QF_NONE)
+    return ceed_error("QFunction '%s' has no gfx950 device functor in this backend (host callbacks are "
+                      "never executed on /gpu/hip/mi355x)", src.c_str());
+  CeedQFunction q = new CeedQFunction_private;
+  q->ceed = ceed; ceed_ref(ceed);
+  q->f = f; q->source = src; q->name = name; q->kind = kind;
+  *qf = q;
+  return 0;
+}
+extern "C" int CeedQFunctionCreateIdentity(Ceed ceed, CeedInt size, CeedEvalMode inmode, CeedEvalMode outmode,
+                                           CeedQFunction *qf) {
+  CeedQFunction q = new CeedQFunction_private;
+  q->ceed = ceed; ceed_ref(ceed);
+  q->name = q->source = "Identity"; q->kind = QF_IDENTITY; q->identity_size = size;
+  q->in.push_back({"input", size, inmode});
+  q->out.push_back({"output", size, outmode});
+  *qf = q;
+  return 0;
+}
+extern "C" int CeedQFunctionAddInput(CeedQFunction qf, const char *name, CeedInt size, CeedEvalMode em) {
+  qf->in.push_back({name, size, em});
+  return 0;
+}
+extern "C" int CeedQFunctionAddOutput(CeedQFunction qf, const char *name, CeedInt size, CeedEvalMode em) {
+  if (em == CEED_EVAL_WEIGHT) return ceed_error("WEIGHT is not an output mode");
+  qf->out.push_back({name, size, em});
+  return 0;
+}
+extern "C" int CeedQFunctionSetContext(CeedQFunction qf, void *ctx, size_t ctxsize) {
+  qf->ctx = ctx; qf->ctxsize = ctxsize;  // borrowed; re-read at every apply (matops.c:215-232)
+  return 0;
+}
+extern "C" int CeedQFunctionDestroy(CeedQFunction *qf) {
+  if (!qf || !*qf) return 0;
+  CeedQFunction q = *qf;
+  *qf = nullptr;
+  if (q == CEED_QFUNCTION_NONE) return 0;
+  if (--q->refcount > 0) return 0;
+  ceed_unref(q->ceed);
+  delete q;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// CeedOperator
+// ---------------------------------------------------------------------------
+extern "C" int CeedOperatorCreate(Ceed ceed, CeedQFunction qf, CeedQFunction, CeedQFunction, CeedOperator *op) {
+  CeedOperator o = new CeedOperator_private;
+  o->ceed = ceed; ceed_ref(ceed);
+  o->qf = qf; qf->refcount++;
+  o->in.resize(qf->in.size()); o->out.resize(qf->out.size());
+  *op = o;
+  return 0;
+}
+extern "C" int CeedCompositeOperatorCreate(Ceed ceed, CeedOperator *op) {
+  CeedOperator o = new CeedOperator_private;
+  o->ceed = ceed; ceed_ref(ceed);
+  o->composite = true;
+  *op = o;
+  return 0;
+}
+extern "C" int CeedCompositeOperatorAddSub(CeedOperator comp, CeedOperator sub) {
+  if (!comp->composite) return ceed_error("not a composite operator");
+  comp->sub.push_back(sub); sub->refcount++;
+  return 0;
+}
+extern "C" int CeedOperatorSetField(CeedOperator op, const char *name, CeedElemRestriction r, CeedBasis b, CeedVector v) {
+  if (op->composite) return ceed_error("cannot set a field on a composite operator");
+  if (op->in.size() != op->qf->in.size()) op->in.resize(op->qf->in.size());
+  if (op->out.size() != op->qf->out.size()) op->out.resize(op->qf->out.size());
+  OpField *f = nullptr;
+  for (size_t i = 0; i < op->qf->in.size() && !f; i++) if (op->qf->in[i].name == name) f = &op->in[i];
+  for (size_t i = 0; i < op->qf->out.size() && !f; i++) if (op->qf->out[i].name == name) f = &op->out[i];
+  if (!f) return ceed_error("QFunction '%s' has no field named '%s'", op->qf->name.c_str(), name);
+  f->set = true; f->rstr = r; f->basis = b; f->vec = v;
+  if (r != CEED_ELEMRESTRICTION_NONE) r->refcount++;
+  if (b != CEED_BASIS_COLLOCATED) b->refcount++;
+  if (v != CEED_VECTOR_ACTIVE && v != CEED_VECTOR_NONE) v->refcount++;
+  op->plan = PLAN_NONE;
+  return 0;
+}
+static void op_free_flags(CeedOperator o) {
+  if (o->d_off_flagged_out && o->d_off_flagged_out != o->d_off_flagged_in) (void)hipFree(o->d_off_flagged_out);
+  if (o->d_off_flagged_in) (void)hipFree(o->d_off_flagged_in);
+  o->d_off_flagged_in = o->d_off_flagged_out = nullptr;
+  o->mask_mode = 0;
+}
+extern "C" int CeedOperatorDestroy(CeedOperator *op) {
+  if (!op || !*op) return 0;
+  CeedOperator o = *op;
+  *op = nullptr;
+  if (--o->refcount > 0) return 0;
+  if (o->composite) {
+    for (CeedOperator s : o->sub) CeedOperatorDestroy(&s);
+  } else {
+    for (auto *arr : {&o->in, &o->out})
+      for (OpField &f : *arr) {
+        if (!f.set) continue;
+        CeedElemRestrictionDestroy(&f.rstr); CeedBasisDestroy(&f.basis); CeedVectorDestroy(&f.vec);
+      }
+    CeedQFunctionDestroy(&o->qf);
+  }
+  op_free_flags(o);
+  CeedVectorDestroy(&o->scale);
+  for (auto &ev : o->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  ceed_unref(o->ceed);
+  delete o;
+  return 0;
+}
+
+static void fill_tables(BasisTables &t, CeedBasis b) {
+  memset(&t, 0, sizeof t);
+  memcpy(t.interp, b->interp1d.data(), sizeof(double) * b->interp1d.size());
+  memcpy(t.grad, b->grad1d.data(), sizeof(double) * b->grad1d.size());
+  memcpy(t.colo, b->colo1d.data(), sizeof(double) * b->colo1d.size());
+  memcpy(t.qw, b->qweight1d.data(), sizeof(double) * b->qweight1d.size());
+}
+static bool is_offsets(CeedElemRestriction r) { return r && r != CEED_ELEMRESTRICTION_NONE && !r->strided; }
+static bool is_strided(CeedElemRestriction r) { return r && r != CEED_ELEMRESTRICTION_NONE && r->strided; }
+
+// Match the operator's field signature against the supported kernel families.
+static int op_plan(CeedOperator op) {
+  if (op->plan != PLAN_NONE) return 0;
+  CeedQFunction qf = op->qf;
+  for (size_t i = 0; i < qf->in.size(); i++) if (!op->in[i].set) return ceed_error("operator field '%s' not set", qf->in[i].name.c_str());
+  for (size_t i = 0; i < qf->out.size(); i++) if (!op->out[i].set) return ceed_error("operator field '%s' not set", qf->out[i].name.c_str());
+  op->i_active = op->i_qdata = op->i_state = op->i_weight = op->o_active = op->o_state = op->o_qdata = -1;
+  const int k = qf->kind;
+  auto unsupported = [&](const char *why) {
+    return ceed_error("operator with QFunction '%s' is outside the kernel families of /gpu/hip/mi355x: %s",
+                      qf->name.c_str(), why);
+  };
+  if (k == QF_LINELAS || k == QF_HYPERSS_F || k == QF_HYPERSS_DF || k == QF_HYPERFS_F || k == QF_HYPERFS_DF) {
+    // inputs: GRAD active (9) | NONE qdata (10) | [NONE state (9)]
+    for (size_t i = 0; i < qf->in.size(); i++) {
+      const QFField &f = qf->in[i];
+      if (f.emode == CEED_EVAL_GRAD && op->in[i].vec == CEED_VECTOR_ACTIVE && f.size == 9 && op->i_active < 0) op->i_active = (int)i;
+      else if (f.emode == CEED_EVAL_NONE && f.size == 10 && op->i_qdata < 0) op->i_qdata = (int)i;
+      else if (f.emode == CEED_EVAL_NONE && f.size == 9 && op->i_state < 0) op->i_state = (int)i;
+      else return unsupported("unexpected input field");
+    }
+    for (size_t i = 0; i < qf->out.size(); i++) {
+      const QFField &f = qf->out[i];
+      if (f.emode == CEED_EVAL_GRAD && op->out[i].vec == CEED_VECTOR_ACTIVE && f.size == 9 && op->o_active < 0) op->o_active = (int)i;
+      else if (f.emode == CEED_EVAL_NONE && f.size == 9 && op->o_state < 0) op->o_state = (int)i;
+      else return unsupported("unexpected output field");
+    }
+    if (op->i_active != 0 || op->i_qdata != 1) return unsupported("inputs must be (GRAD active, NONE qdata[, NONE state])");
+    const bool st_in = (k == QF_HYPERSS_DF || k == QF_HYPERFS_DF), st_out = (k == QF_HYPERSS_F || k == QF_HYPERFS_F);
+    if (st_in != (op->i_state >= 0) || st_out != (op->o_state >= 0) || op->o_active != 0)
+      return unsupported("stored-state fields do not match the QFunction");
+    OpField &ai = op->in[op->i_active], &ao = op->out[op->o_active], &qd = op->in[op->i_qdata];
+    if (!is_offsets(ai.rstr) || ai.rstr != ao.rstr || ai.basis != ao.basis || ai.basis == CEED_BASIS_COLLOCATED)
+      return unsupported("active input and output must share one offsets restriction and one basis");
+    if (ai.rstr->ncomp != 3 || ai.rstr->compstride != 1) return unsupported("active fields must be 3 interlaced components");
+    CeedBasis b = ai.basis;
+    const int P = b->P1d, Q = b->Q1d, Q3 = Q * Q * Q;
+    if (ai.rstr->elemsize != P * P * P) return unsupported("restriction element size is not P^3");
+    if (!is_strided(qd.rstr) || qd.rstr->elemsize != Q3 || qd.rstr->ncomp != 10 || qd.rstr->nelem != ai.rstr->nelem)
+      return unsupported("qdata must be a strided 10 x Q^3 field");
+    if (st_in) { OpField &s = op->in[op->i_state]; if (!is_strided(s.rstr) || s.rstr->elemsize != Q3 || s.rstr->ncomp != 9) return unsupported("state input must be strided 9 x Q^3"); }
+    if (st_out) { OpField &s = op->out[op->o_state]; if (!is_strided(s.rstr) || s.rstr->elemsize != Q3 || s.rstr->ncomp != 9) return unsupported("state output must be strided 9 x Q^3"); }
+    if (b->qmode != CEED_GAUSS && P == Q) { /* fine: any rule works, the tables carry it */ }
+    fill_tables(op->tables, b);
+    op->plan = PLAN_FUSED_GRAD;
+    return 0;
+  }
+  if (k == QF_SETUP_GEO) {
+    if (qf->in.size() != 2 || qf->out.size() != 1) return unsupported("SetupGeo takes (dx, weight) -> qdata");
+    if (qf->in[0].emode != CEED_EVAL_GRAD || qf->in[1].emode != CEED_EVAL_WEIGHT || qf->out[0].emode != CEED_EVAL_NONE)
+      return unsupported("SetupGeo eval modes must be GRAD, WEIGHT -> NONE");
+    OpField &x = op->in[0], &qd = op->out[0];
+    if (!is_offsets(x.rstr) || x.rstr->elemsize != 8 || x.rstr->ncomp != 3 || x.rstr->compstride != 1 || x.basis == CEED_BASIS_COLLOCATED || x.basis->P1d != 2)
+      return unsupported("coordinates must be trilinear (P=2), 3 interlaced components (setuplibceed.c:279,339)");
+    const int Q = x.basis->Q1d;
+    if (!is_strided(qd.rstr) || qd.rstr->ncomp != 10 || qd.rstr->elemsize != Q * Q * Q) return unsupported("qdata must be strided 10 x Q^3");
+    op->i_active = 0; op->i_weight = 1; op->o_qdata = 0;
+    fill_tables(op->tables, x.basis);
+    op->plan = PLAN_SETUP_GEO;
+    return 0;
+  }
+  if (k == QF_IDENTITY) {
+    if (qf->identity_size != 3) return unsupported("identity transfer operators carry 3 components");
+    OpField &fi = op->in[0], &fo = op->out[0];
+    const CeedEvalMode mi = qf->in[0].emode, mo = qf->out[0].emode;
+    if (!is_offsets(fi.rstr) || !is_offsets(fo.rstr) || fi.rstr->nelem != fo.rstr->nelem) return unsupported("transfer needs offsets restrictions on both sides");
+    if (fi.rstr->ncomp != 3 || fo.rstr->ncomp != 3 || fi.rstr->compstride != 1 || fo.rstr->compstride != 1) return unsupported("3 interlaced components expected");
+    if (mi == CEED_EVAL_INTERP && mo == CEED_EVAL_NONE && fi.basis != CEED_BASIS_COLLOCATED && fo.basis == CEED_BASIS_COLLOCATED) {
+      CeedBasis b = fi.basis;
+      if (fi.rstr->elemsize != b->P1d * b->P1d * b->P1d || fo.rstr->elemsize != b->Q1d * b->Q1d * b->Q1d) return unsupported("prolongation sizes");
+      fill_tables(op->tables, b);
+      op->plan = PLAN_PROLONG;
+    } else if (mi == CEED_EVAL_NONE && mo == CEED_EVAL_INTERP && fi.basis == CEED_BASIS_COLLOCATED && fo.basis != CEED_BASIS_COLLOCATED) {
+      CeedBasis b = fo.basis;
+      if (fo.rstr->elemsize != b->P1d * b->P1d * b->P1d || fi.rstr->elemsize != b->Q1d * b->Q1d * b->Q1d) return unsupported("restriction sizes");
+      fill_tables(op->tables, b);
+      op->plan = PLAN_RESTRICT;
+    } else return unsupported("identity operator is neither INTERP->NONE nor NONE->INTERP");
+    op->i_active = 0; op->o_active = 0;
+    return 0;
+  }
+  return unsupported("no kernel family");
+}
+
+static int read_phys(CeedQFunction qf, double *nu, double *E) {
+  // The reference passes sizeof(pointer) as the context size at setuplibceed.c:826; the
+  // context is the 16-byte {nu, E} struct behind the pointer (elasticity.h:33-36).
+  if (!qf->ctx) return ceed_error("QFunction '%s' needs its Physics context", qf->name.c_str());
+  const double *p = (const double *)qf->ctx;
+  *nu = p[0]; *E = p[1];
+  return 0;
+}
+
+struct TimerScope {
+  CeedOperator op; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+  TimerScope(CeedOperator o, hipStream_t st) : op(o), s(st) {
+    if (op->timing && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s);
+  }
+  ~TimerScope() {
+    if (a && b) { (void)hipEventRecord(b, s); op->events.emplace_back(a, b); }
+  }
+};
+
+static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool add) {
+  CHK(op_plan(op));
+  CeedQFunction qf = op->qf;
+  hipStream_t s = op->ceed->stream;
+  const char *kname = "";
+  switch (op->plan) {
+  case PLAN_FUSED_GRAD: {
+    OpField &ai = op->in[op->i_active];
+    CeedElemRestriction r = ai.rstr;
+    if (!in || in == CEED_VECTOR_NONE || !out || out == CEED_VECTOR_NONE) return ceed_error("active vectors required");
+    if (in->length < r->lsize || out->length < r->lsize) return ceed_error("active vector shorter than the restriction's L-size");
+    if (in == out) return ceed_error("in-place operator apply is not supported");
+    FusedGradArgs a{};
+    double *px, *py, *pq, *ps = nullptr;
+    CHK(vec_dev(in, false, &px));
+    CHK(vec_dev(out, true, &py));
+    CHK(vec_dev(op->in[op->i_qdata].vec, false, &pq));
+    a.offsets = op->d_off_flagged_in ? op->d_off_flagged_in : r->d_offsets;
+    a.x = px; a.y = py; a.qdata = pq;
+    if (op->i_state >= 0) { CHK(vec_dev(op->in[op->i_state].vec, false, &ps)); a.state_in = ps; }
+    if (op->o_state >= 0) {
+      CeedVector sv = op->out[op->o_state].vec;
+      if (!sv || sv == CEED_VECTOR_NONE || sv == CEED_VECTOR_ACTIVE) return ceed_error("state output needs a passive vector");
+      CHK(vec_dev(sv, true, &ps)); a.state_out = ps;  // every point is overwritten
+    }
+    a.nelem = r->nelem;
+    a.mask_in = (op->mask_mode & 1) ? 1 : 0; a.mask_out = (op->mask_mode & 2) ? 1 : 0;
+    CHK(read_phys(qf, &a.nu, &a.E));
+    if (!add) HIPCHK(hipMemsetAsync(py, 0, sizeof(double) * (size_t)out->length, s));
+    {
+      TimerScope ts(op, s);
+      hipError_t e = launch_fused_grad(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, a, s, &kname);
+      if (e == hipErrorInvalidValue && !*kname)
+        return ceed_error("no fused kernel instantiated for P=%d Q=%d QFunction %s", ai.basis->P1d, ai.basis->Q1d, qf->name.c_str());
+      HIPCHK(e);
+    }
+    op->launches++;
+    break;
+  }
+  case PLAN_SETUP_GEO: {
+    OpField &x = op->in[0];
+    if (!in || in->length < x.rstr->lsize) return ceed_error("coordinate vector too short");
+    SetupGeoArgs a{};
+    double *px, *pq;
+    CHK(vec_dev(in, false, &px));
+    CHK(vec_dev(out, true, &pq));
+    a.off_x = x.rstr->d_offsets; a.xcoord = px; a.qdata = pq; a.nelem = x.rstr->nelem;
+    if ((size_t)out->length < (size_t)a.nelem * 10 * x.basis->Q1d * x.basis->Q1d * x.basis->Q1d) return ceed_error("qdata vector too short");
+    TimerScope ts(op, s);
+    hipError_t e = launch_setup_geo(x.basis->Q1d, op->tables, a, s, &kname);
+    if (e == hipErrorInvalidValue && !*kname) return ceed_error("no setup_geo kernel for Q=%d", x.basis->Q1d);
+    HIPCHK(e);
+    op->launches++;
+    break;
+  }
+  case PLAN_PROLONG:
+  case PLAN_RESTRICT: {
+    const bool pro = op->plan == PLAN_PROLONG;
+    CeedElemRestriction rc = pro ? op->in[0].rstr : op->out[0].rstr, rf = pro ? op->out[0].rstr : op->in[0].rstr;
+    CeedBasis b = pro ? op->in[0].basis : op->out[0].basis;
+    if (in == out) return ceed_error("in-place operator apply is not supported");
+    if (in->length < (pro ? rc : rf)->lsize || out->length < (pro ? rf : rc)->lsize) return ceed_error("transfer vector too short");
+    TransferArgs a{};
+    double *px, *py, *psc = nullptr;
+    CHK(vec_dev(in, false, &px));
+    CHK(vec_dev(out, true, &py));
+    if (op->scale) { CHK(vec_dev(op->scale, false, &psc)); if (op->scale->length < rf->lsize) return ceed_error("scale vector too short"); }
+    // flagged arrays: *_in belongs to the input side's restriction, *_out to the output side's
+    const uint32_t *fin = op->d_off_flagged_in, *fout = op->d_off_flagged_out;
+    a.off_c = pro ? (fin ? fin : rc->d_offsets) : (fout ? fout : rc->d_offsets);
+    a.off_f = pro ? (fout ? fout : rf->d_offsets) : (fin ? fin : rf->d_offsets);
+    a.x = px; a.y = py; a.scale_f = psc; a.nelem = rc->nelem;
+    a.mask_in = (op->mask_mode & 1) ? 1 : 0; a.mask_out = (op->mask_mode & 2) ? 1 : 0;
+    if (!add) HIPCHK(hipMemsetAsync(py, 0, sizeof(double) * (size_t)out->length, s));
+    TimerScope ts(op, s);
+    hipError_t e = launch_transfer(b->P1d, b->Q1d, pro, op->tables, a, s, &kname);
+    if (e == hipErrorInvalidValue && !*kname) return ceed_error("no transfer kernel for Pc=%d Pf=%d", b->P1d, b->Q1d);
+    HIPCHK(e);
+    op->launches++;
+    break;
+  }
+  default: return ceed_error("operator has no plan");
+  }
+  op->kernel_name = kname;
+  return 0;
+}
+
+extern "C" int CeedOperatorApply(CeedOperator op, CeedVector in, CeedVector out, CeedRequest *) {
+  if (op->composite) {
+    CHK(CeedVectorSetValue(out, 0.));
+    for (CeedOperator s : op->sub) CHK(op_apply_single(s, in, out, true));
+    return 0;
+  }
+  return op_apply_single(op, in, out, false);
+}
+extern "C" int CeedOperatorApplyAdd(CeedOperator op, CeedVector in, CeedVector out, CeedRequest *) {
+  if (op->composite) { for (CeedOperator s : op->sub) CHK(op_apply_single(s, in, out, true)); return 0; }
+  return op_apply_single(op, in, out, true);
+}
+
+extern "C" int CeedOperatorLinearAssembleDiagonal(CeedOperator op, CeedVector assembled, CeedRequest *) {
+  if (op->composite) return ceed_error("diagonal of a composite operator not supported");
+  CHK(op_plan(op));
+  if (op->plan != PLAN_FUSED_GRAD || op->o_state >= 0) return ceed_error("diagonal assembly is provided for the Jacobian operators");
+  CeedQFunction qf = op->qf;
+  hipStream_t s = op->ceed->stream;
+  OpField &ai = op->in[op->i_active];
+  DiagArgs a{};
+  double *pd, *pq, *ps = nullptr;
+  CHK(vec_dev(assembled, true, &pd));
+  CHK(vec_dev(op->in[op->i_qdata].vec, false, &pq));
+  if (op->i_state >= 0) CHK(vec_dev(op->in[op->i_state].vec, false, &ps));
+  if (assembled->length < ai.rstr->lsize) return ceed_error("diagonal vector too short");
+  a.offsets = op->d_off_flagged_in ? op->d_off_flagged_in : ai.rstr->d_offsets;
+  a.diag = pd; a.qdata = pq; a.state_in = ps; a.nelem = ai.rstr->nelem; a.mask_out = (op->mask_mode & 2) ? 1 : 0;
+  CHK(read_phys(qf, &a.nu, &a.E));
+  HIPCHK(hipMemsetAsync(pd, 0, sizeof(double) * (size_t)assembled->length, s));  // overwrite semantics (matops.c:227)
+  const char *kname = "";
+  hipError_t e = launch_diag(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, a, s, &kname);
+  if (e == hipErrorInvalidValue && !*kname) return ceed_error("no diagonal kernel for P=%d Q=%d %s", ai.basis->P1d, ai.basis->Q1d, qf->name.c_str());
+  HIPCHK(e);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// extensions
+// ---------------------------------------------------------------------------
+extern "C" int CeedXOperatorGetKernelName(CeedOperator op, const char **name) { *name = op->kernel_name.c_str(); return 0; }
+
+static int make_flagged(CeedElemRestriction r, const unsigned char *mask, CeedInt lsize, uint32_t **dev) {
+  if (lsize < r->lsize) return ceed_error("Dirichlet mask shorter than the L-vector");
+  std::vector<uint32_t> fl(r->h_offsets.size());
+  for (size_t i = 0; i < fl.size(); i++) {
+    uint32_t o = (uint32_t)r->h_offsets[i], f = 0;
+    for (int c = 0; c < r->ncomp && c < 3; c++) if (mask[(size_t)o + (size_t)c * r->compstride]) f |= 1u << c;
+    fl[i] = o | (f << OFF_FLAG_SHIFT);
+  }
+  HIPCHK(hipMalloc((void **)dev, sizeof(uint32_t) * (fl.size() ? fl.size() : 1)));
+  HIPCHK(hipMemcpy(*dev, fl.data(), sizeof(uint32_t) * fl.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+// mode: 1 = masked entries read as zero, 2 = masked rows dropped, 3 = both (default for mode 0)
+extern "C" int CeedXOperatorSetDirichletMaskMode(CeedOperator op, CeedMemType mtype, const unsigned char *mask,
+                                                 CeedInt lsize, const unsigned char *mask_out, CeedInt lsize_out, int mode) {
+  if (op->composite) return ceed_error("set the mask on the sub-operators");
+  CHK(op_plan(op));
+  op_free_flags(op);
+  if (!mask && !mask_out) return 0;
+  if (mtype != CEED_MEM_HOST) return ceed_error("pass the Dirichlet mask in host memory (it is folded into the offsets once)");
+  if (op->plan == PLAN_FUSED_GRAD) {
+    CHK(make_flagged(op->in[op->i_active].rstr, mask, lsize, &op->d_off_flagged_in));
+    op->d_off_flagged_out = op->d_off_flagged_in;
+  } else if (op->plan == PLAN_PROLONG || op->plan == PLAN_RESTRICT) {
+    if (!mask || !mask_out) return ceed_error("transfer operators need the input-side and the output-side mask");
+    CHK(make_flagged(op->in[0].rstr, mask, lsize, &op->d_off_flagged_in));
+    CHK(make_flagged(op->out[0].rstr, mask_out, lsize_out, &op->d_off_flagged_out));
+  } else return ceed_error("this operator takes no Dirichlet mask");
+  op->mask_mode = mode ? mode : 3;
+  return 0;
+}
+extern "C" int CeedXOperatorSetDirichletMask(CeedOperator op, CeedMemType mtype, const unsigned char *mask, CeedInt lsize) {
+  return CeedXOperatorSetDirichletMaskMode(op, mtype, mask, lsize, nullptr, 0, 3);
+}
+// Fine-side multiplicity scale of the transfer operators (matops.c:149,176); NULL clears.
+extern "C" int CeedXOperatorSetFineScale(CeedOperator op, CeedVector scale) {
+  CeedVectorDestroy(&op->scale);
+  if (scale && scale != CEED_VECTOR_NONE) { op->scale = scale; scale->refcount++; }
+  return 0;
+}
+extern "C" int CeedXOperatorSetTiming(CeedOperator op, int enable) {
+  op->timing = enable != 0;
+  for (auto &ev : op->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  op->events.clear(); op->ms_accum = 0.; op->launches = 0;
+  return 0;
+}
+extern "C" int CeedXOperatorGetTiming(CeedOperator op, double *ms, int64_t *launches) {
+  for (auto &ev : op->events) {
+    float t = 0.f;
+    HIPCHK(hipEventSynchronize(ev.second));
+    HIPCHK(hipEventElapsedTime(&t, ev.first, ev.second));
+    op->ms_accum += t;
+    (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
+  }
+  op->events.clear();
+  *ms = op->ms_accum; *launches = op->launches;
+  return 0;
+}
+
+// Vector helpers standing in for the PETSc Vec calls of src/matops.c on device data.
+extern "C" int CeedXVectorPointwiseMult(CeedVector w, CeedVector x, CeedVector y) {
+  double *pw, *px, *py;
+  CHK(vec_dev(x, false, &px)); CHK(vec_dev(y, false, &py)); CHK(vec_dev(w, true, &pw));
+  HIPCHK(launch_pointwise_mult(pw, px, py, (size_t)w->length, w->ceed->stream));
+  return 0;
+}
+extern "C" int CeedXVectorAXPBY(CeedVector y, double a, CeedVector x, double b) {
+  double *px, *py;
+  CHK(vec_dev(x, false, &px)); CHK(vec_dev(y, true, &py));
+  HIPCHK(launch_axpby(py, a, px, b, (size_t)y->length, y->ceed->stream));
+  return 0;
+}
+extern "C" int CeedXVectorDot(CeedVector x, CeedVector y, CeedVector weight, double *result) {
+  double *px, *py, *pw = nullptr, *dres;
+  CHK(vec_dev(x, false, &px)); CHK(vec_dev(y, false, &py));
+  if (weight && weight != CEED_VECTOR_NONE) CHK(vec_dev(weight, false, &pw));
+  hipStream_t s = x->ceed->stream;
+  HIPCHK(hipMalloc((void **)&dres, sizeof(double)));
+  HIPCHK(hipMemsetAsync(dres, 0, sizeof(double), s));
+  HIPCHK(launch_dot(px, py, pw, (size_t)x->length, dres, s));
+  HIPCHK(hipMemcpyAsync(result, dres, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipFree(dres));
+  return 0;
+}

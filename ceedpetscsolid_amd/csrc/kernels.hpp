@@ -1,0 +1,103 @@
+// kernels.hpp -- host-visible launch interface of the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace cps {
+
+enum QFKind : int {
+  QF_NONE = 0,
+  QF_SETUP_GEO,
+  QF_LINELAS,     // LinElasF and LinElasdF: same linear map
+  QF_HYPERSS_F,
+  QF_HYPERSS_DF,
+  QF_HYPERFS_F,
+  QF_HYPERFS_DF,
+  QF_IDENTITY,
+  QF_CONST_FORCE,
+  QF_MMS_FORCE,
+  QF_MMS_TRUE,
+};
+
+constexpr int MAXN1D = 8;  // largest P or Q supported by the kernel tables
+
+// 1-D tables handed to kernels by value (kernarg segment -> LDS once per block).
+struct BasisTables {
+  double interp[MAXN1D * MAXN1D];  // B[q][p], Q x P row-major (CeedBasis interp1d)
+  double colo[MAXN1D * MAXN1D];    // Dq[q][m], Q x Q: derivative of the Lagrange basis on the
+                                   // quadrature points, evaluated there (collocated gradient)
+  double grad[MAXN1D * MAXN1D];    // G[q][p], Q x P (CeedBasis grad1d; diagonal assembly)
+  double qw[MAXN1D];               // 1-D quadrature weights
+};
+
+// Offsets carry the Dirichlet flags of the three components of a node in their
+// top bits (set by CeedXOperatorSetDirichletMask); plain offsets have none.
+constexpr uint32_t OFF_MASK = 0x1FFFFFFFu;
+constexpr int OFF_FLAG_SHIFT = 29;
+
+struct FusedGradArgs {
+  const uint32_t *offsets;  // [nelem][P^3] (flagged)
+  const double *x;          // active input L-vector, interlaced [node][3]
+  double *y;                // active output L-vector (pre-zeroed; atomically accumulated)
+  const double *qdata;      // [nelem][10][Q^3]
+  const double *state_in;   // [nelem][9][Q^3] or null
+  double *state_out;        // [nelem][9][Q^3] or null
+  int nelem;
+  int mask_in, mask_out;    // honour the Dirichlet flags on gather / scatter
+  double nu, E;
+};
+
+struct TransferArgs {
+  const uint32_t *off_c;  // coarse [nelem][Pc^3]
+  const uint32_t *off_f;  // fine   [nelem][Pf^3]
+  const double *x;
+  double *y;
+  const double *scale_f;  // optional per-dof scale on the fine side (multiplicity^-1), or null
+  int nelem;
+  int mask_in, mask_out;
+};
+
+struct SetupGeoArgs {
+  const uint32_t *off_x;  // [nelem][8]
+  const double *xcoord;   // interlaced [vertex][3]
+  double *qdata;          // [nelem][10][Q^3]
+  int nelem;
+};
+
+struct DiagArgs {
+  const uint32_t *offsets;
+  double *diag;  // pre-zeroed L-vector
+  const double *qdata, *state_in;
+  int nelem, mask_out;
+  double nu, E;
+};
+
+// Each returns hipSuccess or the launch error; `name` receives a static string
+// naming the instantiation, or the call returns hipErrorInvalidValue when the
+// (P, Q, qf) combination is not instantiated.
+hipError_t launch_fused_grad(int P, int Q, int qf, const BasisTables &t, const FusedGradArgs &a,
+                             hipStream_t s, const char **name);
+hipError_t launch_transfer(int Pc, int Pf, bool prolong, const BasisTables &t, const TransferArgs &a,
+                           hipStream_t s, const char **name);
+hipError_t launch_setup_geo(int Q, const BasisTables &t, const SetupGeoArgs &a, hipStream_t s,
+                            const char **name);
+hipError_t launch_diag(int P, int Q, int qf, const BasisTables &t, const DiagArgs &a, hipStream_t s,
+                       const char **name);
+
+// Vector / restriction utilities.
+hipError_t launch_set_value(double *v, size_t n, double val, hipStream_t s);
+hipError_t launch_reciprocal(double *v, size_t n, hipStream_t s);
+hipError_t launch_pointwise_mult(double *w, const double *x, const double *y, size_t n, hipStream_t s);
+hipError_t launch_axpby(double *y, double a, const double *x, double b, size_t n, hipStream_t s);
+hipError_t launch_masked_copy(double *dst, const double *src, const unsigned char *mask, size_t n,
+                              hipStream_t s);  // dst = mask ? 0 : src
+hipError_t launch_rstr_gather(const uint32_t *off, int nelem, int elemsize, int ncomp, int compstride,
+                              const double *l, double *e, hipStream_t s);
+hipError_t launch_rstr_scatter_add(const uint32_t *off, int nelem, int elemsize, int ncomp,
+                                   int compstride, const double *e, double *l, hipStream_t s);
+hipError_t launch_multiplicity(const uint32_t *off, int nelem, int elemsize, int ncomp, int compstride,
+                               double *l, hipStream_t s);
+hipError_t launch_dot(const double *x, const double *y, const double *w, size_t n, double *result_dev,
+                      hipStream_t s);  // *result_dev (pre-zeroed) += sum w_i x_i y_i (w may be null)
+
+}  // namespace cps

@@ -1,0 +1,58 @@
+// kernels_fused_inst.hip -- instantiations of the fused operator kernel for one
+// quadrature size.  Compiled once per -DCPS_Q=<Q> (see Makefile) so the
+// instantiations build in parallel; each object exports launch_fused_grad_q<Q>.
+//
+// Node counts P per Q follow the level-degree rules of the reference
+// (cloptions.c:195-225): the fine level has P = Q (qextra = 0), coarse levels
+// use degrees 1, 2, 4 (logarithmic) with the FINE quadrature (setuplibceed.c:757).
+// Residual kernels (which write the stored state) only exist on the fine level.
+#include "kernel_fused_grad.hpp"
+
+#ifndef CPS_Q
+#error "compile with -DCPS_Q=<points per direction>"
+#endif
+
+namespace cps {
+
+#define CPS_CAT_(a, b) a##b
+#define CPS_CAT(a, b) CPS_CAT_(a, b)
+#define CPS_STR_(x) #x
+#define CPS_STR(x) CPS_STR_(x)
+
+template <int P, int QF>
+static hipError_t go(const BasisTables &t, const FusedGradArgs &a, hipStream_t s) {
+  return launch_fused_grad_t<P, CPS_Q, QF>(t, a, s);
+}
+
+#define CPS_CASE(Pv, QFv, QFname)                                                   \
+  if (P == Pv && qf == QFv) {                                                       \
+    *name = "fused_grad<P=" #Pv ",Q=" CPS_STR(CPS_Q) "," QFname ">";                \
+    return go<Pv, QFv>(t, a, s);                                                    \
+  }
+#define CPS_JACOBIANS(Pv)              \
+  CPS_CASE(Pv, QF_LINELAS, "LinElas")  \
+  CPS_CASE(Pv, QF_HYPERSS_DF, "HyperSSdF") \
+  CPS_CASE(Pv, QF_HYPERFS_DF, "HyperFSdF")
+
+hipError_t CPS_CAT(launch_fused_grad_q, CPS_Q)(int P, int qf, const BasisTables &t,
+                                               const FusedGradArgs &a, hipStream_t s,
+                                               const char **name) {
+  CPS_JACOBIANS(CPS_Q)
+  CPS_CASE(CPS_Q, QF_HYPERSS_F, "HyperSSF")
+  CPS_CASE(CPS_Q, QF_HYPERFS_F, "HyperFSF")
+#if CPS_Q > 2
+  CPS_JACOBIANS(2)
+#endif
+#if CPS_Q > 3
+  CPS_JACOBIANS(3)
+#endif
+#if CPS_Q > 4
+  CPS_JACOBIANS(4)
+#endif
+#if CPS_Q > 5
+  CPS_JACOBIANS(5)
+#endif
+  return hipErrorInvalidValue;
+}
+
+}  // namespace cps

@@ -1,0 +1,354 @@
+// kernels_misc.hip -- geometry set-up, p-multigrid transfer, diagonal assembly,
+// restriction and vector utilities, and the (P,Q,qf) dispatch tables.
+#include "kernels_common.hpp"
+#include "qfunctions_device.hpp"
+
+namespace cps {
+
+// ===========================================================================
+// SetupGeo operator (setuplibceed.c:370-389): coordinates (P=2 per direction,
+// :279,339) -> d x / d xi at the quadrature points -> qdata[10].
+// ===========================================================================
+template <int Q>
+__global__ __launch_bounds__(Geom<Q>::BLOCK) void k_setup_geo(const BasisTables tab,
+                                                               const SetupGeoArgs a) {
+  using G = Geom<Q>;
+  constexpr int Q3 = G::Q3, TPE = G::TPE, EPB = G::EPB;
+  __shared__ double sx[EPB][24];
+  const int tid = threadIdx.x, el = tid / TPE, q = tid % TPE;
+  const int e = blockIdx.x * EPB + el;
+  const bool live = e < a.nelem;
+  if (live && q < 8) {
+    const uint32_t base = a.off_x[(size_t)e * 8 + q] & OFF_MASK;
+#pragma unroll
+    for (int c = 0; c < 3; c++) sx[el][c * 8 + q] = a.xcoord[base + c];
+  }
+  __syncthreads();
+  if (!live || q >= Q3) return;
+  const int i = q % Q, j = (q / Q) % Q, k = q / (Q * Q);
+  // tables of the coordinate basis: B[q][p], G[q][p] with P = 2
+  const double bi[2] = {tab.interp[i * 2], tab.interp[i * 2 + 1]}, gi[2] = {tab.grad[i * 2], tab.grad[i * 2 + 1]};
+  const double bj[2] = {tab.interp[j * 2], tab.interp[j * 2 + 1]}, gj[2] = {tab.grad[j * 2], tab.grad[j * 2 + 1]};
+  const double bk[2] = {tab.interp[k * 2], tab.interp[k * 2 + 1]}, gk[2] = {tab.grad[k * 2], tab.grad[k * 2 + 1]};
+  double Jg[9];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    double s0 = 0., s1 = 0., s2 = 0.;
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int aa = 0; aa < 2; aa++) {
+          const double x = sx[el][c * 8 + aa + 2 * b + 4 * cc];
+          s0 += gi[aa] * bj[b] * bk[cc] * x;
+          s1 += bi[aa] * gj[b] * bk[cc] * x;
+          s2 += bi[aa] * bj[b] * gk[cc] * x;
+        }
+    Jg[0 * 3 + c] = s0; Jg[1 * 3 + c] = s1; Jg[2 * 3 + c] = s2;
+  }
+  double qd[10];
+  qf_setup_geo(Jg, tab.qw[i] * tab.qw[j] * tab.qw[k], qd);
+  double *out = a.qdata + (size_t)e * 10 * Q3 + q;
+#pragma unroll
+  for (int c = 0; c < 10; c++) out[c * Q3] = qd[c];
+}
+
+template <int Q>
+static hipError_t setup_geo_t(const BasisTables &t, const SetupGeoArgs &a, hipStream_t s) {
+  using G = Geom<Q>;
+  if (a.nelem <= 0) return hipSuccess;
+  hipLaunchKernelGGL((k_setup_geo<Q>), dim3((a.nelem + G::EPB - 1) / G::EPB), dim3(G::BLOCK), 0, s, t, a);
+  return hipGetLastError();
+}
+hipError_t launch_setup_geo(int Q, const BasisTables &t, const SetupGeoArgs &a, hipStream_t s,
+                            const char **name) {
+#define CPS_SG(Qv) case Qv: *name = "setup_geo<Q=" #Qv ">"; return setup_geo_t<Qv>(t, a, s);
+  switch (Q) { CPS_SG(2) CPS_SG(3) CPS_SG(4) CPS_SG(5) CPS_SG(6) CPS_SG(7) CPS_SG(8) }
+  return hipErrorInvalidValue;
+}
+
+// ===========================================================================
+// p-multigrid transfer (setuplibceed.c:847-862; matops.c:115-203).
+// PROLONG : coarse gather -> interp Pc->Pf (GLL points = fine nodes) -> fine
+//           scatter-add, each contribution times scale_f (the 1/multiplicity
+//           of matops.c:149 folded into the scatter).
+// RESTRICT: fine gather times scale_f (matops.c:176) -> interp^T -> coarse
+//           scatter-add.
+// ===========================================================================
+template <int PC, int PF, bool PROLONG>
+__global__ __launch_bounds__(Geom<PF>::BLOCK) void k_transfer(const BasisTables tab, const TransferArgs a) {
+  using G = Geom<PF>;
+  constexpr int F3 = G::Q3, C3 = PC * PC * PC, TPE = G::TPE, EPB = G::EPB, BLOCK = G::BLOCK;
+  __shared__ double sB[PF * PC];
+  __shared__ double slab[EPB][9 * F3];
+  const int tid = threadIdx.x, el = tid / TPE, q = tid % TPE;
+  const int e = blockIdx.x * EPB + el;
+  const bool live = e < a.nelem;
+  double *R0 = slab[el], *R1 = R0 + 3 * F3, *R2 = R0 + 6 * F3;
+  stage_table<PF * PC, BLOCK>(tab.interp, sB);
+  const bool cnode = live && q < C3, fnode = live && q < F3;
+  uint32_t offc = cnode ? a.off_c[(size_t)e * C3 + q] : 0u;
+  uint32_t offf = fnode ? a.off_f[(size_t)e * F3 + q] : 0u;
+  if constexpr (PROLONG) {
+    if (q < C3) {
+      const uint32_t base = offc & OFF_MASK, fl = a.mask_in ? (offc >> OFF_FLAG_SHIFT) : 0u;
+#pragma unroll
+      for (int c = 0; c < 3; c++) R0[c * C3 + q] = (cnode && !((fl >> c) & 1u)) ? a.x[base + c] : 0.;
+    }
+    __syncthreads();
+    double v[3];
+    interp_forward<PC, PF>(q, R0, R1, R2, sB, v);
+    if (fnode) {
+      const uint32_t base = offf & OFF_MASK, fl = a.mask_out ? (offf >> OFF_FLAG_SHIFT) : 0u;
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+        if (!((fl >> c) & 1u)) atomic_add_f64(a.y + base + c, a.scale_f ? v[c] * a.scale_f[base + c] : v[c]);
+    }
+  } else {
+    if (q < F3) {
+      const uint32_t base = offf & OFF_MASK, fl = a.mask_in ? (offf >> OFF_FLAG_SHIFT) : 0u;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        double xv = (fnode && !((fl >> c) & 1u)) ? a.x[base + c] : 0.;
+        if (fnode && a.scale_f) xv *= a.scale_f[base + c];
+        R0[c * F3 + q] = xv;
+      }
+    }
+    __syncthreads();
+    double v[3];
+    interp_transpose<PC, PF>(q, R0, R1, R2, sB, v);
+    if (cnode) {
+      const uint32_t base = offc & OFF_MASK, fl = a.mask_out ? (offc >> OFF_FLAG_SHIFT) : 0u;
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+        if (!((fl >> c) & 1u)) atomic_add_f64(a.y + base + c, v[c]);
+    }
+  }
+}
+template <int PC, int PF>
+static hipError_t transfer_t(bool prolong, const BasisTables &t, const TransferArgs &a, hipStream_t s) {
+  using G = Geom<PF>;
+  if (a.nelem <= 0) return hipSuccess;
+  const dim3 grid((a.nelem + G::EPB - 1) / G::EPB), block(G::BLOCK);
+  if (prolong) hipLaunchKernelGGL((k_transfer<PC, PF, true>), grid, block, 0, s, t, a);
+  else hipLaunchKernelGGL((k_transfer<PC, PF, false>), grid, block, 0, s, t, a);
+  return hipGetLastError();
+}
+hipError_t launch_transfer(int Pc, int Pf, bool prolong, const BasisTables &t, const TransferArgs &a,
+                           hipStream_t s, const char **name) {
+#define CPS_TR(C, F)                                                                  \
+  if (Pc == C && Pf == F) {                                                           \
+    *name = prolong ? "prolong<Pc=" #C ",Pf=" #F ">" : "restrict<Pc=" #C ",Pf=" #F ">"; \
+    return transfer_t<C, F>(prolong, t, a, s);                                        \
+  }
+  // adjacent level pairs of the logarithmic (1,2,4,..,p) and uniform ladders up to p = 7
+  CPS_TR(2, 3) CPS_TR(3, 4) CPS_TR(3, 5) CPS_TR(4, 5) CPS_TR(5, 6) CPS_TR(5, 7) CPS_TR(6, 7) CPS_TR(5, 8)
+  CPS_TR(7, 8) CPS_TR(2, 4) CPS_TR(2, 5)
+  return hipErrorInvalidValue;
+}
+
+// ===========================================================================
+// Diagonal of B^T D B (matops.c:227).  D's (d,c),(d',c) entries come
+// from the Jacobian physics applied to unit reference gradients.
+// ===========================================================================
+template <int P, int Q, int QF>
+__global__ __launch_bounds__(Geom<Q>::TPE) void k_diag(const BasisTables tab, const DiagArgs a) {
+  using G = Geom<Q>;
+  constexpr int Q3 = G::Q3, P3 = P * P * P, TPE = G::TPE;
+  constexpr bool ST_IN = QFTraits<QF>::state_in;
+  extern __shared__ double dyn[];
+  double *sB = dyn, *sG = sB + Q * P, *sD = sG + Q * P;  // sD[27][Q3]: ((c*3+d)*3+d')
+  const int q = threadIdx.x, e = blockIdx.x;
+  for (int i = q; i < Q * P; i += TPE) { sB[i] = tab.interp[i]; sG[i] = tab.grad[i]; }
+  if (q < Q3) {
+    double qd[10], st[9], dv[9], sto[9], ug[9];
+    const double *qp = a.qdata + (size_t)e * 10 * Q3 + q;
+#pragma unroll
+    for (int c = 0; c < 10; c++) qd[c] = qp[c * Q3];
+    if constexpr (ST_IN) {
+      const double *sp = a.state_in + (size_t)e * 9 * Q3 + q;
+#pragma unroll
+      for (int c = 0; c < 9; c++) st[c] = sp[c * Q3];
+    }
+    for (int din = 0; din < 3; din++)
+      for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int s = 0; s < 9; s++) ug[s] = (s == din * 3 + c) ? 1. : 0.;
+        qf_point<QF>(Phys{a.nu, a.E}, ug, qd, st, dv, sto);
+        for (int dout = 0; dout < 3; dout++) sD[((c * 3 + dout) * 3 + din) * Q3 + q] = dv[dout * 3 + c];
+      }
+  }
+  __syncthreads();
+  if (q < P3) {
+    const int na = q % P, nb = (q / P) % P, nc = q / (P * P);
+    double acc[3] = {0., 0., 0.};
+    for (int k = 0; k < Q; k++) {
+      const double bk = sB[k * P + nc], gk = sG[k * P + nc];
+      for (int j = 0; j < Q; j++) {
+        const double bj = sB[j * P + nb], gj = sG[j * P + nb];
+        for (int i = 0; i < Q; i++) {
+          const double bi = sB[i * P + na], gi = sG[i * P + na];
+          const double g[3] = {gi * bj * bk, bi * gj * bk, bi * bj * gk};
+          const int qq = (k * Q + j) * Q + i;
+#pragma unroll
+          for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int d = 0; d < 3; d++)
+#pragma unroll
+              for (int d2 = 0; d2 < 3; d2++) acc[c] += g[d] * sD[((c * 3 + d) * 3 + d2) * Q3 + qq] * g[d2];
+        }
+      }
+    }
+    const uint32_t off = a.offsets[(size_t)e * P3 + q];
+    const uint32_t base = off & OFF_MASK, fl = a.mask_out ? (off >> OFF_FLAG_SHIFT) : 0u;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+      if (!((fl >> c) & 1u)) atomic_add_f64(a.diag + base + c, acc[c]);
+  }
+}
+template <int P, int Q, int QF>
+static hipError_t diag_t(const BasisTables &t, const DiagArgs &a, hipStream_t s) {
+  using G = Geom<Q>;
+  if (a.nelem <= 0) return hipSuccess;
+  const size_t lds = sizeof(double) * (2 * Q * P + 27 * G::Q3);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t er = hipFuncSetAttribute((const void *)k_diag<P, Q, QF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (er != hipSuccess) return er;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_diag<P, Q, QF>), dim3(a.nelem), dim3(G::TPE), lds, s, t, a);
+  return hipGetLastError();
+}
+hipError_t launch_diag(int P, int Q, int qf, const BasisTables &t, const DiagArgs &a, hipStream_t s,
+                       const char **name) {
+#define CPS_DG(Pv, Qv, QFv, nm)                                   \
+  if (P == Pv && Q == Qv && qf == QFv) {                          \
+    *name = "diag<P=" #Pv ",Q=" #Qv "," nm ">";                   \
+    return diag_t<Pv, Qv, QFv>(t, a, s);                          \
+  }
+#define CPS_DG3(Pv, Qv) CPS_DG(Pv, Qv, QF_LINELAS, "LinElas") CPS_DG(Pv, Qv, QF_HYPERSS_DF, "HyperSSdF") \
+  CPS_DG(Pv, Qv, QF_HYPERFS_DF, "HyperFSdF")
+  CPS_DG3(2, 2) CPS_DG3(2, 3) CPS_DG3(3, 3) CPS_DG3(2, 4) CPS_DG3(3, 4) CPS_DG3(4, 4)
+  CPS_DG3(2, 5) CPS_DG3(3, 5) CPS_DG3(4, 5) CPS_DG3(5, 5) CPS_DG3(2, 7) CPS_DG3(3, 7) CPS_DG3(5, 7) CPS_DG3(7, 7)
+  return hipErrorInvalidValue;
+}
+
+// ===========================================================================
+// Fused-operator dispatch over the per-Q objects (kernels_fused_inst.hip).
+// ===========================================================================
+#define CPS_DECL_Q(Qv) hipError_t launch_fused_grad_q##Qv(int, int, const BasisTables &, const FusedGradArgs &, hipStream_t, const char **);
+CPS_DECL_Q(2) CPS_DECL_Q(3) CPS_DECL_Q(4) CPS_DECL_Q(5) CPS_DECL_Q(6) CPS_DECL_Q(7) CPS_DECL_Q(8)
+hipError_t launch_fused_grad(int P, int Q, int qf, const BasisTables &t, const FusedGradArgs &a,
+                             hipStream_t s, const char **name) {
+  switch (Q) {
+    case 2: return launch_fused_grad_q2(P, qf, t, a, s, name);
+    case 3: return launch_fused_grad_q3(P, qf, t, a, s, name);
+    case 4: return launch_fused_grad_q4(P, qf, t, a, s, name);
+    case 5: return launch_fused_grad_q5(P, qf, t, a, s, name);
+    case 6: return launch_fused_grad_q6(P, qf, t, a, s, name);
+    case 7: return launch_fused_grad_q7(P, qf, t, a, s, name);
+    case 8: return launch_fused_grad_q8(P, qf, t, a, s, name);
+  }
+  return hipErrorInvalidValue;
+}
+
+// ===========================================================================
+// Vector and restriction utilities (HBM-bound, grid-stride, 2048-block cap).
+// ===========================================================================
+static inline dim3 stream_grid(size_t n) {
+  size_t b = (n + 255) / 256;
+  return dim3((unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b)));
+}
+__global__ void k_set_value(double *v, size_t n, double val) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) v[i] = val;
+}
+__global__ void k_reciprocal(double *v, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    if (fabs(v[i]) > 1e-300) v[i] = 1. / v[i];
+}
+__global__ void k_pointwise_mult(double *w, const double *x, const double *y, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) w[i] = x[i] * y[i];
+}
+__global__ void k_axpby(double *y, double a, const double *x, double b, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = a * x[i] + (b == 0. ? 0. : b * y[i]);
+}
+__global__ void k_masked_copy(double *dst, const double *src, const unsigned char *mask, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = mask[i] ? 0. : src[i];
+}
+// E-layout [e][c][n]
+__global__ void k_rstr(const uint32_t *off, size_t total, int elemsize, int ncomp, int compstride,
+                       const double *src, double *dst, int mode) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i % elemsize, ec = i / elemsize, c = ec % ncomp, e = ec / ncomp;
+    const size_t li = (size_t)(off[e * elemsize + n] & OFF_MASK) + c * (size_t)compstride;
+    if (mode == 0) dst[i] = src[li];
+    else if (mode == 1) atomic_add_f64(dst + li, src[i]);
+    else atomic_add_f64(dst + li, 1.0);
+  }
+}
+__global__ void k_dot(const double *x, const double *y, const double *w, size_t n, double *result) {
+  double s = 0.;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    s += (w ? w[i] : 1.) * x[i] * y[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomic_add_f64(result, part[0] + part[1] + part[2] + part[3]);
+}
+
+hipError_t launch_set_value(double *v, size_t n, double val, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_set_value, stream_grid(n), dim3(256), 0, s, v, n, val);
+  return hipGetLastError();
+}
+hipError_t launch_reciprocal(double *v, size_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_reciprocal, stream_grid(n), dim3(256), 0, s, v, n);
+  return hipGetLastError();
+}
+hipError_t launch_pointwise_mult(double *w, const double *x, const double *y, size_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_pointwise_mult, stream_grid(n), dim3(256), 0, s, w, x, y, n);
+  return hipGetLastError();
+}
+hipError_t launch_axpby(double *y, double a, const double *x, double b, size_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_axpby, stream_grid(n), dim3(256), 0, s, y, a, x, b, n);
+  return hipGetLastError();
+}
+hipError_t launch_masked_copy(double *dst, const double *src, const unsigned char *mask, size_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_masked_copy, stream_grid(n), dim3(256), 0, s, dst, src, mask, n);
+  return hipGetLastError();
+}
+static hipError_t rstr(const uint32_t *off, int nelem, int elemsize, int ncomp, int compstride,
+                       const double *src, double *dst, int mode, hipStream_t s) {
+  const size_t total = (size_t)nelem * elemsize * ncomp;
+  if (!total) return hipSuccess;
+  hipLaunchKernelGGL(k_rstr, stream_grid(total), dim3(256), 0, s, off, total, elemsize, ncomp, compstride, src, dst, mode);
+  return hipGetLastError();
+}
+hipError_t launch_rstr_gather(const uint32_t *off, int nelem, int elemsize, int ncomp, int compstride,
+                              const double *l, double *e, hipStream_t s) {
+  return rstr(off, nelem, elemsize, ncomp, compstride, l, e, 0, s);
+}
+hipError_t launch_rstr_scatter_add(const uint32_t *off, int nelem, int elemsize, int ncomp, int compstride,
+                                   const double *e, double *l, hipStream_t s) {
+  return rstr(off, nelem, elemsize, ncomp, compstride, e, l, 1, s);
+}
+hipError_t launch_multiplicity(const uint32_t *off, int nelem, int elemsize, int ncomp, int compstride,
+                               double *l, hipStream_t s) {
+  return rstr(off, nelem, elemsize, ncomp, compstride, nullptr, l, 2, s);
+}
+hipError_t launch_dot(const double *x, const double *y, const double *w, size_t n, double *result_dev, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_dot, stream_grid(n), dim3(256), 0, s, x, y, w, n, result_dev);
+  return hipGetLastError();
+}
+
+}  // namespace cps

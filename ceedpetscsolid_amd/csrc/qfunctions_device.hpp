@@ -1,0 +1,288 @@
+// qfunctions_device.hpp -- pointwise physics as gfx950 device functors.
+//
+// Device restatement of the reference's QFunctions (qfunctions/common.h,
+// linElas.h, hyperSS.h, hyperFS.h).  Upstream GPU backends JIT the source named
+// by the "file:Name" locator (setuplibceed.c:49-53); here the name after ':' is
+// mapped to one of these precompiled functors (see ceed_api.cpp: resolve_qf).
+//
+// Register conventions inside the fused kernels (one quadrature point per lane):
+//   ug[d*3 + c] = d u_c / d xi_d          (GRAD input,  linElas.h:62-71)
+//   qd[0] = w detJ, qd[1 + 3r + s] = dXdx[r][s]      (common.h:84-96)
+//   st[3c + k] = d u_c / d x_k            (stored state, hyperFS.h:215-220)
+//   dv[k*3 + c]                            (GRAD output, linElas.h:148-153)
+// The log1p series are the reference's own (hyperSS.h:43-55, hyperFS.h:45-67):
+// libm's log1p differs by up to 3e-8 and would break the 1e-10 parity bar.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace cps {
+
+struct Phys { double nu, E; };  // elasticity.h:33-36 (nu first)
+
+#define CPS_DEV static __device__ __forceinline__
+
+// g[c][k] = sum_m dXdx[m][k] du[c][m], du[c][m] = ug[m*3+c]   (linElas.h:90-95)
+CPS_DEV void physical_grad(const double *ug, const double *qd, double g[3][3]) {
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      double s = 0.;
+#pragma unroll
+      for (int m = 0; m < 3; m++) s += qd[1 + 3 * m + k] * ug[m * 3 + c];
+      g[c][k] = s;
+    }
+}
+// dv[k*3+c] = sum_m dXdx[k][m] T[c][m] wdetJ                  (linElas.h:148-153)
+CPS_DEV void pull_back(const double T[3][3], const double *qd, double *dv) {
+  const double wdetJ = qd[0];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      double s = 0.;
+#pragma unroll
+      for (int m = 0; m < 3; m++) s += qd[1 + 3 * k + m] * T[c][m] * wdetJ;
+      dv[k * 3 + c] = s;
+    }
+}
+
+// ---- linear elasticity (linElas.h:97-145; note the reference's shear terms
+// are ss*(1-2nu)*e_ij/2 with the TENSOR strain e_ij) -------------------------
+CPS_DEV void qf_linelas(const Phys ph, const double *ug, const double *qd, double *dv) {
+  double g[3][3], sig[3][3];
+  physical_grad(ug, qd, g);
+  const double nu = ph.nu;
+  const double ss = ph.E / ((1 + nu) * (1 - 2 * nu));
+  const double e00 = g[0][0], e11 = g[1][1], e22 = g[2][2];
+  const double e12 = (g[1][2] + g[2][1]) / 2., e02 = (g[0][2] + g[2][0]) / 2., e01 = (g[0][1] + g[1][0]) / 2.;
+  sig[0][0] = ss * ((1 - nu) * e00 + nu * e11 + nu * e22);
+  sig[1][1] = ss * (nu * e00 + (1 - nu) * e11 + nu * e22);
+  sig[2][2] = ss * (nu * e00 + nu * e11 + (1 - nu) * e22);
+  sig[1][2] = sig[2][1] = ss * (1 - 2 * nu) * e12 * 0.5;
+  sig[0][2] = sig[2][0] = ss * (1 - 2 * nu) * e02 * 0.5;
+  sig[0][1] = sig[1][0] = ss * (1 - 2 * nu) * e01 * 0.5;
+  pull_back(sig, qd, dv);
+}
+
+// ---- Neo-Hookean small strain (hyperSS.h) ---------------------------------
+CPS_DEV double log1p_series4(double x) {  // hyperSS.h:43-55
+  double y = x / (2. + x);
+  const double y2 = y * y;
+  double sum = y;
+  y *= y2; sum += y / 3;
+  y *= y2; sum += y / 5;
+  y *= y2; sum += y / 7;
+  return 2 * sum;
+}
+CPS_DEV void lame(const Phys ph, double &lambda, double &TwoMu) {  // hyperSS.h:79-81
+  TwoMu = ph.E / (1 + ph.nu);
+  const double Kbulk = ph.E / (3 * (1 - 2 * ph.nu));
+  lambda = (3 * Kbulk - TwoMu) / 3;
+}
+CPS_DEV void qf_hyperss_f(const Phys ph, const double *ug, const double *qd, double *dv, double *st) {
+  double lambda, TwoMu, g[3][3], sig[3][3];
+  lame(ph, lambda, TwoMu);
+  physical_grad(ug, qd, g);
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) st[3 * c + k] = g[c][k];
+  const double llv = log1p_series4(g[0][0] + g[1][1] + g[2][2]);
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+      sig[a][b] = TwoMu * ((g[a][b] + g[b][a]) / 2.) + (a == b ? lambda * llv : 0.);
+  pull_back(sig, qd, dv);
+}
+CPS_DEV void qf_hyperss_df(const Phys ph, const double *dug, const double *qd, const double *st, double *dv) {
+  double lambda, TwoMu, dg[3][3], ds[3][3];
+  lame(ph, lambda, TwoMu);
+  physical_grad(dug, qd, dg);
+  const double lambda_bar = lambda / (1 + (st[0] + st[4] + st[8]));  // hyperSS.h:294-295
+  const double ltr = lambda_bar * (dg[0][0] + dg[1][1] + dg[2][2]);
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+      ds[a][b] = TwoMu * ((dg[a][b] + dg[b][a]) / 2.) + (a == b ? ltr : 0.);
+  pull_back(ds, qd, dv);
+}
+
+// ---- Neo-Hookean finite strain (hyperFS.h) --------------------------------
+CPS_DEV double log1p_series4_shifted(double x) {  // hyperFS.h:45-67
+  const double sqrt2 = 1.4142135623730951;       // == sqrt(2.) in IEEE double
+  const double ln2h = 0.6931471805599453 / 2;    // == log(2.)/2
+  const double left = sqrt2 / 2 - 1, right = sqrt2 - 1;
+  double sum = 0.;
+  if (x < left) { sum -= ln2h; x = 1 + 2 * x; }
+  else if (right < x) { sum += ln2h; x = (x - 1) / 2; }
+  double y = x / (2. + x);
+  const double y2 = y * y;
+  sum += y;
+  y *= y2; sum += y / 3;
+  y *= y2; sum += y / 5;
+  y *= y2; sum += y / 7;
+  return 2 * sum;
+}
+// Symmetric 3x3 kept as 6 scalars in the reference's packing (hyperFS.h:91):
+// 0:(0,0) 1:(1,1) 2:(2,2) 3:(1,2) 4:(0,2) 5:(0,1)
+#define CPS_SYM(w, a, b) ((a) == (b) ? w[a] : w[6 - (a) - (b)])
+struct FSState { double S[6], Ci[6], llnj; };
+CPS_DEV void fs_state(double lambda, double mu, const double g[3][3], FSState &s) {  // hyperFS.h:85-142
+  constexpr int J[6] = {0, 1, 2, 1, 0, 0}, K[6] = {0, 1, 2, 2, 2, 1};
+  double E2[6];
+#pragma unroll
+  for (int m = 0; m < 6; m++) {
+    double t = g[J[m]][K[m]] + g[K[m]][J[m]];
+#pragma unroll
+    for (int n = 0; n < 3; n++) t += g[n][J[m]] * g[n][K[m]];
+    E2[m] = t;
+  }
+  const double detCm1 =  // hyperFS.h:72-80
+      E2[0] * (E2[1] * E2[2] - E2[3] * E2[3]) + E2[5] * (E2[4] * E2[3] - E2[5] * E2[2]) +
+      E2[4] * (E2[5] * E2[3] - E2[4] * E2[1]) + E2[0] + E2[1] + E2[2] + E2[0] * E2[1] +
+      E2[0] * E2[2] + E2[1] * E2[2] - E2[5] * E2[5] - E2[4] * E2[4] - E2[3] * E2[3];
+  const double C00 = 1 + E2[0], C11 = 1 + E2[1], C22 = 1 + E2[2], C12 = E2[3], C02 = E2[4], C01 = E2[5];
+  const double A[6] = {C11 * C22 - C12 * C12, C00 * C22 - C02 * C02, C00 * C11 - C01 * C01,
+                       C02 * C01 - C00 * C12, C01 * C12 - C02 * C11, C02 * C12 - C01 * C22};
+  const double den = detCm1 + 1.;
+#pragma unroll
+  for (int m = 0; m < 6; m++) s.Ci[m] = A[m] / den;
+  s.llnj = lambda * log1p_series4_shifted(detCm1) / 2.;
+#pragma unroll
+  for (int m = 0; m < 6; m++) {
+    double t = s.llnj * s.Ci[m];
+#pragma unroll
+    for (int n = 0; n < 3; n++) t += mu * CPS_SYM(s.Ci, J[m], n) * CPS_SYM(E2, n, K[m]);
+    s.S[m] = t;
+  }
+}
+CPS_DEV void fs_lame(const Phys ph, double &lambda, double &mu) {  // hyperFS.h:164-167
+  double TwoMu;
+  lame(ph, lambda, TwoMu);
+  mu = TwoMu / 2;
+}
+CPS_DEV void qf_hyperfs_f(const Phys ph, const double *ug, const double *qd, double *dv, double *st) {
+  double lambda, mu, g[3][3], P[3][3];
+  fs_lame(ph, lambda, mu);
+  physical_grad(ug, qd, g);
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) st[3 * c + k] = g[c][k];
+  FSState s;
+  fs_state(lambda, mu, g, s);
+#pragma unroll
+  for (int a = 0; a < 3; a++)  // P = F S, F = I + grad u   (hyperFS.h:262-268)
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      double t = 0.;
+#pragma unroll
+      for (int m = 0; m < 3; m++) t += (g[a][m] + (a == m ? 1. : 0.)) * CPS_SYM(s.S, m, b);
+      P[a][b] = t;
+    }
+  pull_back(P, qd, dv);
+}
+CPS_DEV void qf_hyperfs_df(const Phys ph, const double *dug, const double *qd, const double *st, double *dv) {
+  constexpr int J[6] = {0, 1, 2, 1, 0, 0}, K[6] = {0, 1, 2, 2, 2, 1};
+  double lambda, mu, dg[3][3], g[3][3], F[3][3];
+  fs_lame(ph, lambda, mu);
+  physical_grad(dug, qd, dg);
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      g[c][k] = st[3 * c + k];
+      F[c][k] = g[c][k] + (c == k ? 1. : 0.);
+    }
+  FSState s;
+  fs_state(lambda, mu, g, s);
+  double dE[6];  // sym(grad(du)^T F)   (hyperFS.h:381-389)
+#pragma unroll
+  for (int m = 0; m < 6; m++) {
+    double t = 0.;
+#pragma unroll
+    for (int n = 0; n < 3; n++) t += (dg[n][J[m]] * F[n][K[m]] + F[n][J[m]] * dg[n][K[m]]) / 2.;
+    dE[m] = t;
+  }
+  double CidE = 0.;  // C^-1 : dE
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) CidE += CPS_SYM(s.Ci, a, b) * CPS_SYM(dE, a, b);
+  double dECi[3][3], dS[3][3], dP[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      double t = 0.;
+#pragma unroll
+      for (int m = 0; m < 3; m++) t += CPS_SYM(dE, a, m) * CPS_SYM(s.Ci, m, b);
+      dECi[a][b] = t;
+    }
+  const double llnj_m = s.llnj - mu;
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      double t = 0.;
+#pragma unroll
+      for (int m = 0; m < 3; m++) t += CPS_SYM(s.Ci, a, m) * dECi[m][b];
+      dS[a][b] = lambda * CidE * CPS_SYM(s.Ci, a, b) - 2. * llnj_m * t;  // hyperFS.h:438-442
+    }
+#pragma unroll
+  for (int a = 0; a < 3; a++)  // dP = grad(du) S + F dS    (hyperFS.h:444-451)
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      double t = 0.;
+#pragma unroll
+      for (int m = 0; m < 3; m++) t += dg[a][m] * CPS_SYM(s.S, m, b) + F[a][m] * dS[m][b];
+      dP[a][b] = t;
+    }
+  pull_back(dP, qd, dv);
+}
+
+// ---- geometry (common.h:47-101).  Jg[d*3+c] = d x_c / d xi_d ---------------
+CPS_DEV void qf_setup_geo(const double *Jg, double w, double *qd) {
+  double adj[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      const int a = (s + 1) % 3, b = (s + 2) % 3, c = (r + 1) % 3, d = (r + 2) % 3;
+      // J[row][col] = d x_row / d xi_col = Jg[col*3 + row]
+      adj[r][s] = Jg[c * 3 + a] * Jg[d * 3 + b] - Jg[d * 3 + a] * Jg[c * 3 + b];
+    }
+  const double detJ = Jg[0] * adj[0][0] + Jg[1] * adj[0][1] + Jg[2] * adj[0][2];
+  qd[0] = w * detJ;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int s = 0; s < 3; s++) qd[1 + 3 * r + s] = adj[r][s] / detJ;
+}
+
+// ---- uniform dispatch used by the fused kernels ----------------------------
+// HAS_STATE_IN : Jacobians of the non-linear models read the stored gradu
+// HAS_STATE_OUT: their residuals write it
+template <int QF> struct QFTraits;
+template <> struct QFTraits<QF_LINELAS>    { static constexpr bool state_in = false, state_out = false; };
+template <> struct QFTraits<QF_HYPERSS_F>  { static constexpr bool state_in = false, state_out = true;  };
+template <> struct QFTraits<QF_HYPERSS_DF> { static constexpr bool state_in = true,  state_out = false; };
+template <> struct QFTraits<QF_HYPERFS_F>  { static constexpr bool state_in = false, state_out = true;  };
+template <> struct QFTraits<QF_HYPERFS_DF> { static constexpr bool state_in = true,  state_out = false; };
+
+template <int QF>
+CPS_DEV void qf_point(const Phys ph, const double *ug, const double *qd, const double *st_in,
+                      double *dv, double *st_out) {
+  if constexpr (QF == QF_LINELAS) qf_linelas(ph, ug, qd, dv);
+  else if constexpr (QF == QF_HYPERSS_F) qf_hyperss_f(ph, ug, qd, dv, st_out);
+  else if constexpr (QF == QF_HYPERSS_DF) qf_hyperss_df(ph, ug, qd, st_in, dv);
+  else if constexpr (QF == QF_HYPERFS_F) qf_hyperfs_f(ph, ug, qd, dv, st_out);
+  else if constexpr (QF == QF_HYPERFS_DF) qf_hyperfs_df(ph, ug, qd, st_in, dv);
+}
+
+}  // namespace cps

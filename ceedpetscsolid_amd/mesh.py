@@ -1,0 +1,412 @@
+"""Hex meshes -> element restrictions: the step in front of the operator path.
+
+Replaces what the reference gets from PETSc DMPlex (src/setupdm.c:40-201,
+src/setuplibceed.c:194-240 ``CreateRestrictionPlex``): HEX8 topology from a
+structured generator or an Exodus file, high-order Gauss-Lobatto node numbering
+with interlaced ``[node][comp]`` L-vectors, tensor (x-fastest) element closure
+order (setupdm.c:194), Dirichlet node sets from side sets, and an element
+partition with interface lists for the multi-GPU halo sum.
+
+DMPlex's own local numbering cannot be reproduced without PETSc;
+the numbering here is deterministic and chosen for gather locality: nodes are
+numbered in order of first touch while sweeping elements, so an element's new
+nodes are contiguous in the L-vector.
+
+Pure numpy, host side, set-up time only.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+# tensor-order corner c = i + 2 j + 4 k  (i,j,k in {0,1}; x fastest)
+# local faces: 0:x- 1:x+ 2:y- 3:y+ 4:z- 5:z+
+_EXO_TO_TENSOR = np.array([0, 1, 3, 2, 4, 5, 7, 6])
+# Exodus HEX8 side (1-based) -> tensor local face
+_EXO_SIDE_TO_FACE = {1: 2, 2: 1, 3: 3, 4: 0, 5: 4, 6: 5}
+
+
+@dataclass
+class HexMesh:
+    coords: np.ndarray            # (nv, 3) vertex coordinates
+    cells: np.ndarray             # (ne, 8) vertex ids, tensor order
+    side_sets: Dict[int, np.ndarray] = field(default_factory=dict)  # id -> (nf, 2) [elem, local face]
+    vertex_gid: Optional[np.ndarray] = None  # (nv,) global vertex ids (sub-meshes)
+    name: str = "mesh"
+
+    @property
+    def nelem(self) -> int:
+        return self.cells.shape[0]
+
+    @property
+    def nvert(self) -> int:
+        return self.coords.shape[0]
+
+    def gid(self) -> np.ndarray:
+        return np.arange(self.nvert, dtype=np.int64) if self.vertex_gid is None else self.vertex_gid
+
+
+# --------------------------------------------------------------------------
+# generators
+# --------------------------------------------------------------------------
+def box_mesh(nx: int, ny: int, nz: int, lo=(0., 0., 0.), hi=(1., 1., 1.)) -> HexMesh:
+    """Structured box, as ``-dm_plex_box_faces nx,ny,nz`` (setupdm.c:49-52).  Face sets
+    follow PETSc's box labels: 1 z-, 2 z+, 3 y-, 4 y+, 5 x+, 6 x-."""
+    xs = [np.linspace(lo[d], hi[d], n + 1) for d, n in enumerate((nx, ny, nz))]
+    Z, Y, X = np.meshgrid(xs[2], xs[1], xs[0], indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    vid = lambda i, j, k: (k * (ny + 1) + j) * (nx + 1) + i
+    K, J, I = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    I, J, K = I.ravel(), J.ravel(), K.ravel()
+    cells = np.stack([vid(I + (c & 1), J + ((c >> 1) & 1), K + ((c >> 2) & 1)) for c in range(8)], axis=1)
+    e = np.arange(cells.shape[0])
+    ss = {}
+    for sid, (mask, face) in {6: (I == 0, 0), 5: (I == nx - 1, 1), 3: (J == 0, 2), 4: (J == ny - 1, 3),
+                              1: (K == 0, 4), 2: (K == nz - 1, 5)}.items():
+        ss[sid] = np.stack([e[mask], np.full(mask.sum(), face)], axis=1)
+    return HexMesh(coords, cells.astype(np.int64), ss, name=f"box{nx}x{ny}x{nz}")
+
+
+def hollow_cylinder_mesh(nr: int, nth: int, nz: int, r_in=0.5, r_out=1.0, z0=-5.0, z1=5.0) -> HexMesh:
+    """Structured hollow cylinder with the geometry and side-set ids of the reference's
+    ``cylinder8_*_4ss_us.exo`` family (meshes/cylinder8.jou):
+    996 inner, 997 outer, 998 z=z0, 999 z=z1.  Stand-in for the absent
+    ``cylinder8_99Ke_4ss_us.exo`` (.MISSING_LARGE_BLOBS:6).  Elements are ordered
+    r fastest, then theta, then z."""
+    r = np.linspace(r_in, r_out, nr + 1)
+    th = 2 * np.pi * np.arange(nth) / nth
+    z = np.linspace(z0, z1, nz + 1)
+    Zg, Tg, Rg = np.meshgrid(z, th, r, indexing="ij")
+    coords = np.stack([(Rg * np.cos(Tg)).ravel(), (Rg * np.sin(Tg)).ravel(), Zg.ravel()], axis=1)
+    vid = lambda i, j, k: (k * nth + (j % nth)) * (nr + 1) + i
+    K, J, I = np.meshgrid(np.arange(nz), np.arange(nth), np.arange(nr), indexing="ij")
+    I, J, K = I.ravel(), J.ravel(), K.ravel()
+    # local x = r, y = theta, z = z is right-handed (r, theta, z)
+    cells = np.stack([vid(I + (c & 1), J + ((c >> 1) & 1), K + ((c >> 2) & 1)) for c in range(8)], axis=1)
+    e = np.arange(cells.shape[0])
+    ss = {}
+    for sid, (mask, face) in {996: (I == 0, 0), 997: (I == nr - 1, 1), 998: (K == 0, 4), 999: (K == nz - 1, 5)}.items():
+        ss[sid] = np.stack([e[mask], np.full(mask.sum(), face)], axis=1)
+    return HexMesh(coords, cells.astype(np.int64), ss, name=f"cyl{nr}x{nth}x{nz}")
+
+
+def read_exodus(path: str) -> HexMesh:
+    """HEX8 Exodus II (NetCDF classic CDF-2) reader for the reference's ``meshes/*.exo``."""
+    from scipy.io import netcdf_file
+    f = netcdf_file(path, "r", mmap=False)
+    v = f.variables
+    if "coordx" in v:
+        coords = np.stack([np.array(v[k][:], dtype=np.float64) for k in ("coordx", "coordy", "coordz")], axis=1)
+    else:
+        coords = np.array(v["coord"][:], dtype=np.float64).T.copy()
+    conn = []
+    b = 1
+    while f"connect{b}" in v:
+        c = np.array(v[f"connect{b}"][:], dtype=np.int64) - 1
+        if c.shape[1] != 8:
+            raise ValueError(f"{path}: block {b} is not HEX8")
+        conn.append(c)
+        b += 1
+    cells = np.concatenate(conn, axis=0)[:, _EXO_TO_TENSOR]
+    ss: Dict[int, np.ndarray] = {}
+    if "ss_prop1" in v:
+        ids = np.array(v["ss_prop1"][:], dtype=np.int64)
+        for k, sid in enumerate(ids, start=1):
+            el = np.array(v[f"elem_ss{k}"][:], dtype=np.int64) - 1
+            sd = np.array(v[f"side_ss{k}"][:], dtype=np.int64)
+            ss[int(sid)] = np.stack([el, np.array([_EXO_SIDE_TO_FACE[int(s)] for s in sd])], axis=1)
+    f.close()
+    mesh = HexMesh(coords, cells, ss, name=path.split("/")[-1])
+    _fix_orientation(mesh)
+    return mesh
+
+
+def _fix_orientation(mesh: HexMesh):
+    """Make every element right-handed (detJ > 0 at the centre) by mirroring in local z."""
+    X = mesh.coords[mesh.cells]  # (ne, 8, 3)
+    dx = (X[:, 1::2] - X[:, 0::2]).mean(axis=1)
+    dy = (X[:, [2, 3, 6, 7]] - X[:, [0, 1, 4, 5]]).mean(axis=1)
+    dz = (X[:, 4:] - X[:, :4]).mean(axis=1)
+    det = np.einsum("ij,ij->i", np.cross(dx, dy), dz)
+    bad = det < 0
+    if bad.any():
+        mesh.cells[bad] = mesh.cells[bad][:, [4, 5, 6, 7, 0, 1, 2, 3]]
+        for sid, fs in mesh.side_sets.items():
+            flip = bad[fs[:, 0]] & (fs[:, 1] >= 4)
+            fs[flip, 1] = 9 - fs[flip, 1]
+
+
+def save_mesh_npz(mesh: HexMesh, path: str):
+    d = {"coords": mesh.coords, "cells": mesh.cells.astype(np.int32)}
+    for sid, fs in mesh.side_sets.items():
+        d[f"ss_{sid}"] = fs.astype(np.int32)
+    np.savez_compressed(path, **d)
+
+
+def load_mesh_npz(path: str) -> HexMesh:
+    z = np.load(path)
+    ss = {int(k[3:]): z[k].astype(np.int64) for k in z.files if k.startswith("ss_")}
+    return HexMesh(z["coords"].astype(np.float64), z["cells"].astype(np.int64), ss, name=path.split("/")[-1])
+
+
+# --------------------------------------------------------------------------
+# Gauss-Lobatto nodes (reference coordinates of the solution nodes)
+# --------------------------------------------------------------------------
+def gll_nodes(P: int) -> np.ndarray:
+    if P == 2:
+        return np.array([-1.0, 1.0])
+    inner = np.polynomial.legendre.Legendre.basis(P - 1).deriv().roots()
+    x = np.concatenate([[-1.0], np.sort(inner.real), [1.0]])
+    return 0.5 * (x - x[::-1])  # enforce symmetry
+
+
+# --------------------------------------------------------------------------
+# high-order numbering
+# --------------------------------------------------------------------------
+@dataclass
+class DofMap:
+    """Degree-p nodes of a mesh.  ``elem_nodes[e, n]`` is the node id of local tensor
+    node n = a + P b + P^2 c (x fastest) -- the closure order of setupdm.c:194."""
+    p: int
+    nnodes: int
+    elem_nodes: np.ndarray        # (ne, P^3) int32
+    node_keys: np.ndarray         # (nnodes, 7) int64 partition-independent topological keys
+    node_coords: np.ndarray       # (nnodes, 3)
+    ncomp: int = 3
+
+    @property
+    def P(self) -> int:
+        return self.p + 1
+
+    @property
+    def lsize(self) -> int:
+        return self.nnodes * self.ncomp
+
+    def offsets(self) -> np.ndarray:
+        """Per-node offset of component 0 in the interlaced L-vector (compstride 1),
+        as CreateRestrictionPlex hands them to CeedElemRestrictionCreate (:235)."""
+        return (self.elem_nodes.astype(np.int64) * self.ncomp).astype(np.int32)
+
+
+def _local_face_nodes(P: int, face: int) -> np.ndarray:
+    a = np.arange(P)
+    A, B = np.meshgrid(a, a, indexing="ij")
+    fixed = 0 if face % 2 == 0 else P - 1
+    if face < 2:
+        i, j, k = np.full_like(A, fixed), A, B
+    elif face < 4:
+        i, j, k = A, np.full_like(A, fixed), B
+    else:
+        i, j, k = A, B, np.full_like(A, fixed)
+    return (i + P * j + P * P * k).ravel()
+
+
+def build_dofmap(mesh: HexMesh, p: int, ncomp: int = 3, locality_order: bool = True) -> DofMap:
+    P = p + 1
+    ne = mesh.nelem
+    cells = mesh.cells
+    gcells = mesh.gid()[cells]       # global vertex ids: canonical orientations agree across ranks
+    V = mesh.nvert
+    m = p - 1                        # interior nodes per edge
+    ids = np.empty((ne, P, P, P), dtype=np.int64)     # [e, c(z), b(y), a(x)]
+    keys = np.zeros((ne, P, P, P, 7), dtype=np.int64)
+    corner = lambda i, j, k: i + 2 * j + 4 * k
+
+    # vertices
+    for k in (0, 1):
+        for j in (0, 1):
+            for i in (0, 1):
+                c = corner(i, j, k)
+                ids[:, k * p, j * p, i * p] = cells[:, c]
+                keys[:, k * p, j * p, i * p, 0] = 0
+                keys[:, k * p, j * p, i * p, 1] = gcells[:, c]
+    nE = nF = 0
+    if m > 0:
+        t = np.arange(1, p)
+        # ---- edges: 12 per element --------------------------------------
+        edge_list = []  # (axis, fixed (u,v) bits)
+        for axis in range(3):
+            for u in (0, 1):
+                for v in (0, 1):
+                    edge_list.append((axis, u, v))
+        ev0 = np.empty((ne, 12), dtype=np.int64)
+        ev1 = np.empty((ne, 12), dtype=np.int64)
+        for n, (axis, u, v) in enumerate(edge_list):
+            bits0 = [0, 0, 0]
+            others = [d for d in range(3) if d != axis]
+            bits0[others[0]], bits0[others[1]] = u, v
+            bits1 = list(bits0)
+            bits1[axis] = 1
+            ev0[:, n] = corner(*bits0)
+            ev1[:, n] = corner(*bits1)
+        g0 = np.take_along_axis(gcells, ev0, axis=1)
+        g1 = np.take_along_axis(gcells, ev1, axis=1)
+        lo, hi = np.minimum(g0, g1), np.maximum(g0, g1)
+        pair = np.stack([lo.ravel(), hi.ravel()], axis=1)
+        uniq_e, eid = np.unique(pair, axis=0, return_inverse=True)
+        eid = eid.reshape(ne, 12)
+        nE = uniq_e.shape[0]
+        for n, (axis, u, v) in enumerate(edge_list):
+            fwd = (g0[:, n] < g1[:, n])[:, None]
+            pos = np.where(fwd, t[None, :], p - t[None, :])            # (ne, m) position from the min vertex
+            nid = V + eid[:, n][:, None] * m + (pos - 1)
+            others = [d for d in range(3) if d != axis]
+            idx = [None, None, None]
+            idx[axis] = t
+            idx[others[0]] = u * p
+            idx[others[1]] = v * p
+            sl = (slice(None), idx[2], idx[1], idx[0])
+            ids[sl] = nid
+            keys[sl + (0,)] = 1
+            keys[sl + (1,)] = lo[:, n][:, None]
+            keys[sl + (2,)] = hi[:, n][:, None]
+            keys[sl + (5,)] = pos
+        # ---- faces: 6 per element ---------------------------------------
+        fc = np.empty((ne, 6, 4), dtype=np.int64)  # corners in local (s,t) order: 00,10,01,11
+        for f in range(6):
+            axis, side = f // 2, f % 2
+            others = [d for d in range(3) if d != axis]
+            for q, (s_, t_) in enumerate(((0, 0), (1, 0), (0, 1), (1, 1))):
+                bits = [0, 0, 0]
+                bits[axis] = side
+                bits[others[0]], bits[others[1]] = s_, t_
+                fc[:, f, q] = gcells[:, corner(*bits)]
+        srt = np.sort(fc, axis=2).reshape(ne * 6, 4)
+        uniq_f, fid = np.unique(srt, axis=0, return_inverse=True)
+        fid = fid.reshape(ne, 6)
+        nF = uniq_f.shape[0]
+        S, T = np.meshgrid(t, t, indexing="ij")      # local (s,t) interior positions
+        S, T = S.ravel(), T.ravel()
+        for f in range(6):
+            axis, side = f // 2, f % 2
+            others = [d for d in range(3) if d != axis]
+            c4 = fc[:, f, :]
+            o = np.argmin(c4, axis=1)                                        # origin corner
+            ns = np.take_along_axis(c4, (o ^ 1)[:, None], axis=1)[:, 0]      # neighbour along s
+            nt = np.take_along_axis(c4, (o ^ 2)[:, None], axis=1)[:, 0]      # neighbour along t
+            swap = (nt < ns)[:, None]
+            srel = np.where(((o & 1) == 0)[:, None], S[None, :], p - S[None, :])
+            trel = np.where(((o & 2) == 0)[:, None], T[None, :], p - T[None, :])
+            s2 = np.where(swap, trel, srel)
+            t2 = np.where(swap, srel, trel)
+            nid = V + nE * m + fid[:, f][:, None] * m * m + (s2 - 1) * m + (t2 - 1)
+            idx = [None, None, None]
+            idx[axis] = np.full(S.shape, side * p)
+            idx[others[0]] = S
+            idx[others[1]] = T
+            sl = (slice(None), idx[2], idx[1], idx[0])
+            ids[sl] = nid
+            keys[sl + (0,)] = 2
+            sq = np.sort(c4, axis=1)
+            for q in range(4):
+                keys[sl + (1 + q,)] = sq[:, q][:, None]
+            keys[sl + (5,)] = s2
+            keys[sl + (6,)] = t2
+        # ---- interiors ---------------------------------------------------
+        C_, B_, A_ = np.meshgrid(t, t, t, indexing="ij")
+        loc = ((C_ - 1) * m + (B_ - 1)) * m + (A_ - 1)
+        base = V + nE * m + nF * m * m
+        sl = (slice(None), C_.ravel(), B_.ravel(), A_.ravel())
+        ids[sl] = base + np.arange(ne)[:, None] * m ** 3 + loc.ravel()[None, :]
+        keys[sl + (0,)] = 3
+        # element identity must be global for keys: use the element's min global vertex + its sorted corners hash
+        keys[sl + (1,)] = np.sort(gcells, axis=1)[:, 0][:, None]
+        keys[sl + (2,)] = np.sort(gcells, axis=1)[:, 7][:, None]
+        keys[sl + (3,)] = np.sort(gcells, axis=1)[:, 3][:, None]
+        keys[sl + (5,)] = loc.ravel()[None, :]
+    nn = V + nE * m + nF * m * m + ne * m ** 3
+    flat = ids.reshape(ne, P ** 3)
+    kflat = keys.reshape(ne * P ** 3, 7)
+    if locality_order:
+        uniq, first = np.unique(flat.ravel(), return_index=True)
+        assert uniq.size == nn, (uniq.size, nn)
+        order = np.argsort(first, kind="stable")
+        new = np.empty(nn, dtype=np.int64)
+        new[uniq[order]] = np.arange(nn)
+        flat = new[flat]
+        first_sorted = first[order]
+    else:
+        _, first = np.unique(flat.ravel(), return_index=True)
+        first_sorted = first
+    node_keys = kflat[first_sorted]
+    # node coordinates by the trilinear map of the GLL reference positions
+    xi = 0.5 * (gll_nodes(P) + 1.0)
+    N1 = np.stack([1 - xi, xi], axis=0)              # (2, P)
+    X = mesh.coords[cells]                            # (ne, 8, 3)
+    w = np.einsum("kc,jb,ia->kjicba", N1, N1, N1).reshape(8, P ** 3)  # corner c=i+2j+4k; node a+P b+P^2 c
+    # reorder: w[corner, node]; corner index = i + 2j + 4k -> axes (k,j,i)
+    xn = np.einsum("cn,ecd->end", w, X)
+    node_coords = np.empty((nn, 3))
+    node_coords[flat.ravel()] = xn.reshape(-1, 3)
+    return DofMap(p, nn, flat.astype(np.int32), node_keys, node_coords, ncomp)
+
+
+def side_set_nodes(mesh: HexMesh, dm: DofMap, side_ids) -> np.ndarray:
+    """Sorted unique node ids lying on the given side sets."""
+    out = []
+    for sid in side_ids:
+        fs = mesh.side_sets[sid]
+        for f in range(6):
+            el = fs[fs[:, 1] == f, 0]
+            if el.size:
+                out.append(dm.elem_nodes[el][:, _local_face_nodes(dm.P, f)].ravel())
+    return np.unique(np.concatenate(out)) if out else np.zeros(0, dtype=np.int64)
+
+
+def boundary_nodes(mesh: HexMesh, dm: DofMap) -> np.ndarray:
+    """Nodes on faces that belong to exactly one element of this (sub-)mesh: the whole
+    boundary -- the "marker" label of -test mode (setupdm.c:160-170) -- and, on a
+    partition, also the interface candidates."""
+    g = mesh.gid()[mesh.cells]
+    faces = []
+    for f in range(6):
+        axis, side = f // 2, f % 2
+        cs = [c for c in range(8) if ((c >> axis) & 1) == side]
+        faces.append(np.sort(g[:, cs], axis=1))
+    allf = np.concatenate(faces, axis=0)
+    _, inv, cnt = np.unique(allf, axis=0, return_inverse=True, return_counts=True)
+    single = (cnt[inv] == 1).reshape(6, mesh.nelem)
+    out = []
+    for f in range(6):
+        el = np.nonzero(single[f])[0]
+        if el.size:
+            out.append(dm.elem_nodes[el][:, _local_face_nodes(dm.P, f)].ravel())
+    return np.unique(np.concatenate(out))
+
+
+def dirichlet_mask(dm: DofMap, nodes: np.ndarray) -> np.ndarray:
+    """uint8 mask over the L-vector: 1 on constrained dofs (all components of ``nodes``)."""
+    m = np.zeros((dm.nnodes, dm.ncomp), dtype=np.uint8)
+    m[nodes] = 1
+    return m.ravel()
+
+
+# --------------------------------------------------------------------------
+# partitioning (element-wise, overlap 0: setupdm.c:57-64)
+# --------------------------------------------------------------------------
+def partition_slabs(mesh: HexMesh, nparts: int, axis: int = 2) -> List[np.ndarray]:
+    """Contiguous equal-count chunks of elements sorted by centroid along ``axis``."""
+    cen = mesh.coords[mesh.cells].mean(axis=1)[:, axis]
+    order = np.argsort(cen, kind="stable")
+    return [np.sort(ch) for ch in np.array_split(order, nparts)]
+
+
+def submesh(mesh: HexMesh, elems: np.ndarray) -> HexMesh:
+    cells = mesh.cells[elems]
+    used, inv = np.unique(cells.ravel(), return_inverse=True)
+    emap = -np.ones(mesh.nelem, dtype=np.int64)
+    emap[elems] = np.arange(elems.size)
+    ss = {}
+    for sid, fs in mesh.side_sets.items():
+        keep = emap[fs[:, 0]] >= 0
+        ss[sid] = np.stack([emap[fs[keep, 0]], fs[keep, 1]], axis=1)
+    return HexMesh(mesh.coords[used], inv.reshape(cells.shape).astype(np.int64), ss,
+                   vertex_gid=mesh.gid()[used], name=mesh.name + f"[{elems.size}e]")
+
+
+def key_bytes(keys: np.ndarray) -> np.ndarray:
+    """Topological keys as fixed-size byte strings (hashable / sortable across ranks)."""
+    k = np.ascontiguousarray(keys, dtype=np.int64)
+    return k.view(np.dtype((np.void, k.shape[1] * 8))).ravel()

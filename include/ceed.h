@@ -1,0 +1,265 @@
+/*
+ * ceed.h -- C-ABI boundary of the MI355X-native operator-apply backend.
+ *
+ * This is the drop-in boundary named in BASELINE.json's north_star: the subset
+ * of the public libCEED (v0.7-era) C interface that ArashMehraban/CeedPetscSolid
+ * binds for its residual / Jacobian / p-multigrid-transfer / diagonal path.
+ * The mini-app's own translation units (`src/setuplibceed.c`, `src/matops.c`,
+ * `src/misc.c`, `elasticity.c`) and its `qfunctions/ *.h` compile against this
+ * header unchanged (`#include <ceed.h>`, reference elasticity.h:24), and link
+ * against either
+ *
+ *   ceedpetscsolid_amd/csrc/libceed_mi355x.so   (the product: resource
+ *                                                "/gpu/hip/mi355x", hand-written
+ *                                                gfx950 kernels), or
+ *   oracle/liboracle_ceed.so                     (TEST INFRASTRUCTURE ONLY: the
+ *                                                plain-C CPU restatement,
+ *                                                resource "/cpu/self/oracle").
+ *
+ * Every entry point returns 0 on success.  Because the reference never checks
+ * a Ceed return code (e.g. src/matops.c:40-50) every failure also goes through
+ * an aborting error handler: the message is printed to stderr and abort() is
+ * called, unless CeedSetErrorReturn() (extension, below) was used to ask for
+ * plain error returns (the Python tests do, so that pytest can see them).
+ *
+ * Each declaration cites the reference call site(s) it serves.
+ * Plain pointers and sizes only; no C++/torch types cross this boundary.
+ */
+#ifndef CEED_MI355X_CEED_H
+#define CEED_MI355X_CEED_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+#  define CEED_EXTERN extern "C"
+#else
+#  define CEED_EXTERN extern
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Scalar / index types (f64 data, int32 indices)                   */
+/* ------------------------------------------------------------------------- */
+typedef int32_t CeedInt;
+typedef double  CeedScalar;
+
+/* QFunction-side helper macros used by qfunctions/ *.h                       */
+/*   CEED_QFUNCTION(name): defines the "file:name" locator string `name_loc`  */
+/*   (consumed at setuplibceed.c:49-53) and opens the static callback.        */
+#ifndef CEED_QFUNCTION
+#  define CEED_QFUNCTION(name) \
+     static const char name ## _loc[] = __FILE__ ":" #name; \
+     static int name
+#endif
+#ifndef CEED_Q_VLA
+#  define CEED_Q_VLA Q
+#endif
+#ifndef CeedPragmaSIMD
+#  if defined(_OPENMP) || defined(__clang__) || defined(__GNUC__)
+#    define CeedPragmaSIMD _Pragma("GCC ivdep")
+#  else
+#    define CeedPragmaSIMD
+#  endif
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Opaque handles                                                             */
+/* ------------------------------------------------------------------------- */
+typedef struct Ceed_private                *Ceed;
+typedef struct CeedRequest_private         *CeedRequest;
+typedef struct CeedVector_private          *CeedVector;
+typedef struct CeedElemRestriction_private *CeedElemRestriction;
+typedef struct CeedBasis_private           *CeedBasis;
+typedef struct CeedQFunction_private       *CeedQFunction;
+typedef struct CeedOperator_private        *CeedOperator;
+
+/* ------------------------------------------------------------------------- */
+/* Enums                                                                      */
+/* ------------------------------------------------------------------------- */
+typedef enum { CEED_MEM_HOST = 0, CEED_MEM_DEVICE = 1 } CeedMemType;
+typedef enum { CEED_COPY_VALUES = 0, CEED_USE_POINTER = 1,
+               CEED_OWN_POINTER = 2 } CeedCopyMode;
+typedef enum { CEED_NOTRANSPOSE = 0, CEED_TRANSPOSE = 1 } CeedTransposeMode;
+typedef enum { CEED_EVAL_NONE = 0, CEED_EVAL_INTERP = 1, CEED_EVAL_GRAD = 2,
+               CEED_EVAL_DIV = 4, CEED_EVAL_CURL = 8,
+               CEED_EVAL_WEIGHT = 16 } CeedEvalMode;
+typedef enum { CEED_GAUSS = 0, CEED_GAUSS_LOBATTO = 1 } CeedQuadMode;
+
+/* Printable names, indexed by CeedMemType (elasticity.c:316-318).            */
+CEED_EXTERN const char *const CeedMemTypes[];
+
+/* ------------------------------------------------------------------------- */
+/* Sentinels (setuplibceed.c:378-385, 531-539, 849-862; matops.c:46)          */
+/* ------------------------------------------------------------------------- */
+CEED_EXTERN const CeedVector          CEED_VECTOR_ACTIVE;
+CEED_EXTERN const CeedVector          CEED_VECTOR_NONE;
+CEED_EXTERN const CeedElemRestriction CEED_ELEMRESTRICTION_NONE;
+CEED_EXTERN const CeedBasis           CEED_BASIS_COLLOCATED;
+CEED_EXTERN const CeedQFunction       CEED_QFUNCTION_NONE;
+CEED_EXTERN CeedRequest *const        CEED_REQUEST_IMMEDIATE;
+CEED_EXTERN CeedRequest *const        CEED_REQUEST_ORDERED;
+CEED_EXTERN const CeedInt             CEED_STRIDES_BACKEND[3];
+
+/* ------------------------------------------------------------------------- */
+/* Ceed (context)            elasticity.c:110-116, 308, 897-898               */
+/* ------------------------------------------------------------------------- */
+CEED_EXTERN int CeedInit(const char *resource, Ceed *ceed);
+CEED_EXTERN int CeedDestroy(Ceed *ceed);               /* NULL-safe (:898)   */
+CEED_EXTERN int CeedGetResource(Ceed ceed, const char **resource);
+CEED_EXTERN int CeedGetPreferredMemType(Ceed ceed, CeedMemType *type);
+
+/* ------------------------------------------------------------------------- */
+/* CeedVector   matops.c:40-50,134-143,183-192,224-235,274-290;               */
+/*              setuplibceed.c:326-328,355-361,601,626-639,808-809;           */
+/*              misc.c:123-139; elasticity.c:243-244,292,300,782-798          */
+/* ------------------------------------------------------------------------- */
+CEED_EXTERN int CeedVectorCreate(Ceed ceed, CeedInt length, CeedVector *vec);
+CEED_EXTERN int CeedVectorSetArray(CeedVector vec, CeedMemType mtype,
+                                   CeedCopyMode cmode, CeedScalar *array);
+CEED_EXTERN int CeedVectorTakeArray(CeedVector vec, CeedMemType mtype,
+                                    CeedScalar **array /* may be NULL */);
+CEED_EXTERN int CeedVectorSetValue(CeedVector vec, CeedScalar value);
+CEED_EXTERN int CeedVectorSyncArray(CeedVector vec, CeedMemType mtype);
+CEED_EXTERN int CeedVectorGetArray(CeedVector vec, CeedMemType mtype,
+                                   CeedScalar **array);
+CEED_EXTERN int CeedVectorGetArrayRead(CeedVector vec, CeedMemType mtype,
+                                       const CeedScalar **array);
+CEED_EXTERN int CeedVectorRestoreArray(CeedVector vec, CeedScalar **array);
+CEED_EXTERN int CeedVectorRestoreArrayRead(CeedVector vec,
+                                           const CeedScalar **array);
+CEED_EXTERN int CeedVectorGetLength(CeedVector vec, CeedInt *length);
+CEED_EXTERN int CeedVectorReciprocal(CeedVector vec);
+CEED_EXTERN int CeedVectorDestroy(CeedVector *vec);    /* NULL-safe (:133)   */
+
+/* ------------------------------------------------------------------------- */
+/* CeedElemRestriction   setuplibceed.c:235-236 (offsets; constrained dofs    */
+/*   already sign-decoded at :221-223), :304-318 (strided, backend layout),   */
+/*   :326,626 (CreateVector), :628 + misc.c:123,278 (multiplicity)            */
+/* ------------------------------------------------------------------------- */
+CEED_EXTERN int CeedElemRestrictionCreate(Ceed ceed, CeedInt nelem,
+    CeedInt elemsize, CeedInt ncomp, CeedInt compstride, CeedInt lsize,
+    CeedMemType mtype, CeedCopyMode cmode, const CeedInt *offsets,
+    CeedElemRestriction *rstr);
+CEED_EXTERN int CeedElemRestrictionCreateStrided(Ceed ceed, CeedInt nelem,
+    CeedInt elemsize, CeedInt ncomp, CeedInt lsize, const CeedInt strides[3],
+    CeedElemRestriction *rstr);
+CEED_EXTERN int CeedElemRestrictionCreateVector(CeedElemRestriction rstr,
+    CeedVector *lvec /* or NULL */, CeedVector *evec /* or NULL */);
+CEED_EXTERN int CeedElemRestrictionApply(CeedElemRestriction rstr,
+    CeedTransposeMode tmode, CeedVector u, CeedVector ru, CeedRequest *request);
+CEED_EXTERN int CeedElemRestrictionGetMultiplicity(CeedElemRestriction rstr,
+    CeedVector mult);
+CEED_EXTERN int CeedElemRestrictionDestroy(CeedElemRestriction *rstr);
+
+/* ------------------------------------------------------------------------- */
+/* CeedBasis   setuplibceed.c:335-348, 604, 782-803                           */
+/* ------------------------------------------------------------------------- */
+CEED_EXTERN int CeedBasisCreateTensorH1Lagrange(Ceed ceed, CeedInt dim,
+    CeedInt ncomp, CeedInt P, CeedInt Q, CeedQuadMode qmode, CeedBasis *basis);
+CEED_EXTERN int CeedBasisGetNumQuadraturePoints(CeedBasis basis, CeedInt *Q);
+CEED_EXTERN int CeedBasisGetNumNodes(CeedBasis basis, CeedInt *P);
+CEED_EXTERN int CeedBasisApply(CeedBasis basis, CeedInt nelem,
+    CeedTransposeMode tmode, CeedEvalMode emode, CeedVector u, CeedVector v);
+CEED_EXTERN int CeedBasisDestroy(CeedBasis *basis);
+/* 1-D rules and tables (host copies; used by parity tests)                   */
+CEED_EXTERN int CeedGaussQuadrature(CeedInt Q, CeedScalar *qref1d,
+                                    CeedScalar *qweight1d);
+CEED_EXTERN int CeedLobattoQuadrature(CeedInt Q, CeedScalar *qref1d,
+                                      CeedScalar *qweight1d);
+CEED_EXTERN int CeedBasisGetInterp1D(CeedBasis basis,
+                                     const CeedScalar **interp1d);
+CEED_EXTERN int CeedBasisGetGrad1D(CeedBasis basis, const CeedScalar **grad1d);
+CEED_EXTERN int CeedBasisGetQWeights1D(CeedBasis basis,
+                                       const CeedScalar **qweight1d);
+
+/* ------------------------------------------------------------------------- */
+/* CeedQFunction   setuplibceed.c:370-375,518-526,818-826; elasticity.c:249;  */
+/*                 matops.c:215-232 (context swap for -nu_smoother)           */
+/* ------------------------------------------------------------------------- */
+typedef int (*CeedQFunctionUser)(void *ctx, const CeedInt Q,
+                                 const CeedScalar *const *in,
+                                 CeedScalar *const *out);
+CEED_EXTERN int CeedQFunctionCreateInterior(Ceed ceed, CeedInt vlength,
+    CeedQFunctionUser f, const char *source, CeedQFunction *qf);
+CEED_EXTERN int CeedQFunctionCreateIdentity(Ceed ceed, CeedInt size,
+    CeedEvalMode inmode, CeedEvalMode outmode, CeedQFunction *qf);
+CEED_EXTERN int CeedQFunctionAddInput(CeedQFunction qf, const char *fieldname,
+                                      CeedInt size, CeedEvalMode emode);
+CEED_EXTERN int CeedQFunctionAddOutput(CeedQFunction qf, const char *fieldname,
+                                       CeedInt size, CeedEvalMode emode);
+/* ctx is borrowed: the pointer is kept and re-read at every apply.  The       */
+/* reference passes sizeof(pointer) at setuplibceed.c:826, so `ctxsize` is    */
+/* recorded but never trusted for the known QFunctions.       */
+CEED_EXTERN int CeedQFunctionSetContext(CeedQFunction qf, void *ctx,
+                                        size_t ctxsize);
+CEED_EXTERN int CeedQFunctionDestroy(CeedQFunction *qf);
+
+/* ------------------------------------------------------------------------- */
+/* CeedOperator   setuplibceed.c:378-393,529-542,829-839,849-862;             */
+/*                matops.c:46,138,187,227,277                                 */
+/* ------------------------------------------------------------------------- */
+CEED_EXTERN int CeedOperatorCreate(Ceed ceed, CeedQFunction qf,
+    CeedQFunction dqf, CeedQFunction dqfT, CeedOperator *op);
+CEED_EXTERN int CeedCompositeOperatorCreate(Ceed ceed, CeedOperator *op);
+CEED_EXTERN int CeedCompositeOperatorAddSub(CeedOperator compositeop,
+                                            CeedOperator subop);
+CEED_EXTERN int CeedOperatorSetField(CeedOperator op, const char *fieldname,
+    CeedElemRestriction r, CeedBasis b, CeedVector v);
+/* Overwrites every output, passive ones included (residual's `gradu`).       */
+CEED_EXTERN int CeedOperatorApply(CeedOperator op, CeedVector in,
+                                  CeedVector out, CeedRequest *request);
+CEED_EXTERN int CeedOperatorApplyAdd(CeedOperator op, CeedVector in,
+                                     CeedVector out, CeedRequest *request);
+/* Overwrites `assembled` (matops.c:227; Xloc is not zero on entry).          */
+CEED_EXTERN int CeedOperatorLinearAssembleDiagonal(CeedOperator op,
+    CeedVector assembled, CeedRequest *request);
+CEED_EXTERN int CeedOperatorDestroy(CeedOperator *op);
+
+/* ------------------------------------------------------------------------- */
+/* Extensions (not in libCEED; prefixed CeedX).  None is needed by the        */
+/* reference's call sites; they serve the harness, bench.py and the tests.    */
+/* ------------------------------------------------------------------------- */
+/* 0: abort on error (default, libCEED's behaviour);  1: return the code and  */
+/* keep the message for CeedXLastError().                                     */
+CEED_EXTERN int CeedXSetErrorReturn(int enable);
+CEED_EXTERN const char *CeedXLastError(void);
+/* Launch all device work of this Ceed on the given hipStream_t (as void*).   */
+CEED_EXTERN int CeedXSetStream(Ceed ceed, void *hip_stream);
+/* Block until all device work queued by this Ceed has finished.              */
+CEED_EXTERN int CeedXSynchronize(Ceed ceed);
+/* Name of the kernel family an operator was lowered to, e.g.                 */
+/* "fused_grad<P=5,Q=5,HyperFSdF>" (empty before the first apply).            */
+CEED_EXTERN int CeedXOperatorGetKernelName(CeedOperator op, const char **name);
+/* Fused BC handling for the MatShell wrappers (matops.c:33-34,56-57,106):    */
+/* `mask` has one byte per L-vector entry of the operator's ACTIVE fields;    */
+/* entries with mask!=0 are read as zero on input and dropped on output.      */
+/* Pass NULL to clear.  Device or host pointer according to mtype; copied.    */
+CEED_EXTERN int CeedXOperatorSetDirichletMask(CeedOperator op,
+    CeedMemType mtype, const unsigned char *mask, CeedInt lsize);
+/* General form: `mode` 1 = masked entries read as zero on input (matops.c:106 */
+/* VecZeroEntries(Xloc)), 2 = masked rows dropped on output (matops.c:57       */
+/* DMLocalToGlobal skips constrained dofs), 3 = both.  Transfer operators have */
+/* different L-vectors on their two sides and take both masks.                 */
+CEED_EXTERN int CeedXOperatorSetDirichletMaskMode(CeedOperator op,
+    CeedMemType mtype, const unsigned char *mask_in, CeedInt lsize_in,
+    const unsigned char *mask_out, CeedInt lsize_out, int mode);
+/* Fine-side 1/multiplicity of the p-multigrid transfer operators, folded     */
+/* into the fine scatter (Prolong_Ceed, matops.c:149) or gather               */
+/* (Restrict_Ceed, matops.c:176).  NULL / CEED_VECTOR_NONE clears.            */
+CEED_EXTERN int CeedXOperatorSetFineScale(CeedOperator op, CeedVector scale);
+/* Stand-ins for the PETSc Vec calls of src/matops.c / src/misc.c on backend   */
+/* memory: w = x .* y (VecPointwiseMult), y = a x + b y, weighted dot.        */
+CEED_EXTERN int CeedXVectorPointwiseMult(CeedVector w, CeedVector x,
+                                         CeedVector y);
+CEED_EXTERN int CeedXVectorAXPBY(CeedVector y, double a, CeedVector x,
+                                 double b);
+CEED_EXTERN int CeedXVectorDot(CeedVector x, CeedVector y,
+                               CeedVector weight /* or NULL */, double *result);
+/* Accumulated device time (ms) and launch count of the operator's dominant   */
+/* kernel since the last reset; measured with hipEvents on the Ceed's stream  */
+/* when timing is enabled.                                                    */
+CEED_EXTERN int CeedXOperatorSetTiming(CeedOperator op, int enable);
+CEED_EXTERN int CeedXOperatorGetTiming(CeedOperator op, double *ms,
+                                       int64_t *launches);
+
+#endif /* CEED_MI355X_CEED_H */
