@@ -75,7 +75,16 @@ class CeedLib:
                 f"Ceed backend library not found: {path} -- build it first "
                 "(python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path")
         self.path = path
-        self.lib = C.CDLL(path, mode=C.RTLD_GLOBAL if hasattr(C, "RTLD_GLOBAL") else 0)
+        if "mi355x" in os.path.basename(path):
+            # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64 /
+            # libhsa-runtime64 (soname libamdhip64.so.7, same as /opt/rocm's); two copies in
+            # one process cannot both open the device.  Importing torch first makes the
+            # loader satisfy this library's NEEDED entry with torch's already-loaded copy
+            # (measured on the GPU box: tools/diag_hip_runtime.py).  A plain C host without
+            # torch gets /opt/rocm's runtime through the usual search path.
+            import torch  # noqa: F401
+        # RTLD_LOCAL: the oracle and the product export the same Ceed* names
+        self.lib = C.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_NOW", 2))
         L = self.lib
         L.CeedXLastError.restype = C.c_char_p
         L.CeedXSetErrorReturn(1)

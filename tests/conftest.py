@@ -1,0 +1,60 @@
+"""Shared fixtures.  `-m "not gpu"` runs on the CPU-only build container (oracle vs
+golden vectors, host logic, ABI symbol checks, gloo multi-process); `-m gpu` runs on an
+MI355X and drives the product library through the C ABI against the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from ceedpetscsolid_amd import ceed as cd  # noqa: E402
+
+ORACLE_LIB = os.path.join(ROOT, "oracle", "liboracle_ceed.so")
+REF_QF_LIB = os.path.join(ROOT, "oracle", "_ref", "libref_qfunctions.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure_oracle():
+    if not os.path.exists(ORACLE_LIB):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle_ceed.so"])
+    return ORACLE_LIB
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    return cd.CeedLib(_ensure_oracle())
+
+
+@pytest.fixture(scope="session")
+def oracle(oracle_lib):
+    return cd.Ceed(oracle_lib, "/cpu/self/oracle")
+
+
+@pytest.fixture(scope="session")
+def product_lib():
+    # no fallback: a missing product library is a hard failure on the GPU box
+    return cd.CeedLib(cd.PRODUCT_LIB)
+
+
+@pytest.fixture(scope="session")
+def gpu(product_lib):
+    return cd.Ceed(product_lib, "/gpu/hip/mi355x")
+
+
+@pytest.fixture(scope="session")
+def golden_qf():
+    return np.load(os.path.join(GOLDEN, "qfunctions.npz"))
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    den = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (den if den > 0 else 1.0)

@@ -1,0 +1,211 @@
+"""Parity of the hand-written gfx950 path with the CPU oracle, through the C ABI.
+
+Bar (BASELINE.json north_star): restriction indices bit-exact; residual / Jacobian action
+within 1e-10 relative on identical inputs.  Everything here calls the product library
+(ceedpetscsolid_amd/csrc/libceed_mi355x.so); the oracle is only the checker."""
+import os
+
+import numpy as np
+import pytest
+
+from ceedpetscsolid_amd import ceed as cd
+from ceedpetscsolid_amd.mesh import box_mesh, hollow_cylinder_mesh, load_mesh_npz
+from ceedpetscsolid_amd.solid import SolidProblem
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10  # north_star tolerance for the floating-point path
+
+
+def distorted_box(nx, ny, nz, seed=0, amp=0.04):
+    m = box_mesh(nx, ny, nz)
+    rng = np.random.default_rng(seed)
+    m.coords += amp / max(nx, ny, nz) * rng.uniform(-1, 1, m.coords.shape)
+    return m
+
+
+def build_pair(oracle, gpu, mesh, degree, problem, **kw):
+    a = SolidProblem(oracle, mesh, degree, problem, **kw)
+    b = SolidProblem(gpu, mesh, degree, problem, **kw)
+    return a, b
+
+
+def vec_pair(pa, pb, n, arr=None):
+    va, vb = pa.ceed.vector(n), pb.ceed.vector(n)
+    if arr is not None:
+        va.set_array(arr); vb.set_array(arr)
+    return va, vb
+
+
+CASES = [  # (mesh factory, degree, problem, bc)
+    ("box p1", lambda: distorted_box(3, 2, 2), 1, "hyperFS", dict(bc_sides=[1])),
+    ("box p2", lambda: distorted_box(4, 4, 4), 2, "linElas", dict(bc_all_boundary=True)),      # config 1 shape
+    ("box p2 fs", lambda: distorted_box(3, 3, 2), 2, "hyperFS", dict(bc_sides=[1, 2])),
+    ("box p3 ss", lambda: distorted_box(3, 2, 3), 3, "hyperSS", dict(bc_sides=[6])),
+    ("cyl p4 fs", lambda: hollow_cylinder_mesh(2, 8, 3), 4, "hyperFS", dict(bc_sides=[998, 999])),
+    ("cyl p4 ss", lambda: hollow_cylinder_mesh(2, 8, 3), 4, "hyperSS", dict(bc_sides=[998])),
+    ("box p6 fs", lambda: distorted_box(2, 2, 2), 6, "hyperFS", dict(bc_sides=[1])),              # config 5 shape
+    ("ragged", lambda: distorted_box(5, 1, 1), 4, "hyperFS", dict()),   # nelem not a multiple of the block's elements; no BC
+]
+
+
+@pytest.mark.parametrize("name,mk,degree,problem,bc", CASES, ids=[c[0] for c in CASES])
+def test_all_operators_match_oracle(oracle, gpu, name, mk, degree, problem, bc):
+    mesh = mk()
+    pa, pb = build_pair(oracle, gpu, mesh, degree, problem, nu=0.3, E=2.5, **bc)
+    rng = np.random.default_rng(42)
+    # geometry (opSetupGeo): identical layout [elem][comp][point] on both backends
+    assert rel_err(pb.qdata.to_numpy(), pa.qdata.to_numpy()) < 1e-13
+    n = pa.lsize()
+    u = pa.smooth_state(0.15)
+    # residual (+ stored state)
+    xa, xb = vec_pair(pa, pb, n, u)
+    ya, yb = vec_pair(pa, pb, n)
+    pa.form_residual(xa, ya); pb.form_residual(xb, yb)
+    assert "fused_grad" in pb.opApply.kernel_name
+    assert rel_err(yb.to_numpy(), ya.to_numpy()) < TOL
+    if pa.gradu is not None:
+        assert rel_err(pb.gradu.to_numpy(), pa.gradu.to_numpy()) < 1e-12
+    # Jacobian, transfer and diagonal on every level
+    for lv in range(len(pa.levels)):
+        nl = pa.lsize(lv)
+        x = rng.uniform(-1, 1, nl)
+        xa, xb = vec_pair(pa, pb, nl, x)
+        ya, yb = vec_pair(pa, pb, nl)
+        pa.apply_jacobian(lv, xa, ya); pb.apply_jacobian(lv, xb, yb)
+        ja, jb = ya.to_numpy(), yb.to_numpy()
+        assert rel_err(jb, ja) < TOL, (lv, rel_err(jb, ja))
+        assert np.all(jb[pa.levels[lv].mask != 0] == 0.0)       # constrained rows dropped
+        da, db = vec_pair(pa, pb, nl)
+        db.set_value(7.0)                                        # overwrite semantics (matops.c:227)
+        pa.get_diag(lv, da); pb.get_diag(lv, db)
+        assert rel_err(db.to_numpy(), da.to_numpy()) < TOL
+        assert rel_err(pb.levels[lv].multinv.to_numpy(), pa.levels[lv].multinv.to_numpy()) == 0.0
+        if lv > 0:
+            nc = pa.lsize(lv - 1)
+            xc = rng.uniform(-1, 1, nc)
+            ca, cb = vec_pair(pa, pb, nc, xc)
+            fa, fb = vec_pair(pa, pb, nl)
+            pa.prolong(lv, ca, fa); pb.prolong(lv, cb, fb)
+            assert rel_err(fb.to_numpy(), fa.to_numpy()) < TOL
+            fa, fb = vec_pair(pa, pb, nl, x)
+            ca, cb = vec_pair(pa, pb, nc)
+            pa.restrict(lv, fa, ca); pb.restrict(lv, fb, cb)
+            assert rel_err(cb.to_numpy(), ca.to_numpy()) < TOL
+
+
+def test_restriction_indices_bit_exact(oracle, gpu):
+    """Gather through the offsets is a pure copy: the E-vectors must be bitwise identical."""
+    mesh = distorted_box(3, 3, 2)
+    from ceedpetscsolid_amd.mesh import build_dofmap
+    dm = build_dofmap(mesh, 3)
+    rng = np.random.default_rng(5)
+    lv = rng.uniform(-1, 1, dm.lsize)
+    outs = []
+    for c in (oracle, gpu):
+        r = c.elem_restriction(mesh.nelem, dm.P ** 3, 3, 1, dm.lsize, dm.offsets())
+        L = c.vector(dm.lsize).set_array(lv)
+        E = r.create_evector()
+        r.apply(cd.NOTRANSPOSE, L, E)
+        M = r.create_lvector(); r.multiplicity(M)
+        outs.append((E.to_numpy(), M.to_numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert outs[1][1].sum() == mesh.nelem * dm.P ** 3 * 3
+
+
+def test_log1p_range_shift_branches_on_gpu(oracle, gpu):
+    """hyperFS.h:49-55: drive det(C)-1 outside (sqrt2/2-1, sqrt2-1) with a large uniform
+    stretch / compression so both range-shift branches of the series run on the GPU."""
+    mesh = box_mesh(2, 2, 2)
+    for scale in (-0.25, 0.3):
+        pa, pb = build_pair(oracle, gpu, mesh, 2, "hyperFS", nu=0.3, E=1.0)
+        n = pa.lsize()
+        u = (scale * pa.levels[pa.fine].dofmap.node_coords).reshape(-1)
+        xa, xb = vec_pair(pa, pb, n, u); ya, yb = vec_pair(pa, pb, n)
+        pa.form_residual(xa, ya); pb.form_residual(xb, yb)
+        assert rel_err(yb.to_numpy(), ya.to_numpy()) < TOL
+        x = np.random.default_rng(3).uniform(-1, 1, n)
+        xa, xb = vec_pair(pa, pb, n, x)
+        pa.apply_jacobian(pa.fine, xa, ya); pb.apply_jacobian(pb.fine, xb, yb)
+        assert rel_err(yb.to_numpy(), ya.to_numpy()) < TOL
+
+
+def test_config2_cube4096_p3_linelas(oracle, gpu):
+    """BASELINE config 2: linElas, cube8_4096e_6ss_s, degree 3, Jacobian apply vs the CPU path."""
+    mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cube8_4096e_6ss_s.npz"))
+    pa, pb = build_pair(oracle, gpu, mesh, 3, "linElas", nu=0.3, E=1e6, bc_sides=[999] if 999 in mesh.side_sets else [992])
+    n = pa.lsize()
+    assert n == 352947
+    x = np.random.default_rng(0).uniform(-1, 1, n)
+    xa, xb = vec_pair(pa, pb, n, x); ya, yb = vec_pair(pa, pb, n)
+    pa.apply_jacobian(pa.fine, xa, ya); pb.apply_jacobian(pb.fine, xb, yb)
+    assert rel_err(yb.to_numpy(), ya.to_numpy()) < TOL
+
+
+def test_config3_cylinder5580_p4_hyperss(oracle, gpu):
+    """BASELINE config 3's operator: hyperSS, cylinder8_5580e_4ss_us, degree 4 (levels 1,2,4)."""
+    mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_5580e_4ss_us.npz"))
+    pa, pb = build_pair(oracle, gpu, mesh, 4, "hyperSS", nu=0.3, E=1e3, bc_sides=[998, 999])
+    n = pa.lsize()
+    assert n == 1159692 and pa.degrees == [1, 2, 4]
+    u = pa.smooth_state(0.05)
+    xa, xb = vec_pair(pa, pb, n, u); ya, yb = vec_pair(pa, pb, n)
+    pa.form_residual(xa, ya); pb.form_residual(xb, yb)
+    assert rel_err(yb.to_numpy(), ya.to_numpy()) < TOL
+    for lv in range(3):
+        nl = pa.lsize(lv)
+        x = np.random.default_rng(lv).uniform(-1, 1, nl)
+        xa, xb = vec_pair(pa, pb, nl, x); ya, yb = vec_pair(pa, pb, nl)
+        pa.apply_jacobian(lv, xa, ya); pb.apply_jacobian(lv, xb, yb)
+        assert rel_err(yb.to_numpy(), ya.to_numpy()) < TOL
+
+
+def test_full_size_properties_config4(gpu):
+    """BASELINE config 4 at full size (hyperFS, ~99k-element hollow cylinder, degree 4): too big
+    for the oracle in seconds, so size-independent properties: symmetry of the tangent
+    (v'Jw = w'Jv), linearity, rigid-translation null space without BCs."""
+    mesh = hollow_cylinder_mesh(10, 110, 90)
+    assert mesh.nelem == 99000
+    p = SolidProblem(gpu, mesh, 4, "hyperFS", nu=0.3, E=1.0, multigrid="none")
+    n = p.lsize()
+    c = p.ceed
+    u = p.smooth_state(0.1)
+    X, Y = c.vector(n).set_array(u), c.vector(n)
+    p.form_residual(X, Y)
+    rng = np.random.default_rng(11)
+    v, w = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    def J(z):
+        X.set_array(z); p.apply_jacobian(p.fine, X, Y); return Y.to_numpy()
+    jv, jw = J(v), J(w)
+    assert abs(v @ jw - w @ jv) < 1e-11 * abs(v @ jw)
+    assert rel_err(J(2.0 * v - 0.5 * w), 2.0 * jv - 0.5 * jw) < 1e-12
+    t = np.tile([0.3, -1.0, 2.0], n // 3)
+    assert np.abs(J(t)).max() < 1e-11 * np.abs(jv).max()
+
+
+def test_device_pointer_use_pointer_roundtrip(gpu):
+    """matops.c:40-50 with -memtype device: SetArray(DEVICE, USE_POINTER) / TakeArray on
+    buffers owned by the caller (torch tensors standing in for PETSc's device Vecs)."""
+    import torch
+    mesh = box_mesh(2, 2, 2)
+    p = SolidProblem(gpu, mesh, 2, "linElas", nu=0.3, E=1.0, bc_sides=[1])
+    n = p.lsize()
+    x = torch.rand(n, dtype=torch.float64, device="cuda")
+    y = torch.full((n,), 3.0, dtype=torch.float64, device="cuda")
+    lv = p.levels[p.fine]
+    lv.xceed.set_device_pointer(x.data_ptr()); lv.yceed.set_device_pointer(y.data_ptr())
+    p.apply_jacobian(p.fine, lv.xceed, lv.yceed)
+    lv.xceed.take_array(cd.MEM_DEVICE); lv.yceed.take_array(cd.MEM_DEVICE)
+    torch.cuda.synchronize()
+    X, Y = p.ceed.vector(n).set_array(x.cpu().numpy()), p.ceed.vector(n)
+    p.apply_jacobian(p.fine, X, Y)
+    assert rel_err(y.cpu().numpy(), Y.to_numpy()) < 1e-13
+
+
+def test_unsupported_graphs_fail_loudly(gpu):
+    with pytest.raises(cd.CeedError):
+        gpu.qfunction("SomeUserQFunction", source="user.h:SomeUserQFunction")
+    b = gpu.basis_lagrange(3, 3, 3, 3, cd.GAUSS)
+    with pytest.raises(cd.CeedError):
+        b.apply(1, cd.NOTRANSPOSE, cd.EVAL_INTERP, gpu.vector(81), gpu.vector(81))
