@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- MDoF/s of the matrix-free Jacobian apply (BASELINE.json metric).
+
+One "step" = one y = J(u) x with the semantics of ApplyJacobian_Ceed -> ApplyLocalCeedOp
+(reference src/matops.c:98-112,26-60): homogeneous Dirichlet rows/columns removed, gather ->
+grad -> HyperFSdF -> grad^T -> scatter-add, plus (N > 1) the interface-dof halo sum that
+replaces DMLocalToGlobal(ADD_VALUES).  Inputs are resident in HBM before the timed region.
+
+Workload (config.workload): BASELINE config 4 -- hyperFS, degree 4, ~99k-element hollow
+cylinder (R 0.5-1, height 10; structured stand-in for the absent cylinder8_99Ke_4ss_us.exo,
+same geometry and side-set ids), clamped at both ends.  N > 1 is WEAK scaling: every rank
+owns one such 99 000-element z-slab of a cylinder N slabs tall; ranks exchange the slab
+interfaces over RCCL (torch.distributed "nccl").
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+           --master-port 29500 bench.py --gpus 8 --steps 50 --warmup 5
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from ceedpetscsolid_amd import ceed as cd  # noqa: E402
+from ceedpetscsolid_amd.halo import HaloExchange, slab_cylinder  # noqa: E402
+from ceedpetscsolid_amd.solid import SolidProblem  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def coord_hash_vector(coords: np.ndarray, mask: np.ndarray) -> np.ndarray:
+    """Deterministic pseudo-random x in (-1, 1) from node coordinates: identical on every rank
+    that shares a node, zero on constrained dofs."""
+    k = np.array([[12.9898, 78.233, 37.719], [93.989, 67.345, 24.113], [45.164, 11.135, 83.951]])
+    v = np.sin(coords @ k.T) * 43758.5453
+    x = 2.0 * (v - np.floor(v)) - 1.0
+    return (x.reshape(-1) * (mask == 0)).astype(np.float64)
+
+
+def algorithmic_bytes(nelem: int, P: int, Q: int, lsize: int, state: bool) -> int:
+    """per element 8*(10 [+9])*Q^3 q-point data + 4*P^3 offsets; per L-dof 8 (x) + 8 (y)."""
+    return nelem * (8 * (19 if state else 10) * Q ** 3 + 4 * P ** 3) + 16 * lsize
+
+
+def cpu_baseline(args, nr, nth):
+    """The oracle (CPU restatement of the reference's /cpu/self path) on a bounded sample of the
+    same workload: a thin z-slab of the same cylinder, same degree / model / state."""
+    import ctypes as C
+    from ceedpetscsolid_amd.mesh import hollow_cylinder_mesh
+    path = os.path.join(ROOT, "oracle", "liboracle_ceed.so")
+    if not os.path.exists(path):
+        return None
+    lib = cd.CeedLib(path)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    lib.lib.OracleSetNumThreads(C.c_int(cores))
+    orc = cd.Ceed(lib, "/cpu/self/oracle")
+    nz = args.cpu_sample_layers
+    mesh = hollow_cylinder_mesh(nr, nth, nz, z0=-5.0, z1=-5.0 + 10.0 * nz / args.nz)
+    p = SolidProblem(orc, mesh, args.degree, args.problem, nu=args.nu, E=args.E, bc_sides=[998], multigrid="none")
+    n = p.lsize()
+    X, Y = orc.vector(n), orc.vector(n)
+    X.set_array(p.smooth_state(0.1)); p.form_residual(X, Y)
+    X.set_array(coord_hash_vector(p.levels[p.fine].dofmap.node_coords, p.levels[p.fine].mask))
+    p.apply_jacobian(p.fine, X, Y)  # warm-up
+    t0 = time.perf_counter(); k = 0
+    while True:
+        p.apply_jacobian(p.fine, X, Y); k += 1
+        el = time.perf_counter() - t0
+        if el > args.cpu_seconds or k >= 200:
+            break
+    return {"value": 1e-6 * p.n_free() * k / el, "unit": "MDoF/s", "cores": cores, "kind": "port",
+            "sample": f"{mesh.nelem}-element z-slab ({nr}x{nth}x{nz}) of the same cylinder, degree {args.degree} "
+                      f"{args.problem}, {k} applies in {el:.1f} s, oracle with OpenMP element chunks"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--degree", type=int, default=4)
+    ap.add_argument("--problem", default="hyperFS")
+    ap.add_argument("--nr", type=int, default=10)
+    ap.add_argument("--nth", type=int, default=110)
+    ap.add_argument("--nz", type=int, default=90)
+    ap.add_argument("--nu", type=float, default=0.3)
+    ap.add_argument("--E", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-sample-layers", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    lib = cd.CeedLib(cd.PRODUCT_LIB)          # fails loudly if the HIP library is missing
+    ceed = cd.Ceed(lib, "/gpu/hip/mi355x")
+    stream = torch.cuda.current_stream()
+    ceed.set_stream(stream.cuda_stream)
+
+    # ---- workload ---------------------------------------------------------
+    mesh = slab_cylinder(rank, world, args.nr, args.nth, args.nz)
+    bc = [s for s in (998, 999) if s in mesh.side_sets]
+    prob = SolidProblem(ceed, mesh, args.degree, args.problem, nu=args.nu, E=args.E, bc_sides=bc, multigrid="none")
+    lv = prob.levels[prob.fine]
+    n = prob.lsize()
+    halo = HaloExchange(mesh, lv.dofmap, device=dev)
+    free = (lv.mask == 0).astype(np.float64)
+    n_global = halo.global_count(free)
+
+    # state u (stores gradu through the residual), then the Jacobian input x
+    xt = torch.from_numpy(prob.smooth_state(0.1)).to(dev)
+    yt = torch.zeros(n, dtype=torch.float64, device=dev)
+    X, Y = lv.xceed, lv.yceed
+    X.set_device_pointer(xt.data_ptr()); Y.set_device_pointer(yt.data_ptr())
+    prob.form_residual(X, Y)
+    xt.copy_(torch.from_numpy(coord_hash_vector(lv.dofmap.node_coords, lv.mask)).to(dev))
+    op = lv.opJacob
+
+    def step():
+        prob.apply_jacobian(prob.fine, X, Y)   # memset(y) + fused kernel on `stream`
+        halo.add(yt)                            # interface sum (no-op at N = 1)
+
+    for _ in range(args.warmup):
+        step()
+    op.set_timing(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = op.get_timing()
+    op.set_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity on the result of the last step (cheap, outside the timed region)
+    ynorm = float(torch.linalg.vector_norm(yt).item())
+    assert np.isfinite(ynorm) and ynorm > 0.0
+
+    if rank == 0:
+        P, Q = args.degree + 1, args.degree + 1
+        abytes = algorithmic_bytes(mesh.nelem, P, Q, n, prob.info["state"])
+        avg_s = kernel_ms * 1e-3 / max(launches, 1)
+        achieved = abytes / avg_s / 1e9
+        out = {
+            "metric": "MDoF/s for matrix-free Jacobian apply, p=4 hyperFS hex, 1/2/4/8 GPU",
+            "value": 1e-6 * n_global * args.steps / elapsed,
+            "unit": "MDoF/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"config 4: {args.problem}, hollow cylinder {args.nr}x{args.nth}x{args.nz} = "
+                                   f"{mesh.nelem} hex per GPU (stand-in for cylinder8_99Ke_4ss_us.exo), degree {args.degree}, "
+                                   f"Q={Q}, clamped ends, Jacobian apply y=J(u)x",
+                       "global_dofs": n_global, "elements_per_gpu": mesh.nelem, "ldofs_per_gpu": n,
+                       "halo_dofs_rank0": halo.n_shared_dofs, "kernel": op.kernel_name,
+                       "partition": "z-slabs, one per GPU" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": abytes, "kernel_avg_us": avg_s * 1e6,
+                         "kernel_launches_timed": launches,
+                         "note": "fused operator kernel only (hipEvents on its stream); per-step also has a memset of y"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, args.nr, args.nth)
+            except Exception as e:  # the baseline is informational; never hide the GPU number
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

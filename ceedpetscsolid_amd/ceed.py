@@ -31,7 +31,9 @@ GAUSS, GAUSS_LOBATTO = 0, 1
 
 QFUNCTION_USER = C.CFUNCTYPE(C.c_int, C.c_void_p, c_int, C.POINTER(c_scalar_p), C.POINTER(c_scalar_p))
 
-PRODUCT_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libceed_mi355x.so")
+PRODUCT_LIB = os.environ.get(  # override only for A/B-ing kernel builds (tools/); must still be a *mi355x* build
+    "CEEDPETSCSOLID_MI355X_LIB",
+    os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libceed_mi355x.so"))
 
 
 class CeedError(RuntimeError):

@@ -717,6 +717,12 @@ static int op_plan(CeedOperator op) {
   return unsupported("no kernel family");
 }
 
+static void lame_constants(double nu, double E, double *lambda, double *TwoMu) {
+  // hyperSS.h:79-81 / hyperFS.h:164-167, evaluated once per apply on the host
+  *TwoMu = E / (1 + nu);
+  const double Kbulk = E / (3 * (1 - 2 * nu));
+  *lambda = (3 * Kbulk - *TwoMu) / 3;
+}
 static int read_phys(CeedQFunction qf, double *nu, double *E) {
   // The reference passes sizeof(pointer) as the context size at setuplibceed.c:826; the
   // context is the 16-byte {nu, E} struct behind the pointer (elasticity.h:33-36).
@@ -764,6 +770,7 @@ static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool 
     a.nelem = r->nelem;
     a.mask_in = (op->mask_mode & 1) ? 1 : 0; a.mask_out = (op->mask_mode & 2) ? 1 : 0;
     CHK(read_phys(qf, &a.nu, &a.E));
+    lame_constants(a.nu, a.E, &a.lambda, &a.TwoMu);
     if (!add) HIPCHK(hipMemsetAsync(py, 0, sizeof(double) * (size_t)out->length, s));
     {
       TimerScope ts(op, s);
@@ -852,6 +859,7 @@ extern "C" int CeedOperatorLinearAssembleDiagonal(CeedOperator op, CeedVector as
   a.offsets = op->d_off_flagged_in ? op->d_off_flagged_in : ai.rstr->d_offsets;
   a.diag = pd; a.qdata = pq; a.state_in = ps; a.nelem = ai.rstr->nelem; a.mask_out = (op->mask_mode & 2) ? 1 : 0;
   CHK(read_phys(qf, &a.nu, &a.E));
+  lame_constants(a.nu, a.E, &a.lambda, &a.TwoMu);
   HIPCHK(hipMemsetAsync(pd, 0, sizeof(double) * (size_t)assembled->length, s));  // overwrite semantics (matops.c:227)
   const char *kname = "";
   hipError_t e = launch_diag(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, a, s, &kname);

@@ -44,7 +44,7 @@ struct FusedGradArgs {
   double *state_out;        // [nelem][9][Q^3] or null
   int nelem;
   int mask_in, mask_out;    // honour the Dirichlet flags on gather / scatter
-  double nu, E;
+  double nu, E, lambda, TwoMu;
 };
 
 struct TransferArgs {
@@ -69,7 +69,7 @@ struct DiagArgs {
   double *diag;  // pre-zeroed L-vector
   const double *qdata, *state_in;
   int nelem, mask_out;
-  double nu, E;
+  double nu, E, lambda, TwoMu;
 };
 
 // Each returns hipSuccess or the launch error; `name` receives a static string

@@ -26,7 +26,10 @@ constexpr int next_pow2(int n) { int p = 1; while (p < n) p *= 2; return p; }
 template <int Q> struct Geom {
   static constexpr int Q3 = cpow3(Q);
   static constexpr int TPE = Q3 <= 32 ? next_pow2(Q3) : ((Q3 + 63) / 64) * 64;
-  static constexpr int EPB = TPE >= 256 ? 1 : 256 / TPE;
+#ifndef CPS_BLOCK_TARGET
+#define CPS_BLOCK_TARGET 256
+#endif
+  static constexpr int EPB = TPE >= CPS_BLOCK_TARGET ? 1 : CPS_BLOCK_TARGET / TPE;
   static constexpr int BLOCK = TPE * EPB;
 };
 

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(Geom<Q>::TPE) void k_diag(const BasisTables tab, co
       for (int c = 0; c < 3; c++) {
 #pragma unroll
         for (int s = 0; s < 9; s++) ug[s] = (s == din * 3 + c) ? 1. : 0.;
-        qf_point<QF>(Phys{a.nu, a.E}, ug, qd, st, dv, sto);
+        qf_point<QF>(Phys{a.nu, a.E, a.lambda, a.TwoMu}, ug, qd, st, dv, sto);
         for (int dout = 0; dout < 3; dout++) sD[((c * 3 + dout) * 3 + din) * Q3 + q] = dv[dout * 3 + c];
       }
   }

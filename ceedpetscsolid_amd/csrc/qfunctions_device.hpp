@@ -19,7 +19,10 @@
 
 namespace cps {
 
-struct Phys { double nu, E; };  // elasticity.h:33-36 (nu first)
+// {nu, E} as in elasticity.h:33-36, plus the Lame constants derived from them ON THE HOST with
+// the reference's formulas (hyperSS.h:79-81; IEEE division is correctly rounded on both sides,
+// so the values are bit-identical) to keep f64 divisions out of the per-point code.
+struct Phys { double nu, E, lambda, TwoMu; };
 
 #define CPS_DEV static __device__ __forceinline__
 
@@ -72,15 +75,14 @@ CPS_DEV double log1p_series4(double x) {  // hyperSS.h:43-55
   double y = x / (2. + x);
   const double y2 = y * y;
   double sum = y;
-  y *= y2; sum += y / 3;
-  y *= y2; sum += y / 5;
-  y *= y2; sum += y / 7;
+  y *= y2; sum += y * (1. / 3);
+  y *= y2; sum += y * (1. / 5);
+  y *= y2; sum += y * (1. / 7);
   return 2 * sum;
 }
 CPS_DEV void lame(const Phys ph, double &lambda, double &TwoMu) {  // hyperSS.h:79-81
-  TwoMu = ph.E / (1 + ph.nu);
-  const double Kbulk = ph.E / (3 * (1 - 2 * ph.nu));
-  lambda = (3 * Kbulk - TwoMu) / 3;
+  TwoMu = ph.TwoMu;
+  lambda = ph.lambda;
 }
 CPS_DEV void qf_hyperss_f(const Phys ph, const double *ug, const double *qd, double *dv, double *st) {
   double lambda, TwoMu, g[3][3], sig[3][3];
@@ -123,9 +125,9 @@ CPS_DEV double log1p_series4_shifted(double x) {  // hyperFS.h:45-67
   double y = x / (2. + x);
   const double y2 = y * y;
   sum += y;
-  y *= y2; sum += y / 3;
-  y *= y2; sum += y / 5;
-  y *= y2; sum += y / 7;
+  y *= y2; sum += y * (1. / 3);
+  y *= y2; sum += y * (1. / 5);
+  y *= y2; sum += y * (1. / 7);
   return 2 * sum;
 }
 // Symmetric 3x3 kept as 6 scalars in the reference's packing (hyperFS.h:91):
@@ -149,9 +151,9 @@ CPS_DEV void fs_state(double lambda, double mu, const double g[3][3], FSState &s
   const double C00 = 1 + E2[0], C11 = 1 + E2[1], C22 = 1 + E2[2], C12 = E2[3], C02 = E2[4], C01 = E2[5];
   const double A[6] = {C11 * C22 - C12 * C12, C00 * C22 - C02 * C02, C00 * C11 - C01 * C01,
                        C02 * C01 - C00 * C12, C01 * C12 - C02 * C11, C02 * C12 - C01 * C22};
-  const double den = detCm1 + 1.;
+  const double rden = 1. / (detCm1 + 1.);  // one reciprocal instead of six divisions (<= 1 ulp apart)
 #pragma unroll
-  for (int m = 0; m < 6; m++) s.Ci[m] = A[m] / den;
+  for (int m = 0; m < 6; m++) s.Ci[m] = A[m] * rden;
   s.llnj = lambda * log1p_series4_shifted(detCm1) / 2.;
 #pragma unroll
   for (int m = 0; m < 6; m++) {

@@ -338,6 +338,9 @@ int CeedElemRestrictionCreateVector(CeedElemRestriction r, CeedVector *lvec,
 /* E-layout is [e][c][n] everywhere in the oracle. */
 static void rstr_gather(CeedElemRestriction r, const CeedScalar *l, CeedScalar *e) {
   const CeedInt S = r->elemsize, C = r->ncomp;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(g_nthreads) if (g_nthreads > 1) schedule(static)
+#endif
   for (CeedInt el = 0; el < r->nelem; el++)
     for (CeedInt c = 0; c < C; c++)
       for (CeedInt n = 0; n < S; n++) {
