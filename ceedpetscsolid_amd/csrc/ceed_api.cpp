@@ -126,6 +126,7 @@ struct CeedOperator_private {
   int mask_mode = 0;
   // optional fine-side scale for transfers
   CeedVector scale = nullptr;
+  unsigned long long *stamps = nullptr;  // diagnostic builds only
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -771,6 +772,7 @@ static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool 
     a.mask_in = (op->mask_mode & 1) ? 1 : 0; a.mask_out = (op->mask_mode & 2) ? 1 : 0;
     CHK(read_phys(qf, &a.nu, &a.E));
     lame_constants(a.nu, a.E, &a.lambda, &a.TwoMu);
+    a.stamps = op->stamps;
     if (!add) HIPCHK(hipMemsetAsync(py, 0, sizeof(double) * (size_t)out->length, s));
     {
       TimerScope ts(op, s);
@@ -931,6 +933,9 @@ extern "C" int CeedXOperatorGetTiming(CeedOperator op, double *ms, int64_t *laun
   *ms = op->ms_accum; *launches = op->launches;
   return 0;
 }
+
+// Diagnostic builds (-DCPS_STAMPS) write 8 s_memtime stamps per wave here; ignored otherwise.
+extern "C" int CeedXOperatorSetStampBuffer(CeedOperator op, void *dev) { op->stamps = (unsigned long long *)dev; return 0; }
 
 // Vector helpers standing in for the PETSc Vec calls of src/matops.c on device data.
 extern "C" int CeedXVectorPointwiseMult(CeedVector w, CeedVector x, CeedVector y) {

@@ -30,9 +30,18 @@ template <int Q> struct WaveGeom {
   static constexpr int SLAB = 12 * Q3;                                           // doubles of LDS per element
 };
 
-// All LDS traffic of a wave is in-order; in a single-wave workgroup this only keeps
-// the compiler from moving LDS accesses across a phase boundary.
-CPS_DEV void wave_sync() { __syncthreads(); }
+// Phase boundary inside ONE wave.  The hardware executes a wave's LDS instructions in
+// order, so a ds_write followed by another lane's ds_read of that address needs no wait
+// and no s_barrier -- only the COMPILER must not move LDS accesses across the boundary.
+// A wavefront-scope fence does exactly that and emits no instruction; in particular it
+// does not drain vmcnt, so the q-point loads issued at kernel entry stay in flight across
+// the whole interpolation (a __syncthreads() here cost 30 % of the wave's lifetime in
+// `s_waitcnt vmcnt(0)`: tools/stamp_profile.py, round 1).
+CPS_DEV void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 template <int P, int Q, int QF>
 __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const FusedGradArgs a) {
@@ -45,6 +54,13 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   __shared__ double sD[Q * Q];
   __shared__ double slab[EPW][G::SLAB];
 
+#ifdef CPS_STAMPS  // diagnostic build: where does a wave's lifetime go?  (never in the product build)
+  unsigned long long stamp_[8]; int nst_ = 0;
+#define CPS_STAMP() do { __builtin_amdgcn_sched_barrier(0); stamp_[nst_++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CPS_STAMP() do {} while (0)
+#endif
+  CPS_STAMP();
   const int lane = threadIdx.x;
   const int el = EPW > 1 ? lane / TPE : 0;
   const int q0 = EPW > 1 ? lane % TPE : lane;  // slot s handles point q0 + 64 s
@@ -55,43 +71,57 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   // disjoint from RA, which holds the interpolated field while the physics runs).
   double *RA = slab[el], *RB = RA + 3 * Q3, *RC = RA + 6 * Q3, *RG = RA + 3 * Q3;
 
+  // All global loads are unconditional and in-bounds (indices clamped, results selected
+  // afterwards): no exec-mask branches around loads, so a wave's loads issue back to back.
+  const int ec = live ? e : a.nelem - 1;
   double qd[10], st[9];
   auto load_point = [&](int q) {
-    if (live && q < Q3) {
-      const double *qp = a.qdata + (size_t)e * 10 * Q3 + q;
+#ifdef CPS_ABLATE_QDATA  // timing-only build: no q-point stream (WRONG results)
+    for (int c = 0; c < 10; c++) qd[c] = (c == 1 || c == 5 || c == 9 || c == 0) ? 1.0 + 1e-3 * q : 1e-3 * c;
+    for (int c = 0; c < 9; c++) st[c] = 1e-3 * (c + lane);
+    return;
+#endif
+    const int qc = q < Q3 ? q : Q3 - 1;
+    const double *qp = a.qdata + (size_t)ec * 10 * Q3 + qc;
 #pragma unroll
-      for (int c = 0; c < 10; c++) qd[c] = qp[c * Q3];
-      if constexpr (ST_IN) {
-        const double *sp = a.state_in + (size_t)e * 9 * Q3 + q;
+    for (int c = 0; c < 10; c++) qd[c] = qp[c * Q3];
+    if constexpr (ST_IN) {
+      const double *sp = a.state_in + (size_t)ec * 9 * Q3 + qc;
 #pragma unroll
-        for (int c = 0; c < 9; c++) st[c] = sp[c * Q3];
-      }
+      for (int c = 0; c < 9; c++) st[c] = sp[c * Q3];
     }
   };
 
-  // ---- gather ---------------------------------------------------------------------------
+  // ---- gather: offsets of every slot first, then all x loads, then slot 0's q-point data ---
+  // (vmcnt retires in order: the q-point loads go LAST so that waiting for x leaves them in
+  // flight across the interpolation).
   uint32_t off[SLOTS];
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
     const int n = q0 + 64 * s;
-    off[s] = 0;
-    if (n < P3) {
-      double xin[3] = {0., 0., 0.};
-      if (live) {
-        off[s] = a.offsets[(size_t)e * P3 + n];
-        const uint32_t base = off[s] & OFF_MASK;
-        const uint32_t fl = a.mask_in ? (off[s] >> OFF_FLAG_SHIFT) : 0u;
+    off[s] = a.offsets[(size_t)ec * P3 + (n < P3 ? n : P3 - 1)];
+  }
+  double xin[SLOTS][3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) xin[c] = ((fl >> c) & 1u) ? 0. : a.x[base + c];
-      }
+  for (int s = 0; s < SLOTS; s++) {
+    const uint32_t base = off[s] & OFF_MASK;
 #pragma unroll
-      for (int c = 0; c < 3; c++) RA[c * P3 + n] = xin[c];
-    }
+    for (int c = 0; c < 3; c++) xin[s][c] = a.x[base + c];
   }
   load_point(q0);  // slot 0's q-point data: in flight across the interpolation
   for (int i = lane; i < Q * P; i += 64) sB[i] = tab.interp[i];
   for (int i = lane; i < Q * Q; i += 64) sD[i] = tab.colo[i];
+#pragma unroll
+  for (int s = 0; s < SLOTS; s++) {
+    const int n = q0 + 64 * s;
+    if (n < P3) {
+      const uint32_t fl = (a.mask_in && live) ? (off[s] >> OFF_FLAG_SHIFT) : (live ? 0u : 7u);
+#pragma unroll
+      for (int c = 0; c < 3; c++) RA[c * P3 + n] = ((fl >> c) & 1u) ? 0. : xin[s][c];
+    }
+  }
   wave_sync();
+  CPS_STAMP();  // 1: gather landed in LDS
 
   // ---- B: nodes -> points (x, y, z passes) -----------------------------------------------
 #pragma unroll
@@ -151,6 +181,7 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
     }
   }
   wave_sync();
+  CPS_STAMP();  // 2: interpolated
 
   // ---- collocated gradient + physics, one point slot at a time ---------------------------
 #pragma unroll
@@ -193,6 +224,7 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
     }
   }
   wave_sync();
+  CPS_STAMP();  // 3: physics done
 
   // ---- collocated gradient^T: RG[d][c] -> RA[c]  (RA is dead: every slot has read it) ------
 #pragma unroll
@@ -218,6 +250,7 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
     }
   }
   wave_sync();
+  CPS_STAMP();  // 4: gradient^T done
 
   // ---- B^T: points -> nodes (z^T, y^T, x^T), then scatter-add -------------------------------
 #pragma unroll
@@ -274,10 +307,24 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
         double t = 0.;
 #pragma unroll
         for (int m = 0; m < Q; m++) t += b[m] * u[m];
+#if defined(CPS_ABLATE_ATOMICS)   // timing-only build: plain store instead of the atomic (WRONG results)
+        if (!((fl >> c) & 1u)) a.y[base + c] = t;
+#elif defined(CPS_ABLATE_SCATTER)  // timing-only build: no scatter at all
+        asm volatile("" ::"v"(t));
+#else
         if (!((fl >> c) & 1u)) atomic_add_f64(a.y + base + c, t);
+#endif
       }
     }
   }
+  CPS_STAMP();  // 5: atomics issued
+#ifdef CPS_STAMPS
+  if (a.stamps && lane == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    stamp_[nst_++] = __builtin_amdgcn_s_memtime();  // 6: all memory ops retired
+    for (int i = 0; i < nst_; i++) a.stamps[(size_t)blockIdx.x * 8 + i] = stamp_[i];
+  }
+#endif
 }
 
 template <int P, int Q, int QF>

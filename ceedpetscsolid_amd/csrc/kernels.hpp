@@ -45,6 +45,7 @@ struct FusedGradArgs {
   int nelem;
   int mask_in, mask_out;    // honour the Dirichlet flags on gather / scatter
   double nu, E, lambda, TwoMu;
+  unsigned long long *stamps;  // diagnostic builds only (-DCPS_STAMPS): 8 s_memtime stamps per wave
 };
 
 struct TransferArgs {
