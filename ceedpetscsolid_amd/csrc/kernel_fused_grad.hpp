@@ -1,33 +1,45 @@
 // kernel_fused_grad.hpp -- the whole CeedOperatorApply of the residual / Jacobian
 // operators (setuplibceed.c:517-542, :817-839) in ONE launch:
 //   E-vector gather (offsets, Dirichlet flags) -> sum-factorised interpolation to
-//   the Gauss points -> collocated gradient -> pointwise physics in registers
-//   (q-point data streamed once, coalesced, prefetched one point-slot ahead) ->
-//   collocated gradient^T -> interpolation^T -> f64 atomic scatter-add.
+//   the Gauss points -> gradient (z-derivative for free inside the z-pass, x/y by
+//   the collocated derivative) -> pointwise physics in registers (q-point data
+//   streamed once, coalesced, prefetched one point-slot ahead) -> gradient^T ->
+//   interpolation^T -> f64 atomic scatter-add.
 // Nothing but the L-vectors and the q-point data touches HBM: no E-vector, no
 // quadrature-point intermediate is ever written out.
 //
-// Wave-per-element, barrier-free (v2).  A workgroup is ONE wave64 and owns its
+// Wave-per-element, barrier-free.  A workgroup is ONE wave64 and owns its
 // element(s) outright, so every LDS write -> read dependency stays inside one
 // wave, where the LDS queue is in-order: no cross-wave barrier is ever needed and
 // the waves of a CU never wait for each other (v1, two waves per element around
-// ten workgroup barriers, spent 54 % of its wave-cycles in SQ_WAIT_ANY:
-// profiles/r01_pmc_v1.txt).  Each lane owns SLOTS quadrature points of the element
-// (q = lane + 64 s): Q=5 -> 125 points on 2 x 64 slots (97.7 % of lane-slots
-// busy), Q=4 -> one point per lane, Q=7 -> 6 slots; small elements share a wave
-// (Q=3: two elements, Q=2: eight).
+// ten workgroup barriers, spent 54 % of its wave-cycles in SQ_WAIT_ANY).  Each lane
+// owns SLOTS quadrature points of the element (q = lane + 64 s): Q=5 -> 125 points
+// on 2 x 64 slots (97.7 % of lane-slots busy), Q=4 -> one point per lane, Q=7 -> 6
+// slots; small elements share a wave (Q=3: two elements, Q=2: eight).
+//
+// LDS layout (v3).  Every 1-D contraction reads a ROW that is contiguous in LDS:
+// each pass writes its result with the NEXT pass's contraction index fastest, and
+// rows are padded to an even length so they are 16-byte aligned.  A row of 5
+// doubles is then 2 x ds_read_b128 + 1 x ds_read_b64 (10 LDS cycles) instead of
+// the 2.5 x ds_read2_b64 (20 cycles: ds_read2_b64 runs at half the byte rate on
+// gfx950, MI355X_MICROARCH.md LDS table) hipcc emits for strided scalar reads;
+// v2 had the LDS pipe busy 41 % of the kernel on those.
 #pragma once
 #include "kernels_common.hpp"
 #include "qfunctions_device.hpp"
 
 namespace cps {
 
-template <int Q> struct WaveGeom {
+constexpr int pad2(int n) { return n + (n & 1); }
+
+template <int P, int Q> struct WaveGeom {
   static constexpr int Q3 = Q * Q * Q;
   static constexpr int TPE = Q3 <= 32 ? next_pow2(Q3) : ((Q3 + 63) / 64) * 64;  // point slots per element
   static constexpr int EPW = TPE >= 64 ? 1 : 64 / TPE;                           // elements per wave
   static constexpr int SLOTS = TPE >= 64 ? TPE / 64 : 1;                         // point slots per lane
-  static constexpr int SLAB = 12 * Q3;                                           // doubles of LDS per element
+  static constexpr int LD = pad2(Q), LDP = pad2(P);                              // padded row lengths
+  static constexpr int BLK = 3 * Q * Q * LD;                                     // one 3-component block
+  static constexpr int SLAB = 5 * BLK;                                           // doubles of LDS per element
 };
 
 // Phase boundary inside ONE wave.  The hardware executes a wave's LDS instructions in
@@ -35,24 +47,51 @@ template <int Q> struct WaveGeom {
 // and no s_barrier -- only the COMPILER must not move LDS accesses across the boundary.
 // A wavefront-scope fence does exactly that and emits no instruction; in particular it
 // does not drain vmcnt, so the q-point loads issued at kernel entry stay in flight across
-// the whole interpolation (a __syncthreads() here cost 30 % of the wave's lifetime in
-// `s_waitcnt vmcnt(0)`: tools/stamp_profile.py, round 1).
+// the whole interpolation.
 CPS_DEV void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// dot product of a coefficient row (registers) with a 16-byte-aligned LDS row of N doubles
+template <int N>
+CPS_DEV double row_dot(const double *coef, const double *row) {
+  double t = 0.;
+#pragma unroll
+  for (int m = 0; m + 1 < N; m += 2) {
+    const double2 v = *reinterpret_cast<const double2 *>(row + m);
+    t += coef[m] * v.x;
+    t += coef[m + 1] * v.y;
+  }
+  if (N & 1) t += coef[N - 1] * row[N - 1];
+  return t;
+}
+template <int N>
+CPS_DEV void row_load(const double *row, double *r) {
+#pragma unroll
+  for (int m = 0; m + 1 < N; m += 2) {
+    const double2 v = *reinterpret_cast<const double2 *>(row + m);
+    r[m] = v.x; r[m + 1] = v.y;
+  }
+  if (N & 1) r[N - 1] = row[N - 1];
+}
+
 template <int P, int Q, int QF>
 __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const FusedGradArgs a) {
-  using G = WaveGeom<Q>;
+  using G = WaveGeom<P, Q>;
   constexpr int Q3 = G::Q3, P3 = P * P * P, TPE = G::TPE, EPW = G::EPW, SLOTS = G::SLOTS;
+  constexpr int LD = G::LD, LDP = G::LDP, BLK = G::BLK;
   constexpr bool ST_IN = QFTraits<QF>::state_in, ST_OUT = QFTraits<QF>::state_out;
   static_assert(P <= Q, "interpolation to at least as many points as nodes");
 
-  __shared__ double sB[Q * P];
-  __shared__ double sD[Q * Q];
-  __shared__ double slab[EPW][G::SLAB];
+  // coefficient tables, rows padded to even length (16-byte aligned rows)
+  __shared__ __attribute__((aligned(16))) double sB[Q * LDP];    // B[q][p]
+  __shared__ __attribute__((aligned(16))) double sG[Q * LDP];    // G[q][p]  (grad1d)
+  __shared__ __attribute__((aligned(16))) double sBt[P * LD];    // B^T[p][q]
+  __shared__ __attribute__((aligned(16))) double sD[Q * LD];     // Dq[q][m] (collocated derivative)
+  __shared__ __attribute__((aligned(16))) double sDt[Q * LD];    // Dq^T[q][m] = Dq[m][q]
+  __shared__ __attribute__((aligned(16))) double slab[EPW][G::SLAB];
 
 #ifdef CPS_STAMPS  // diagnostic build: where does a wave's lifetime go?  (never in the product build)
   unsigned long long stamp_[8]; int nst_ = 0;
@@ -66,10 +105,8 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   const int q0 = EPW > 1 ? lane % TPE : lane;  // slot s handles point q0 + 64 s
   const int e = blockIdx.x * EPW + el;
   const bool live = e < a.nelem;
-  // Element slab: RA, RB, RC = 3*Q3 work regions; RG = 9*Q3 region for the physics output,
-  // spanning RB, RC and a further 3*Q3 (it is written only once RB / RC are dead, and is
-  // disjoint from RA, which holds the interpolated field while the physics runs).
-  double *RA = slab[el], *RB = RA + 3 * Q3, *RC = RA + 6 * Q3, *RG = RA + 3 * Q3;
+  // five 3-component blocks, reused along the pipeline (who is dead when is noted at each phase)
+  double *B0 = slab[el], *B1 = B0 + BLK, *B2 = B0 + 2 * BLK, *B3 = B0 + 3 * BLK, *B4 = B0 + 4 * BLK;
 
   // All global loads are unconditional and in-bounds (indices clamped, results selected
   // afterwards): no exec-mask branches around loads, so a wave's loads issue back to back.
@@ -108,102 +145,104 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
 #pragma unroll
     for (int c = 0; c < 3; c++) xin[s][c] = a.x[base + c];
   }
-  load_point(q0);  // slot 0's q-point data: in flight across the interpolation
-  for (int i = lane; i < Q * P; i += 64) sB[i] = tab.interp[i];
-  for (int i = lane; i < Q * Q; i += 64) sD[i] = tab.colo[i];
+  load_point(q0);
+  for (int i = lane; i < Q * P; i += 64) {
+    const int qq = i / P, pp = i % P;
+    sB[qq * LDP + pp] = tab.interp[i];
+    sG[qq * LDP + pp] = tab.grad[i];
+    sBt[pp * LD + qq] = tab.interp[i];
+  }
+  for (int i = lane; i < Q * Q; i += 64) {
+    const int qq = i / Q, mm = i % Q;
+    sD[qq * LD + mm] = tab.colo[i];
+    sDt[mm * LD + qq] = tab.colo[i];
+  }
+  // XA = B0: [c][k][j][i], i fastest (row length LDP)
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
     const int n = q0 + 64 * s;
     if (n < P3) {
       const uint32_t fl = (a.mask_in && live) ? (off[s] >> OFF_FLAG_SHIFT) : (live ? 0u : 7u);
+      const int i = n % P, kj = n / P;
 #pragma unroll
-      for (int c = 0; c < 3; c++) RA[c * P3 + n] = ((fl >> c) & 1u) ? 0. : xin[s][c];
+      for (int c = 0; c < 3; c++) B0[(c * P * P + kj) * LDP + i] = ((fl >> c) & 1u) ? 0. : xin[s][c];
     }
   }
   wave_sync();
   CPS_STAMP();  // 1: gather landed in LDS
 
-  // ---- B: nodes -> points (x, y, z passes) -----------------------------------------------
+  // ---- B: nodes -> points ------------------------------------------------------------------
+  // x: XA[c][k][j][:] -> RB = B1: [c][k][i'][j], j fastest
 #pragma unroll
-  for (int s = 0; s < SLOTS; s++) {  // x: RA[c][k][j][i] -> RB[c][k][j][i']
+  for (int s = 0; s < SLOTS; s++) {
     const int q = q0 + 64 * s;
     if (q < P * P * Q) {
-      const int i = q % Q, kj = q / Q;
+      const int i = q % Q, kj = q / Q, j = kj % P, k = kj / P;
       double b[P];
+      row_load<P>(sB + i * LDP, b);
 #pragma unroll
-      for (int m = 0; m < P; m++) b[m] = sB[i * P + m];
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const double *u = RA + c * P3 + kj * P;
-        double t = 0.;
-#pragma unroll
-        for (int m = 0; m < P; m++) t += b[m] * u[m];
-        RB[c * Q3 + kj * Q + i] = t;
-      }
+      for (int c = 0; c < 3; c++)
+        B1[((c * P + k) * Q + i) * LDP + j] = row_dot<P>(b, B0 + (c * P * P + kj) * LDP);
     }
   }
   wave_sync();
+  // y: RB[c][k][i'][:] -> RC = B2: [c][j'][i'][k], k fastest
 #pragma unroll
-  for (int s = 0; s < SLOTS; s++) {  // y: RB[c][k][j][i'] -> RC[c][k][j'][i']
+  for (int s = 0; s < SLOTS; s++) {
     const int q = q0 + 64 * s;
     if (q < P * Q * Q) {
       const int i = q % Q, j = (q / Q) % Q, k = q / (Q * Q);
       double b[P];
+      row_load<P>(sB + j * LDP, b);
 #pragma unroll
-      for (int m = 0; m < P; m++) b[m] = sB[j * P + m];
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const double *u = RB + c * Q3 + k * (P * Q) + i;
-        double t = 0.;
-#pragma unroll
-        for (int m = 0; m < P; m++) t += b[m] * u[m * Q];
-        RC[c * Q3 + (k * Q + j) * Q + i] = t;
-      }
+      for (int c = 0; c < 3; c++)
+        B2[((c * Q + j) * Q + i) * LDP + k] = row_dot<P>(b, B1 + ((c * P + k) * Q + i) * LDP);
     }
   }
   wave_sync();
+  // z: RC[c][j'][i'][:] -> U and, from the same row, dU/dz (grad1d row).  U is stored twice:
+  // UX = B0 [c][k'][j'][i'] (i fastest) and UY = B1 [c][k'][i'][j'] (j fastest).
+  double uz[SLOTS][3];
 #pragma unroll
-  for (int s = 0; s < SLOTS; s++) {  // z: RC[c][k][j'][i'] -> RA[c][k'][j'][i']
+  for (int s = 0; s < SLOTS; s++) {
     const int q = q0 + 64 * s;
     if (q < Q3) {
-      const int ji = q % (Q * Q), k = q / (Q * Q);
-      double b[P];
-#pragma unroll
-      for (int m = 0; m < P; m++) b[m] = sB[k * P + m];
+      const int i = q % Q, j = (q / Q) % Q, k = q / (Q * Q);
+      double b[P], g[P];
+      row_load<P>(sB + k * LDP, b);
+      row_load<P>(sG + k * LDP, g);
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const double *u = RC + c * Q3 + ji;
-        double t = 0.;
+        double r[P];
+        row_load<P>(B2 + ((c * Q + j) * Q + i) * LDP, r);
+        double t = 0., tz = 0.;
 #pragma unroll
-        for (int m = 0; m < P; m++) t += b[m] * u[m * Q * Q];
-        RA[c * Q3 + q] = t;
+        for (int m = 0; m < P; m++) { t += b[m] * r[m]; tz += g[m] * r[m]; }
+        uz[s][c] = tz;
+        B0[((c * Q + k) * Q + j) * LD + i] = t;
+        B1[((c * Q + k) * Q + i) * LD + j] = t;
       }
     }
   }
   wave_sync();
   CPS_STAMP();  // 2: interpolated
 
-  // ---- collocated gradient + physics, one point slot at a time ---------------------------
+  // ---- x/y collocated gradient + physics, one point slot at a time -------------------------
+  // reads UX = B0, UY = B1; writes GX = B2 (i fastest), GY = B3 (j fastest), GZ = B4 (k fastest)
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
     const int q = q0 + 64 * s;
     const int qi = q % Q, qj = (q / Q) % Q, qk = q / (Q * Q);
     double ug[9], dv[9], sto[9];
     if (q < Q3) {
-      double d0[Q], d1[Q], d2[Q];
-#pragma unroll
-      for (int m = 0; m < Q; m++) { d0[m] = sD[qi * Q + m]; d1[m] = sD[qj * Q + m]; d2[m] = sD[qk * Q + m]; }
+      double d0[Q], d1[Q];
+      row_load<Q>(sD + qi * LD, d0);
+      row_load<Q>(sD + qj * LD, d1);
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const double *w = RA + c * Q3;
-        double s0 = 0., s1 = 0., s2 = 0.;
-#pragma unroll
-        for (int m = 0; m < Q; m++) {
-          s0 += d0[m] * w[(qk * Q + qj) * Q + m];
-          s1 += d1[m] * w[(qk * Q + m) * Q + qi];
-          s2 += d2[m] * w[(m * Q + qj) * Q + qi];
-        }
-        ug[0 * 3 + c] = s0; ug[1 * 3 + c] = s1; ug[2 * 3 + c] = s2;
+        ug[0 * 3 + c] = row_dot<Q>(d0, B0 + ((c * Q + qk) * Q + qj) * LD);
+        ug[1 * 3 + c] = row_dot<Q>(d1, B1 + ((c * Q + qk) * Q + qi) * LD);
+        ug[2 * 3 + c] = uz[s][c];
       }
     }
     if (live && q < Q3) {
@@ -220,97 +259,82 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
     if (s + 1 < SLOTS) load_point(q + 64);  // next slot's q-point data
     if (q < Q3) {
 #pragma unroll
-      for (int c = 0; c < 9; c++) RG[c * Q3 + q] = dv[c];
+      for (int c = 0; c < 3; c++) {
+        B2[((c * Q + qk) * Q + qj) * LD + qi] = dv[0 * 3 + c];
+        B3[((c * Q + qk) * Q + qi) * LD + qj] = dv[1 * 3 + c];
+        B4[((c * Q + qj) * Q + qi) * LD + qk] = dv[2 * 3 + c];
+      }
     }
   }
   wave_sync();
   CPS_STAMP();  // 3: physics done
 
-  // ---- collocated gradient^T: RG[d][c] -> RA[c]  (RA is dead: every slot has read it) ------
+  // ---- gradient^T: GX, GY, GZ -> WZ = B0 [c][j][i][k], k fastest (UX is dead) -----------------
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
     const int q = q0 + 64 * s;
     if (q < Q3) {
       const int qi = q % Q, qj = (q / Q) % Q, qk = q / (Q * Q);
       double d0[Q], d1[Q], d2[Q];
-#pragma unroll
-      for (int m = 0; m < Q; m++) { d0[m] = sD[m * Q + qi]; d1[m] = sD[m * Q + qj]; d2[m] = sD[m * Q + qk]; }
+      row_load<Q>(sDt + qi * LD, d0);
+      row_load<Q>(sDt + qj * LD, d1);
+      row_load<Q>(sDt + qk * LD, d2);
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const double *g0 = RG + (0 * 3 + c) * Q3, *g1 = RG + (1 * 3 + c) * Q3, *g2 = RG + (2 * 3 + c) * Q3;
-        double t = 0.;
-#pragma unroll
-        for (int m = 0; m < Q; m++) {
-          t += d0[m] * g0[(qk * Q + qj) * Q + m];
-          t += d1[m] * g1[(qk * Q + m) * Q + qi];
-          t += d2[m] * g2[(m * Q + qj) * Q + qi];
-        }
-        RA[c * Q3 + q] = t;
+        const double t = row_dot<Q>(d0, B2 + ((c * Q + qk) * Q + qj) * LD) +
+                         row_dot<Q>(d1, B3 + ((c * Q + qk) * Q + qi) * LD) +
+                         row_dot<Q>(d2, B4 + ((c * Q + qj) * Q + qi) * LD);
+        B0[((c * Q + qj) * Q + qi) * LD + qk] = t;
       }
     }
   }
   wave_sync();
   CPS_STAMP();  // 4: gradient^T done
 
-  // ---- B^T: points -> nodes (z^T, y^T, x^T), then scatter-add -------------------------------
+  // ---- B^T: points -> nodes, then scatter-add -----------------------------------------------
+  // z^T: WZ[c][j'][i'][:] -> TY = B1 [c][k][i'][j'], j fastest (UY is dead)
 #pragma unroll
-  for (int s = 0; s < SLOTS; s++) {  // z^T: RA[c][k'][j'][i'] -> RB[c][k][j'][i']
+  for (int s = 0; s < SLOTS; s++) {
     const int q = q0 + 64 * s;
     if (q < P * Q * Q) {
-      const int ji = q % (Q * Q), k = q / (Q * Q);
+      const int i = q % Q, j = (q / Q) % Q, k = q / (Q * Q);
       double b[Q];
+      row_load<Q>(sBt + k * LD, b);
 #pragma unroll
-      for (int m = 0; m < Q; m++) b[m] = sB[m * P + k];
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const double *u = RA + c * Q3 + ji;
-        double t = 0.;
-#pragma unroll
-        for (int m = 0; m < Q; m++) t += b[m] * u[m * Q * Q];
-        RB[c * Q3 + k * Q * Q + ji] = t;
-      }
+      for (int c = 0; c < 3; c++)
+        B1[((c * P + k) * Q + i) * LD + j] = row_dot<Q>(b, B0 + ((c * Q + j) * Q + i) * LD);
     }
   }
   wave_sync();
+  // y^T: TY[c][k][i'][:] -> TX = B2 [c][k][j][i'], i fastest (GX is dead)
 #pragma unroll
-  for (int s = 0; s < SLOTS; s++) {  // y^T: RB[c][k][j'][i'] -> RC[c][k][j][i']
+  for (int s = 0; s < SLOTS; s++) {
     const int q = q0 + 64 * s;
     if (q < P * P * Q) {
       const int i = q % Q, j = (q / Q) % P, k = q / (Q * P);
       double b[Q];
+      row_load<Q>(sBt + j * LD, b);
 #pragma unroll
-      for (int m = 0; m < Q; m++) b[m] = sB[m * P + j];
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const double *u = RB + c * Q3 + k * Q * Q + i;
-        double t = 0.;
-#pragma unroll
-        for (int m = 0; m < Q; m++) t += b[m] * u[m * Q];
-        RC[c * Q3 + (k * P + j) * Q + i] = t;
-      }
+      for (int c = 0; c < 3; c++)
+        B2[((c * P + k) * P + j) * LD + i] = row_dot<Q>(b, B1 + ((c * P + k) * Q + i) * LD);
     }
   }
   wave_sync();
+  // x^T + scatter
 #pragma unroll
-  for (int s = 0; s < SLOTS; s++) {  // x^T + scatter
+  for (int s = 0; s < SLOTS; s++) {
     const int n = q0 + 64 * s;
     if (live && n < P3) {
       const int i = n % P, kj = n / P;
       double b[Q];
-#pragma unroll
-      for (int m = 0; m < Q; m++) b[m] = sB[m * P + i];
+      row_load<Q>(sBt + i * LD, b);
       const uint32_t base = off[s] & OFF_MASK;
       const uint32_t fl = a.mask_out ? (off[s] >> OFF_FLAG_SHIFT) : 0u;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const double *u = RC + c * Q3 + kj * Q;
-        double t = 0.;
-#pragma unroll
-        for (int m = 0; m < Q; m++) t += b[m] * u[m];
+        const double t = row_dot<Q>(b, B2 + (c * P * P + kj) * LD);
 #if defined(CPS_ABLATE_ATOMICS)   // timing-only build: plain store instead of the atomic (WRONG results)
         if (!((fl >> c) & 1u)) a.y[base + c] = t;
-#elif defined(CPS_ABLATE_SCATTER)  // timing-only build: no scatter at all
-        asm volatile("" ::"v"(t));
 #else
         if (!((fl >> c) & 1u)) atomic_add_f64(a.y + base + c, t);
 #endif
@@ -329,7 +353,7 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
 
 template <int P, int Q, int QF>
 hipError_t launch_fused_grad_t(const BasisTables &t, const FusedGradArgs &a, hipStream_t s) {
-  using G = WaveGeom<Q>;
+  using G = WaveGeom<P, Q>;
   if (a.nelem <= 0) return hipSuccess;
   const int grid = (a.nelem + G::EPW - 1) / G::EPW;
   hipLaunchKernelGGL((k_fused_grad<P, Q, QF>), dim3(grid), dim3(64), 0, s, t, a);
