@@ -17,6 +17,16 @@
 // on 2 x 64 slots (97.7 % of lane-slots busy), Q=4 -> one point per lane, Q=7 -> 6
 // slots; small elements share a wave (Q=3: two elements, Q=2: eight).
 //
+// Persistent waves (v4).  The grid is a fixed number of waves per CU; each wave walks a
+// strided list of elements and software-pipelines the global traffic across elements:
+// the NEXT element's offsets are requested at the top of an element, its x values after
+// the interpolation and its first q-point slot after the last physics evaluation, so the
+// dependent offset -> x round trips (10k cycles of a 42k-cycle wave lifetime in v3:
+// tools/stamp_profile.py) and the tail wait for the atomics are off the critical path.
+// Blocks b and b+8 share an XCD (round-robin dispatch), so wave b works on the b%8-th
+// contiguous chunk of the element list: concurrently processed elements on one XCD are
+// mesh neighbours and their shared nodes hit that XCD's L2.
+//
 // LDS layout (v3).  Every 1-D contraction reads a ROW that is contiguous in LDS:
 // each pass writes its result with the NEXT pass's contraction index fastest, and
 // rows are padded to an even length so they are 16-byte aligned.  A row of 5
@@ -99,20 +109,39 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
 #else
 #define CPS_STAMP() do {} while (0)
 #endif
-  CPS_STAMP();
   const int lane = threadIdx.x;
   const int el = EPW > 1 ? lane / TPE : 0;
   const int q0 = EPW > 1 ? lane % TPE : lane;  // slot s handles point q0 + 64 s
-  const int e = blockIdx.x * EPW + el;
-  const bool live = e < a.nelem;
   // five 3-component blocks, reused along the pipeline (who is dead when is noted at each phase)
   double *B0 = slab[el], *B1 = B0 + BLK, *B2 = B0 + 2 * BLK, *B3 = B0 + 3 * BLK, *B4 = B0 + 4 * BLK;
 
+  // coefficient tables: staged once per wave, reused for every element it processes
+  for (int i = lane; i < Q * P; i += 64) {
+    const int qq = i / P, pp = i % P;
+    sB[qq * LDP + pp] = tab.interp[i];
+    sG[qq * LDP + pp] = tab.grad[i];
+    sBt[pp * LD + qq] = tab.interp[i];
+  }
+  for (int i = lane; i < Q * Q; i += 64) {
+    const int qq = i / Q, mm = i % Q;
+    sD[qq * LD + mm] = tab.colo[i];
+    sDt[mm * LD + qq] = tab.colo[i];
+  }
+
+  // ---- work list of this wave (XCD-aware) --------------------------------------------------
+  const int ngroups = (a.nelem + EPW - 1) / EPW;          // a group = the EPW elements of one wave pass
+  const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1;
+  const int xcd = blockIdx.x % nxcd, wrank = blockIdx.x / nxcd, wper = gridDim.x / nxcd;
+  const int chunk = (ngroups + nxcd - 1) / nxcd;           // contiguous groups per XCD
+  const int gbeg = xcd * chunk, gend = min(ngroups, gbeg + chunk);
+  int grp = gbeg + wrank;
+  if (grp >= gend) return;
+
   // All global loads are unconditional and in-bounds (indices clamped, results selected
   // afterwards): no exec-mask branches around loads, so a wave's loads issue back to back.
-  const int ec = live ? e : a.nelem - 1;
+  auto elem_of = [&](int g) { const int ee = g * EPW + el; return ee < a.nelem ? ee : a.nelem - 1; };
   double qd[10], st[9];
-  auto load_point = [&](int q) {
+  auto load_point = [&](int ec, int q) {
 #ifdef CPS_ABLATE_QDATA  // timing-only build: no q-point stream (WRONG results)
     for (int c = 0; c < 10; c++) qd[c] = (c == 1 || c == 5 || c == 9 || c == 0) ? 1.0 + 1e-3 * q : 1e-3 * c;
     for (int c = 0; c < 9; c++) st[c] = 1e-3 * (c + lane);
@@ -128,35 +157,39 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
       for (int c = 0; c < 9; c++) st[c] = sp[c * Q3];
     }
   };
+  auto load_offsets = [&](int ec, uint32_t *o) {
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) {
+      const int n = q0 + 64 * s;
+      o[s] = a.offsets[(size_t)ec * P3 + (n < P3 ? n : P3 - 1)];
+    }
+  };
+  auto load_x = [&](const uint32_t *o, double (*xv)[3]) {
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) {
+      const uint32_t base = o[s] & OFF_MASK;
+#pragma unroll
+      for (int c = 0; c < 3; c++) xv[s][c] = a.x[base + c];
+    }
+  };
 
-  // ---- gather: offsets of every slot first, then all x loads, then slot 0's q-point data ---
-  // (vmcnt retires in order: the q-point loads go LAST so that waiting for x leaves them in
-  // flight across the interpolation).
-  uint32_t off[SLOTS];
-#pragma unroll
-  for (int s = 0; s < SLOTS; s++) {
-    const int n = q0 + 64 * s;
-    off[s] = a.offsets[(size_t)ec * P3 + (n < P3 ? n : P3 - 1)];
-  }
+  // ---- pipeline prologue: first element's offsets, x and slot-0 q-point data ----------------
+  uint32_t off[SLOTS], off_nx[SLOTS];
   double xin[SLOTS][3];
-#pragma unroll
-  for (int s = 0; s < SLOTS; s++) {
-    const uint32_t base = off[s] & OFF_MASK;
-#pragma unroll
-    for (int c = 0; c < 3; c++) xin[s][c] = a.x[base + c];
-  }
-  load_point(q0);
-  for (int i = lane; i < Q * P; i += 64) {
-    const int qq = i / P, pp = i % P;
-    sB[qq * LDP + pp] = tab.interp[i];
-    sG[qq * LDP + pp] = tab.grad[i];
-    sBt[pp * LD + qq] = tab.interp[i];
-  }
-  for (int i = lane; i < Q * Q; i += 64) {
-    const int qq = i / Q, mm = i % Q;
-    sD[qq * LD + mm] = tab.colo[i];
-    sDt[mm * LD + qq] = tab.colo[i];
-  }
+  load_offsets(elem_of(grp), off);
+  load_x(off, xin);
+  load_point(elem_of(grp), q0);
+
+  for (;; ) {
+  CPS_STAMP();
+  const int e = grp * EPW + el;
+  const bool live = e < a.nelem;
+  const int ec = live ? e : a.nelem - 1;
+  const int grp_nx = grp + wper;
+  const bool more = grp_nx < gend;                           // wave-uniform
+  const int ec_nx = elem_of(more ? grp_nx : grp);
+  load_offsets(ec_nx, off_nx);                               // next element's offsets: a whole element ahead
+
   // XA = B0: [c][k][j][i], i fastest (row length LDP)
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
@@ -226,6 +259,7 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   }
   wave_sync();
   CPS_STAMP();  // 2: interpolated
+  load_x(off_nx, xin);                                       // next element's x (its offsets have landed)
 
   // ---- x/y collocated gradient + physics, one point slot at a time -------------------------
   // reads UX = B0, UY = B1; writes GX = B2 (i fastest), GY = B3 (j fastest), GZ = B4 (k fastest)
@@ -256,7 +290,8 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
 #pragma unroll
       for (int c = 0; c < 9; c++) dv[c] = 0.;
     }
-    if (s + 1 < SLOTS) load_point(q + 64);  // next slot's q-point data
+    if (s + 1 < SLOTS) load_point(ec, q + 64);                // next slot's q-point data
+    else load_point(ec_nx, q0);                                // next element's slot 0: a whole back half ahead
     if (q < Q3) {
 #pragma unroll
       for (int c = 0; c < 3; c++) {
@@ -341,21 +376,43 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
       }
     }
   }
-  CPS_STAMP();  // 5: atomics issued
+  CPS_STAMP();  // 5: atomics issued (never waited for: the wave moves on)
 #ifdef CPS_STAMPS
   if (a.stamps && lane == 0) {
-    __builtin_amdgcn_s_waitcnt(0);
-    stamp_[nst_++] = __builtin_amdgcn_s_memtime();  // 6: all memory ops retired
-    for (int i = 0; i < nst_; i++) a.stamps[(size_t)blockIdx.x * 8 + i] = stamp_[i];
+    for (int i = 0; i < nst_; i++) a.stamps[(size_t)grp * 8 + i] = stamp_[i];
   }
+  nst_ = 0;
 #endif
+  if (!more) break;
+  grp = grp_nx;
+#pragma unroll
+  for (int s = 0; s < SLOTS; s++) off[s] = off_nx[s];
+  wave_sync();  // WAR: the next element's gather overwrites B0, which x^T's source B2 does not alias
+  }  // element loop
+}
+
+// waves per CU the persistent grid is sized for: LDS (5 blocks + tables per wave) and VGPRs
+template <int P, int Q> constexpr int fused_waves_per_cu() {
+  using G = WaveGeom<P, Q>;
+  constexpr int lds = (G::EPW * G::SLAB + 2 * Q * G::LDP + P * G::LD + 2 * Q * G::LD) * 8;
+  constexpr int by_lds = (160 * 1024) / lds;
+  return by_lds < 1 ? 1 : (by_lds > 8 ? 8 : by_lds);   // 8 = 2 waves per SIMD at <= 256 VGPRs
 }
 
 template <int P, int Q, int QF>
 hipError_t launch_fused_grad_t(const BasisTables &t, const FusedGradArgs &a, hipStream_t s) {
   using G = WaveGeom<P, Q>;
   if (a.nelem <= 0) return hipSuccess;
-  const int grid = (a.nelem + G::EPW - 1) / G::EPW;
+  const int ngroups = (a.nelem + G::EPW - 1) / G::EPW;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    ncu = prop.multiProcessorCount;
+  }
+  int grid = ncu * fused_waves_per_cu<P, Q>();   // persistent: a multiple of 8 on MI355X (256 CUs)
+  if (grid > ngroups) grid = ngroups;
   hipLaunchKernelGGL((k_fused_grad<P, Q, QF>), dim3(grid), dim3(64), 0, s, t, a);
   return hipGetLastError();
 }

@@ -18,11 +18,12 @@ for _ in range(3): p.apply_jacobian(p.fine, X, Y)
 st = torch.zeros(mesh.nelem * 8, dtype=torch.int64, device="cuda")
 lib.lib.CeedXOperatorSetStampBuffer(op.h, C.c_void_p(st.data_ptr()))
 p.apply_jacobian(p.fine, X, Y); ceed.synchronize(); torch.cuda.synchronize()
-s = st.cpu().numpy().reshape(-1, 8)[:, :7].astype(np.float64)
+s = st.cpu().numpy().reshape(-1, 8)[:, :6].astype(np.float64)
+s = s[s[:, 0] > 0]
 d = np.diff(s, axis=1)
-names = ["gather+tables", "interp (3 passes)", "grad+physics (all slots)", "grad^T", "interp^T+atomics issue", "drain (waitcnt 0)"]
-tot = s[:, 6] - s[:, 0]
+names = ["top: next offsets + gather->LDS", "interp (3 passes)", "grad+physics (all slots)", "grad^T", "interp^T+atomics issue"]
+tot = s[:, 5] - s[:, 0]
 print("waves", len(s), "median lifetime (s_memtime ticks)", np.median(tot))
 for i, nm in enumerate(names):
     print(f"  {nm:28s} median {np.median(d[:, i]):9.0f}  share {100*np.median(d[:, i])/np.median(tot):5.1f} %")
-print("kernel span ticks", s[:, 6].max() - s[:, 0].min())
+print("kernel span ticks", s[:, 5].max() - s[:, 0].min())
