@@ -62,6 +62,10 @@ struct Ceed_private {
   std::string resource;
   hipStream_t stream = nullptr;
   int device = 0;
+  // scratch E-vector shared by the operators of this Ceed (applies are serialised on `stream`)
+  double *evec = nullptr;
+  size_t evec_len = 0;
+  bool atomic_scatter = false;  // CEED_MI355X_SCATTER=atomic: f64 atomics instead of E-vector + assembly
 };
 
 struct CeedVector_private {
@@ -81,6 +85,12 @@ struct CeedElemRestriction_private {
   CeedInt strides[3] = {0, 0, 0};
   std::vector<CeedInt> h_offsets;
   uint32_t *d_offsets = nullptr;  // plain (unflagged)
+  // transpose map for the atomic-free scatter: distinct node offsets (ascending), their contributors
+  // (E-vector positions e*elemsize + n, in element order) -- built on first use
+  bool csr_built = false, csr_full_cover = false;
+  int csr_nnodes = 0;
+  std::vector<uint32_t> h_node_off;
+  uint32_t *d_rowptr = nullptr, *d_cols = nullptr, *d_node_off = nullptr;
 };
 
 struct CeedBasis_private {
@@ -123,6 +133,8 @@ struct CeedOperator_private {
   std::string kernel_name;
   // Dirichlet flags
   uint32_t *d_off_flagged_in = nullptr, *d_off_flagged_out = nullptr;  // same array unless transfer
+  unsigned char *d_node_flags = nullptr;  // per distinct node of the restriction's transpose map
+  std::vector<unsigned char> h_mask;      // copy of the output mask (node flags are derived lazily)
   int mask_mode = 0;
   // optional fine-side scale for transfers
   CeedVector scale = nullptr;
@@ -167,11 +179,13 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   Ceed c = new Ceed_private;
   c->resource = "/gpu/hip/mi355x";
   HIPCHK(hipGetDevice(&c->device));
+  const char *sc = getenv("CEED_MI355X_SCATTER");
+  c->atomic_scatter = sc && !strcmp(sc, "atomic");
   *ceed = c;
   return 0;
 }
 static void ceed_ref(Ceed c) { c->refcount++; }
-static void ceed_unref(Ceed c) { if (--c->refcount == 0) delete c; }
+static void ceed_unref(Ceed c) { if (--c->refcount == 0) { if (c->evec) (void)hipFree(c->evec); delete c; } }
 extern "C" int CeedDestroy(Ceed *ceed) {
   if (!ceed || !*ceed) return 0;
   ceed_unref(*ceed);
@@ -386,6 +400,9 @@ extern "C" int CeedElemRestrictionDestroy(CeedElemRestriction *rstr) {
   if (r == CEED_ELEMRESTRICTION_NONE) return 0;
   if (--r->refcount > 0) return 0;
   if (r->d_offsets) (void)hipFree(r->d_offsets);
+  if (r->d_rowptr) (void)hipFree(r->d_rowptr);
+  if (r->d_cols) (void)hipFree(r->d_cols);
+  if (r->d_node_off) (void)hipFree(r->d_node_off);
   ceed_unref(r->ceed);
   delete r;
   return 0;
@@ -599,6 +616,9 @@ static void op_free_flags(CeedOperator o) {
   if (o->d_off_flagged_out && o->d_off_flagged_out != o->d_off_flagged_in) (void)hipFree(o->d_off_flagged_out);
   if (o->d_off_flagged_in) (void)hipFree(o->d_off_flagged_in);
   o->d_off_flagged_in = o->d_off_flagged_out = nullptr;
+  if (o->d_node_flags) (void)hipFree(o->d_node_flags);
+  o->d_node_flags = nullptr;
+  o->h_mask.clear();
   o->mask_mode = 0;
 }
 extern "C" int CeedOperatorDestroy(CeedOperator *op) {
@@ -621,6 +641,58 @@ extern "C" int CeedOperatorDestroy(CeedOperator *op) {
   for (auto &ev : o->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   ceed_unref(o->ceed);
   delete o;
+  return 0;
+}
+
+// Transpose map of an offsets restriction (setup time, host): counting sort over the L-vector.
+static int rstr_build_csr(CeedElemRestriction r) {
+  if (r->csr_built) return 0;
+  const size_t n = r->h_offsets.size();
+  std::vector<uint32_t> cnt((size_t)r->lsize + 1, 0u);
+  for (size_t i = 0; i < n; i++) cnt[(size_t)r->h_offsets[i]]++;
+  std::vector<uint32_t> slot((size_t)r->lsize, 0xFFFFFFFFu), rowptr;
+  r->h_node_off.clear();
+  rowptr.push_back(0u);
+  for (CeedInt o = 0; o < r->lsize; o++)
+    if (cnt[o]) {
+      slot[o] = (uint32_t)r->h_node_off.size();
+      r->h_node_off.push_back((uint32_t)o);
+      rowptr.push_back(rowptr.back() + cnt[o]);
+    }
+  const int nn = (int)r->h_node_off.size();
+  std::vector<uint32_t> cursor(rowptr.begin(), rowptr.end() - 1), cols(n);
+  const size_t es = (size_t)r->elemsize, nc = (size_t)r->ncomp;
+  for (size_t i = 0; i < n; i++) {  // element order => each node's contributors are sorted by element
+    const size_t e = i / es, ln = i % es;
+    (void)e; (void)ln; (void)nc;
+    cols[cursor[slot[(size_t)r->h_offsets[i]]]++] = (uint32_t)i;  // E position e * elemsize + n
+  }
+  r->csr_nnodes = nn;
+  r->csr_full_cover = (size_t)nn * nc == (size_t)r->lsize;  // every L-vector entry is written by the assembly
+  HIPCHK(hipMalloc((void **)&r->d_rowptr, sizeof(uint32_t) * (nn + 1)));
+  HIPCHK(hipMalloc((void **)&r->d_cols, sizeof(uint32_t) * (n ? n : 1)));
+  HIPCHK(hipMalloc((void **)&r->d_node_off, sizeof(uint32_t) * (nn ? nn : 1)));
+  HIPCHK(hipMemcpy(r->d_rowptr, rowptr.data(), sizeof(uint32_t) * (nn + 1), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(r->d_cols, cols.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(r->d_node_off, r->h_node_off.data(), sizeof(uint32_t) * nn, hipMemcpyHostToDevice));
+  r->csr_built = true;
+  return 0;
+}
+static int ceed_need_evec(Ceed c, size_t len) {
+  if (c->evec_len >= len) return 0;
+  if (c->evec) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->evec)); c->evec = nullptr; c->evec_len = 0; }
+  HIPCHK(hipMalloc((void **)&c->evec, sizeof(double) * len));
+  c->evec_len = len;
+  return 0;
+}
+static int op_need_node_flags(CeedOperator op, CeedElemRestriction r) {
+  if (op->d_node_flags || op->h_mask.empty()) return 0;
+  std::vector<unsigned char> fl((size_t)r->csr_nnodes, 0);
+  for (int i = 0; i < r->csr_nnodes; i++)
+    for (int c = 0; c < r->ncomp && c < 3; c++)
+      if (op->h_mask[(size_t)r->h_node_off[i] + (size_t)c * r->compstride]) fl[i] |= (unsigned char)(1u << c);
+  HIPCHK(hipMalloc((void **)&op->d_node_flags, fl.size() ? fl.size() : 1));
+  HIPCHK(hipMemcpy(op->d_node_flags, fl.data(), fl.size(), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -773,13 +845,25 @@ static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool 
     CHK(read_phys(qf, &a.nu, &a.E));
     lame_constants(a.nu, a.E, &a.lambda, &a.TwoMu);
     a.stamps = op->stamps;
-    if (!add) HIPCHK(hipMemsetAsync(py, 0, sizeof(double) * (size_t)out->length, s));
+    const bool use_evec = !op->ceed->atomic_scatter;
+    if (use_evec) {  // atomic-free, deterministic scatter: element results -> E-vector -> per-node sums
+      CHK(rstr_build_csr(r));
+      CHK(op_need_node_flags(op, r));
+      CHK(ceed_need_evec(op->ceed, (size_t)r->nelem * r->ncomp * r->elemsize));
+      a.evec = op->ceed->evec;
+      if (!add && !r->csr_full_cover) HIPCHK(hipMemsetAsync(py, 0, sizeof(double) * (size_t)out->length, s));
+    } else if (!add) {
+      HIPCHK(hipMemsetAsync(py, 0, sizeof(double) * (size_t)out->length, s));
+    }
     {
       TimerScope ts(op, s);
       hipError_t e = launch_fused_grad(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, a, s, &kname);
       if (e == hipErrorInvalidValue && !*kname)
         return ceed_error("no fused kernel instantiated for P=%d Q=%d QFunction %s", ai.basis->P1d, ai.basis->Q1d, qf->name.c_str());
       HIPCHK(e);
+      if (use_evec)  // timed together with the fused kernel: the two launches ARE the operator apply
+        HIPCHK(launch_assemble(r->d_rowptr, r->d_cols, r->d_node_off, (op->mask_mode & 2) ? op->d_node_flags : nullptr,
+                               a.evec, py, r->csr_nnodes, r->elemsize, add ? 1 : 0, s));
     }
     op->launches++;
     break;
@@ -898,6 +982,7 @@ extern "C" int CeedXOperatorSetDirichletMaskMode(CeedOperator op, CeedMemType mt
   if (op->plan == PLAN_FUSED_GRAD) {
     CHK(make_flagged(op->in[op->i_active].rstr, mask, lsize, &op->d_off_flagged_in));
     op->d_off_flagged_out = op->d_off_flagged_in;
+    op->h_mask.assign(mask, mask + lsize);
   } else if (op->plan == PLAN_PROLONG || op->plan == PLAN_RESTRICT) {
     if (!mask || !mask_out) return ceed_error("transfer operators need the input-side and the output-side mask");
     CHK(make_flagged(op->in[0].rstr, mask, lsize, &op->d_off_flagged_in));

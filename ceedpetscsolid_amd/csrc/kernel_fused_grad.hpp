@@ -140,21 +140,25 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   // All global loads are unconditional and in-bounds (indices clamped, results selected
   // afterwards): no exec-mask branches around loads, so a wave's loads issue back to back.
   auto elem_of = [&](int g) { const int ee = g * EPW + el; return ee < a.nelem ? ee : a.nelem - 1; };
-  double qd[10], st[9];
-  auto load_point = [&](int ec, int q) {
+  // q-point data lives in NSET register sets used round-robin by the point slots; a set is
+  // refilled (for the slot NSET positions further down the element/slot stream) as soon as the
+  // physics of its current slot is done, so every q-point load has a full element of work to hide under.
+  constexpr int NSET = SLOTS >= 2 ? 2 : 1;
+  double qd[NSET][10], st[NSET][9];
+  auto load_point = [&](double *qdv, double *stv, int ec, int q) {
 #ifdef CPS_ABLATE_QDATA  // timing-only build: no q-point stream (WRONG results)
-    for (int c = 0; c < 10; c++) qd[c] = (c == 1 || c == 5 || c == 9 || c == 0) ? 1.0 + 1e-3 * q : 1e-3 * c;
-    for (int c = 0; c < 9; c++) st[c] = 1e-3 * (c + lane);
+    for (int c = 0; c < 10; c++) qdv[c] = (c == 1 || c == 5 || c == 9 || c == 0) ? 1.0 + 1e-3 * q : 1e-3 * c;
+    for (int c = 0; c < 9; c++) stv[c] = 1e-3 * (c + lane);
     return;
 #endif
     const int qc = q < Q3 ? q : Q3 - 1;
     const double *qp = a.qdata + (size_t)ec * 10 * Q3 + qc;
 #pragma unroll
-    for (int c = 0; c < 10; c++) qd[c] = qp[c * Q3];
+    for (int c = 0; c < 10; c++) qdv[c] = qp[c * Q3];
     if constexpr (ST_IN) {
       const double *sp = a.state_in + (size_t)ec * 9 * Q3 + qc;
 #pragma unroll
-      for (int c = 0; c < 9; c++) st[c] = sp[c * Q3];
+      for (int c = 0; c < 9; c++) stv[c] = sp[c * Q3];
     }
   };
   auto load_offsets = [&](int ec, uint32_t *o) {
@@ -173,12 +177,44 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
     }
   };
 
+  // ---- loop-invariant LDS indices of this lane's point slots (hoisted out of the element loop:
+  // v4 spent ~a quarter of its VALU instructions re-deriving them per element) ----------------
+  struct SlotIdx {
+    int g_w;                 // gather: write position in XA
+    int x_r, x_w, x_c;       // x pass: read row, write position, coefficient row
+    int y_r, y_w, y_c;       // y pass
+    int z_r, z_c;            // z pass (writes use rowX+i / rowY+j)
+    int rowX, rowY, rowZ;    // point rows: (k*Q+j)*LD, (k*Q+i)*LD, (j*Q+i)*LD
+    int qi, qj, qk;
+    int zt_r, zt_w, zt_c;    // z^T
+    int yt_r, yt_w, yt_c;    // y^T
+    int xt_r, xt_c;          // x^T
+  } ix[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; s++) {
+    const int q = q0 + 64 * s;
+    SlotIdx &I = ix[s];
+    { const int i = q % P, kj = q / P; I.g_w = kj * LDP + i; I.xt_r = kj * LD; I.xt_c = i * LD; }
+    { const int i = q % Q, kj = q / Q, j = kj % P, k = kj / P;
+      I.x_r = kj * LDP; I.x_w = (k * Q + i) * LDP + j; I.x_c = i * LDP;
+      I.yt_r = (k * Q + i) * LD; I.yt_w = (k * P + j) * LD + i; I.yt_c = j * LD; }
+    { const int i = q % Q, j = (q / Q) % Q, k = q / (Q * Q);
+      I.y_r = (k * Q + i) * LDP; I.y_w = (j * Q + i) * LDP + k; I.y_c = j * LDP;
+      I.z_r = (j * Q + i) * LDP; I.z_c = k * LDP;
+      I.rowX = (k * Q + j) * LD; I.rowY = (k * Q + i) * LD; I.rowZ = (j * Q + i) * LD;
+      I.qi = i; I.qj = j; I.qk = k;
+      I.zt_r = (j * Q + i) * LD; I.zt_w = (k * Q + i) * LD + j; I.zt_c = k * LD; }
+  }
+  constexpr int CPP = P * P * LDP, CPQ = P * Q * LDP, CQQ = Q * Q * LDP;   // component strides, P-padded rows
+  constexpr int DQQ = Q * Q * LD, DPQ = P * Q * LD, DPP = P * P * LD;      // component strides, Q-padded rows
+
   // ---- pipeline prologue: first element's offsets, x and slot-0 q-point data ----------------
   uint32_t off[SLOTS], off_nx[SLOTS];
   double xin[SLOTS][3];
   load_offsets(elem_of(grp), off);
   load_x(off, xin);
-  load_point(elem_of(grp), q0);
+#pragma unroll
+  for (int t = 0; t < NSET; t++) load_point(qd[t], st[t], elem_of(grp), q0 + 64 * t);
 
   for (;; ) {
   CPS_STAMP();
@@ -196,9 +232,8 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
     const int n = q0 + 64 * s;
     if (n < P3) {
       const uint32_t fl = (a.mask_in && live) ? (off[s] >> OFF_FLAG_SHIFT) : (live ? 0u : 7u);
-      const int i = n % P, kj = n / P;
 #pragma unroll
-      for (int c = 0; c < 3; c++) B0[(c * P * P + kj) * LDP + i] = ((fl >> c) & 1u) ? 0. : xin[s][c];
+      for (int c = 0; c < 3; c++) B0[c * CPP + ix[s].g_w] = ((fl >> c) & 1u) ? 0. : xin[s][c];
     }
   }
   wave_sync();
@@ -210,12 +245,10 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   for (int s = 0; s < SLOTS; s++) {
     const int q = q0 + 64 * s;
     if (q < P * P * Q) {
-      const int i = q % Q, kj = q / Q, j = kj % P, k = kj / P;
       double b[P];
-      row_load<P>(sB + i * LDP, b);
+      row_load<P>(sB + ix[s].x_c, b);
 #pragma unroll
-      for (int c = 0; c < 3; c++)
-        B1[((c * P + k) * Q + i) * LDP + j] = row_dot<P>(b, B0 + (c * P * P + kj) * LDP);
+      for (int c = 0; c < 3; c++) B1[c * CPQ + ix[s].x_w] = row_dot<P>(b, B0 + c * CPP + ix[s].x_r);
     }
   }
   wave_sync();
@@ -224,12 +257,10 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   for (int s = 0; s < SLOTS; s++) {
     const int q = q0 + 64 * s;
     if (q < P * Q * Q) {
-      const int i = q % Q, j = (q / Q) % Q, k = q / (Q * Q);
       double b[P];
-      row_load<P>(sB + j * LDP, b);
+      row_load<P>(sB + ix[s].y_c, b);
 #pragma unroll
-      for (int c = 0; c < 3; c++)
-        B2[((c * Q + j) * Q + i) * LDP + k] = row_dot<P>(b, B1 + ((c * P + k) * Q + i) * LDP);
+      for (int c = 0; c < 3; c++) B2[c * CQQ + ix[s].y_w] = row_dot<P>(b, B1 + c * CPQ + ix[s].y_r);
     }
   }
   wave_sync();
@@ -240,20 +271,19 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   for (int s = 0; s < SLOTS; s++) {
     const int q = q0 + 64 * s;
     if (q < Q3) {
-      const int i = q % Q, j = (q / Q) % Q, k = q / (Q * Q);
       double b[P], g[P];
-      row_load<P>(sB + k * LDP, b);
-      row_load<P>(sG + k * LDP, g);
+      row_load<P>(sB + ix[s].z_c, b);
+      row_load<P>(sG + ix[s].z_c, g);
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         double r[P];
-        row_load<P>(B2 + ((c * Q + j) * Q + i) * LDP, r);
+        row_load<P>(B2 + c * CQQ + ix[s].z_r, r);
         double t = 0., tz = 0.;
 #pragma unroll
         for (int m = 0; m < P; m++) { t += b[m] * r[m]; tz += g[m] * r[m]; }
         uz[s][c] = tz;
-        B0[((c * Q + k) * Q + j) * LD + i] = t;
-        B1[((c * Q + k) * Q + i) * LD + j] = t;
+        B0[c * DQQ + ix[s].rowX + ix[s].qi] = t;
+        B1[c * DQQ + ix[s].rowY + ix[s].qj] = t;
       }
     }
   }
@@ -266,21 +296,20 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
     const int q = q0 + 64 * s;
-    const int qi = q % Q, qj = (q / Q) % Q, qk = q / (Q * Q);
     double ug[9], dv[9], sto[9];
     if (q < Q3) {
       double d0[Q], d1[Q];
-      row_load<Q>(sD + qi * LD, d0);
-      row_load<Q>(sD + qj * LD, d1);
+      row_load<Q>(sD + ix[s].qi * LD, d0);
+      row_load<Q>(sD + ix[s].qj * LD, d1);
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        ug[0 * 3 + c] = row_dot<Q>(d0, B0 + ((c * Q + qk) * Q + qj) * LD);
-        ug[1 * 3 + c] = row_dot<Q>(d1, B1 + ((c * Q + qk) * Q + qi) * LD);
+        ug[0 * 3 + c] = row_dot<Q>(d0, B0 + c * DQQ + ix[s].rowX);
+        ug[1 * 3 + c] = row_dot<Q>(d1, B1 + c * DQQ + ix[s].rowY);
         ug[2 * 3 + c] = uz[s][c];
       }
     }
     if (live && q < Q3) {
-      qf_point<QF>(Phys{a.nu, a.E, a.lambda, a.TwoMu}, ug, qd, st, dv, sto);
+      qf_point<QF>(Phys{a.nu, a.E, a.lambda, a.TwoMu}, ug, qd[s % NSET], st[s % NSET], dv, sto);
       if constexpr (ST_OUT) {
         double *sp = a.state_out + (size_t)e * 9 * Q3 + q;
 #pragma unroll
@@ -290,14 +319,14 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
 #pragma unroll
       for (int c = 0; c < 9; c++) dv[c] = 0.;
     }
-    if (s + 1 < SLOTS) load_point(ec, q + 64);                // next slot's q-point data
-    else load_point(ec_nx, q0);                                // next element's slot 0: a whole back half ahead
+    if (s + NSET < SLOTS) load_point(qd[s % NSET], st[s % NSET], ec, q + 64 * NSET);       // same element, NSET slots on
+    else load_point(qd[s % NSET], st[s % NSET], ec_nx, q0 + 64 * (s + NSET - SLOTS));      // next element
     if (q < Q3) {
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        B2[((c * Q + qk) * Q + qj) * LD + qi] = dv[0 * 3 + c];
-        B3[((c * Q + qk) * Q + qi) * LD + qj] = dv[1 * 3 + c];
-        B4[((c * Q + qj) * Q + qi) * LD + qk] = dv[2 * 3 + c];
+        B2[c * DQQ + ix[s].rowX + ix[s].qi] = dv[0 * 3 + c];
+        B3[c * DQQ + ix[s].rowY + ix[s].qj] = dv[1 * 3 + c];
+        B4[c * DQQ + ix[s].rowZ + ix[s].qk] = dv[2 * 3 + c];
       }
     }
   }
@@ -309,17 +338,15 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   for (int s = 0; s < SLOTS; s++) {
     const int q = q0 + 64 * s;
     if (q < Q3) {
-      const int qi = q % Q, qj = (q / Q) % Q, qk = q / (Q * Q);
       double d0[Q], d1[Q], d2[Q];
-      row_load<Q>(sDt + qi * LD, d0);
-      row_load<Q>(sDt + qj * LD, d1);
-      row_load<Q>(sDt + qk * LD, d2);
+      row_load<Q>(sDt + ix[s].qi * LD, d0);
+      row_load<Q>(sDt + ix[s].qj * LD, d1);
+      row_load<Q>(sDt + ix[s].qk * LD, d2);
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const double t = row_dot<Q>(d0, B2 + ((c * Q + qk) * Q + qj) * LD) +
-                         row_dot<Q>(d1, B3 + ((c * Q + qk) * Q + qi) * LD) +
-                         row_dot<Q>(d2, B4 + ((c * Q + qj) * Q + qi) * LD);
-        B0[((c * Q + qj) * Q + qi) * LD + qk] = t;
+        const double t = row_dot<Q>(d0, B2 + c * DQQ + ix[s].rowX) + row_dot<Q>(d1, B3 + c * DQQ + ix[s].rowY) +
+                         row_dot<Q>(d2, B4 + c * DQQ + ix[s].rowZ);
+        B0[c * DQQ + ix[s].rowZ + ix[s].qk] = t;
       }
     }
   }
@@ -332,12 +359,10 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   for (int s = 0; s < SLOTS; s++) {
     const int q = q0 + 64 * s;
     if (q < P * Q * Q) {
-      const int i = q % Q, j = (q / Q) % Q, k = q / (Q * Q);
       double b[Q];
-      row_load<Q>(sBt + k * LD, b);
+      row_load<Q>(sBt + ix[s].zt_c, b);
 #pragma unroll
-      for (int c = 0; c < 3; c++)
-        B1[((c * P + k) * Q + i) * LD + j] = row_dot<Q>(b, B0 + ((c * Q + j) * Q + i) * LD);
+      for (int c = 0; c < 3; c++) B1[c * DPQ + ix[s].zt_w] = row_dot<Q>(b, B0 + c * DQQ + ix[s].zt_r);
     }
   }
   wave_sync();
@@ -346,12 +371,10 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   for (int s = 0; s < SLOTS; s++) {
     const int q = q0 + 64 * s;
     if (q < P * P * Q) {
-      const int i = q % Q, j = (q / Q) % P, k = q / (Q * P);
       double b[Q];
-      row_load<Q>(sBt + j * LD, b);
+      row_load<Q>(sBt + ix[s].yt_c, b);
 #pragma unroll
-      for (int c = 0; c < 3; c++)
-        B2[((c * P + k) * P + j) * LD + i] = row_dot<Q>(b, B1 + ((c * P + k) * Q + i) * LD);
+      for (int c = 0; c < 3; c++) B2[c * DPP + ix[s].yt_w] = row_dot<Q>(b, B1 + c * DPQ + ix[s].yt_r);
     }
   }
   wave_sync();
@@ -360,14 +383,19 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   for (int s = 0; s < SLOTS; s++) {
     const int n = q0 + 64 * s;
     if (live && n < P3) {
-      const int i = n % P, kj = n / P;
       double b[Q];
-      row_load<Q>(sBt + i * LD, b);
+      row_load<Q>(sBt + ix[s].xt_c, b);
       const uint32_t base = off[s] & OFF_MASK;
       const uint32_t fl = a.mask_out ? (off[s] >> OFF_FLAG_SHIFT) : 0u;
+      if (a.evec) {  // wave-uniform: element results as plain coalesced stores, summed by launch_assemble()
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+          a.evec[((size_t)e * P3 + n) * 3 + c] = row_dot<Q>(b, B2 + c * DPP + ix[s].xt_r);
+        continue;
+      }
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const double t = row_dot<Q>(b, B2 + (c * P * P + kj) * LD);
+        const double t = row_dot<Q>(b, B2 + c * DPP + ix[s].xt_r);
 #if defined(CPS_ABLATE_ATOMICS)   // timing-only build: plain store instead of the atomic (WRONG results)
         if (!((fl >> c) & 1u)) a.y[base + c] = t;
 #else

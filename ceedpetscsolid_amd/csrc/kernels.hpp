@@ -46,6 +46,8 @@ struct FusedGradArgs {
   int mask_in, mask_out;    // honour the Dirichlet flags on gather / scatter
   double nu, E, lambda, TwoMu;
   unsigned long long *stamps;  // diagnostic builds only (-DCPS_STAMPS): 8 s_memtime stamps per wave
+  double *evec;                // if set: element results go here ([elem][P^3][3], plain coalesced stores)
+                               // and launch_assemble() sums them into y; else f64 atomics straight into y
 };
 
 struct TransferArgs {
@@ -84,6 +86,12 @@ hipError_t launch_setup_geo(int Q, const BasisTables &t, const SetupGeoArgs &a, 
                             const char **name);
 hipError_t launch_diag(int P, int Q, int qf, const BasisTables &t, const DiagArgs &a, hipStream_t s,
                        const char **name);
+
+// Deterministic, atomic-free E^T: y[node_off[r] + c] (+)= sum over the node's contributors, in element
+// order, of E[3 * cols[k] + c] (cols[k] = e * P3 + n).  `flags` (one byte per node, bit c = component c constrained) may be null.
+hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off,
+                           const unsigned char *flags, const double *evec, double *y, int nnodes, int P3,
+                           int add, hipStream_t s);
 
 // Vector / restriction utilities.
 hipError_t launch_set_value(double *v, size_t n, double val, hipStream_t s);

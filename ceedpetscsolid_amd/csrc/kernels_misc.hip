@@ -290,6 +290,27 @@ __global__ void k_rstr(const uint32_t *off, size_t total, int elemsize, int ncom
     else atomic_add_f64(dst + li, 1.0);
   }
 }
+// One lane per L-node.  The E-vector is interlaced [elem][node][3] like the L-vector: a contributor is
+// 24 contiguous bytes, consecutive lanes (consecutively numbered nodes of one element) read and write
+// consecutive 24-byte rows, so the three strided 8-byte accesses of a wave cover whole cache lines.
+__global__ void k_assemble(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off,
+                           const unsigned char *flags, const double *evec, double *y, int nnodes, int add) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nnodes; r += gridDim.x * blockDim.x) {
+    const uint32_t k0 = rowptr[r], k1 = rowptr[r + 1];
+    double a0 = 0., a1 = 0., a2 = 0.;
+    for (uint32_t k = k0; k < k1; k++) {
+      const double *p = evec + (size_t)cols[k] * 3;
+      a0 += p[0]; a1 += p[1]; a2 += p[2];
+    }
+    const unsigned fl = flags ? flags[r] : 0u;
+    double *dst = y + (node_off[r] & OFF_MASK);
+    if (fl & 1u) a0 = 0.;
+    if (fl & 2u) a1 = 0.;
+    if (fl & 4u) a2 = 0.;
+    if (add) { a0 += dst[0]; a1 += dst[1]; a2 += dst[2]; }
+    dst[0] = a0; dst[1] = a1; dst[2] = a2;
+  }
+}
 __global__ void k_dot(const double *x, const double *y, const double *w, size_t n, double *result) {
   double s = 0.;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -344,6 +365,14 @@ hipError_t launch_rstr_scatter_add(const uint32_t *off, int nelem, int elemsize,
 hipError_t launch_multiplicity(const uint32_t *off, int nelem, int elemsize, int ncomp, int compstride,
                                double *l, hipStream_t s) {
   return rstr(off, nelem, elemsize, ncomp, compstride, nullptr, l, 2, s);
+}
+hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off,
+                           const unsigned char *flags, const double *evec, double *y, int nnodes, int P3,
+                           int add, hipStream_t s) {
+  if (nnodes <= 0) return hipSuccess;
+  (void)P3;
+  hipLaunchKernelGGL(k_assemble, dim3((unsigned)((nnodes + 255) / 256)), dim3(256), 0, s, rowptr, cols, node_off, flags, evec, y, nnodes, add);
+  return hipGetLastError();
 }
 hipError_t launch_dot(const double *x, const double *y, const double *w, size_t n, double *result_dev, hipStream_t s) {
   if (!n) return hipSuccess;
