@@ -50,6 +50,32 @@ def algorithmic_bytes(nelem: int, P: int, Q: int, lsize: int, state: bool) -> in
     return nelem * (8 * (19 if state else 10) * Q ** 3 + 4 * P ** 3) + 16 * lsize
 
 
+def host_cores() -> int:
+    """Host threads this process may really use: affinity, capped by the cgroup CPU quota and by the
+    GPU box's per-GPU share (16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("BENCH_CPU_THREADS", "16"))))
+
+
+def traffic_from_profile(kernel_name: str, nelem: int):
+    """HBM bytes per operator apply from the committed PMC reduction (tools/collect_traffic.py ->
+    profiles/r01_traffic.json), if it was taken on this workload; else None."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        d = json.load(open(path))
+        if d.get("elements_per_gpu") == nelem and d.get("kernel") == kernel_name:
+            return d.get("hbm_bytes_per_apply")
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(args, nr, nth):
     """The oracle (CPU restatement of the reference's /cpu/self path) on a bounded sample of the
     same workload: a thin z-slab of the same cylinder, same degree / model / state."""
@@ -59,7 +85,7 @@ def cpu_baseline(args, nr, nth):
     if not os.path.exists(path):
         return None
     lib = cd.CeedLib(path)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     lib.lib.OracleSetNumThreads(C.c_int(cores))
     orc = cd.Ceed(lib, "/cpu/self/oracle")
     nz = args.cpu_sample_layers
@@ -126,7 +152,7 @@ def main():
     n_global = halo.global_count(free)
 
     # state u (stores gradu through the residual), then the Jacobian input x
-    xt = torch.from_numpy(prob.smooth_state(0.1)).to(dev)
+    xt = torch.from_numpy(prob.smooth_state(0.1, origin=(-1.0, -1.0, 0.0), span=(2.0, 2.0, 10.0))).to(dev)
     yt = torch.zeros(n, dtype=torch.float64, device=dev)
     X, Y = lv.xceed, lv.yceed
     X.set_device_pointer(xt.data_ptr()); Y.set_device_pointer(yt.data_ptr())
@@ -182,10 +208,11 @@ def main():
                        "halo_dofs_rank0": halo.n_shared_dofs, "kernel": op.kernel_name,
                        "partition": "z-slabs, one per GPU" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(op.kernel_name, mesh.nelem),
                          "algorithmic_bytes_per_launch": abytes, "kernel_avg_us": avg_s * 1e6,
                          "kernel_launches_timed": launches,
-                         "note": "fused operator kernel only (hipEvents on its stream); per-step also has a memset of y"},
+                         "kernels": "k_fused_grad (gather..physics..E-vector) + k_assemble (deterministic per-node sum): the two launches of one CeedOperatorApply, timed together with hipEvents on their stream",
+                         "peak_measured_copy_GBs": 6290.0},
         }
         if not args.no_cpu_baseline and world == 1:
             try:

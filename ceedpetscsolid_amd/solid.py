@@ -244,12 +244,15 @@ class SolidProblem:
         self.levels[level].opJacob.assemble_diagonal(d)
 
     # --------------------------------------------------------------- helpers
-    def smooth_state(self, amplitude: float = 0.1) -> np.ndarray:
+    def smooth_state(self, amplitude: float = 0.1, origin=None, span=None) -> np.ndarray:
         """A smooth displacement field with |grad u| ~ amplitude on the fine level (SURVEY 8d,
-        config 4: "clamp-translate profile + MMS-shaped perturbation"); host array, L layout."""
+        config 4: "clamp-translate profile + MMS-shaped perturbation"); host array, L layout.
+        With ``origin`` / ``span`` given it is a function of the absolute coordinates only, i.e.
+        identical on every rank that shares a node."""
         X = self.levels[self.fine].dofmap.node_coords
-        span = np.maximum(X.max(axis=0) - X.min(axis=0), 1e-12)
-        s = (X - X.min(axis=0)) / span
+        origin = X.min(axis=0) if origin is None else np.asarray(origin, dtype=np.float64)
+        span = np.maximum(X.max(axis=0) - X.min(axis=0), 1e-12) if span is None else np.asarray(span, dtype=np.float64)
+        s = (X - origin) / span
         k = 2.0 * np.pi
         u = np.empty_like(X)
         u[:, 0] = amplitude * span[0] / k * np.sin(k * s[:, 1]) * np.cos(k * s[:, 2]) + 0.02 * amplitude * span[0] * s[:, 2]

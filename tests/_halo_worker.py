@@ -1,0 +1,51 @@
+"""Worker for the world_size-2 gloo test: element-partitioned Jacobian apply with the halo sum."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def coord_field(X, mask):
+    k = np.array([[12.9898, 78.233, 37.719], [93.989, 67.345, 24.113], [45.164, 11.135, 83.951]])
+    v = np.sin(X @ k.T) * 437.5453
+    return ((2.0 * (v - np.floor(v)) - 1.0).reshape(-1) * (mask == 0))
+
+
+def run(rank, world, initfile, outdir, mode):
+    from ceedpetscsolid_amd import ceed as cd
+    from ceedpetscsolid_amd.halo import HaloExchange, slab_cylinder
+    from ceedpetscsolid_amd.mesh import hollow_cylinder_mesh, partition_slabs, submesh
+    from ceedpetscsolid_amd.solid import SolidProblem
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    lib = cd.CeedLib(os.path.join(ROOT, "oracle", "liboracle_ceed.so"))   # tests only: the oracle as local operator
+    ceed = cd.Ceed(lib, "/cpu/self/oracle")
+    if mode == "slab":        # the weak-scaling generator of bench.py
+        mesh = slab_cylinder(rank, world, 2, 6, 2, height_per_rank=2.0)
+    else:                     # generic partition of one global mesh
+        full = hollow_cylinder_mesh(2, 6, 2 * world, z0=-world, z1=world)
+        mesh = submesh(full, partition_slabs(full, world)[rank])
+    bc = [s for s in (998, 999) if s in mesh.side_sets and len(mesh.side_sets[s])]
+    p = SolidProblem(ceed, mesh, 3, "hyperFS", nu=0.3, E=1.0, bc_sides=bc, multigrid="none")
+    lv = p.levels[p.fine]
+    n = p.lsize()
+    halo = HaloExchange(mesh, lv.dofmap, device="cpu")
+    X, Y = ceed.vector(n), ceed.vector(n)
+    # state: a smooth function of the GLOBAL coordinates so both ranks agree on shared nodes
+    xyz = lv.dofmap.node_coords
+    u = 0.05 * np.stack([np.sin(xyz[:, 1]) * xyz[:, 2], np.cos(xyz[:, 0]) * 0.5 * xyz[:, 2], np.sin(xyz[:, 0] + xyz[:, 1])], axis=1).reshape(-1)
+    X.set_array(u); p.form_residual(X, Y)
+    x = coord_field(xyz, lv.mask)
+    X.set_array(x); p.apply_jacobian(p.fine, X, Y)
+    y = torch.from_numpy(Y.to_numpy().copy())
+    halo.add(y)
+    nglob = halo.global_count((lv.mask == 0).astype(np.float64))
+    w = torch.from_numpy(halo.owner_weight.copy())
+    dot = halo.dot(torch.from_numpy(x), y, w)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), y=y.numpy(), keys=lv.dofmap.node_keys, nglob=nglob, dot=dot,
+             nshared=halo.n_shared_dofs, mask=lv.mask, x=x)
+    dist.destroy_process_group()

@@ -1,0 +1,92 @@
+"""Mesh -> element restriction pipeline (the step in front of the operator path): topology counts of
+the reference's meshes, tensor closure order, Dirichlet node sets, partitions."""
+import os
+
+import numpy as np
+import pytest
+
+from ceedpetscsolid_amd.mesh import (box_mesh, boundary_nodes, build_dofmap, dirichlet_mask, gll_nodes,
+                                     hollow_cylinder_mesh, key_bytes, load_mesh_npz, partition_slabs,
+                                     side_set_nodes, submesh)
+from conftest import GOLDEN
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 6])
+def test_box_node_counts_and_closure_order(p):
+    nx, ny, nz = 3, 2, 4
+    m = box_mesh(nx, ny, nz)
+    dm = build_dofmap(m, p)
+    assert dm.nnodes == (nx * p + 1) * (ny * p + 1) * (nz * p + 1)
+    assert dm.elem_nodes.shape == (m.nelem, (p + 1) ** 3)
+    assert dm.elem_nodes.min() == 0 and dm.elem_nodes.max() == dm.nnodes - 1
+    assert len(np.unique(dm.elem_nodes[0])) == (p + 1) ** 3
+    # tensor (x fastest) closure order with GLL spacing: node coordinates of element 0
+    g = 0.5 * (gll_nodes(p + 1) + 1.0)
+    X = dm.node_coords[dm.elem_nodes[0]].reshape(p + 1, p + 1, p + 1, 3)   # [c][b][a]
+    assert np.allclose(X[0, 0, :, 0], g / nx) and np.allclose(X[0, :, 0, 1], g / ny) and np.allclose(X[:, 0, 0, 2], g / nz)
+    # shared nodes agree geometrically from every element that touches them
+    P = p + 1
+    xi = 0.5 * (gll_nodes(P) + 1.0)
+    for e in (1, m.nelem - 1):
+        v = m.coords[m.cells[e]]
+        lo, hi = v.min(axis=0), v.max(axis=0)
+        Z, Y, Xg = np.meshgrid(xi, xi, xi, indexing="ij")
+        ref = np.stack([lo[0] + Xg * (hi[0] - lo[0]), lo[1] + Y * (hi[1] - lo[1]), lo[2] + Z * (hi[2] - lo[2])], axis=-1)
+        assert np.allclose(dm.node_coords[dm.elem_nodes[e]].reshape(P, P, P, 3), ref, atol=1e-13)
+
+
+@pytest.mark.parametrize("name,p,nodes", [("cube8_4096e_6ss_s", 3, 117649), ("cylinder8_5580e_4ss_us", 4, 386564),
+                                          ("cylinder8_5580e_4ss_us", 2, 52030), ("cylinder8_5580e_4ss_us", 1, 7442)])
+def test_reference_mesh_node_counts(name, p, nodes):
+    """L dofs per level = 3 * nodes (cfg 2: 352 947; cfg 3: 1 159 692 / 156 090 / 22 326)."""
+    m = load_mesh_npz(os.path.join(GOLDEN, f"mesh_{name}.npz"))
+    dm = build_dofmap(m, p)
+    assert dm.nnodes == nodes
+    # every element is right-handed
+    X = m.coords[m.cells]
+    J = np.stack([X[:, 1] - X[:, 0], X[:, 2] - X[:, 0], X[:, 4] - X[:, 0]], axis=1)
+    assert (np.linalg.det(J) > 0).all()
+
+
+def test_cylinder_side_sets_match_geometry():
+    m = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_5580e_4ss_us.npz"))
+    dm = build_dofmap(m, 2)
+    r = lambda nd: np.hypot(dm.node_coords[nd, 0], dm.node_coords[nd, 1])
+    assert np.allclose(dm.node_coords[side_set_nodes(m, dm, [998]), 2], -5.0)
+    assert np.allclose(dm.node_coords[side_set_nodes(m, dm, [999]), 2], 5.0)
+    assert r(side_set_nodes(m, dm, [996])).max() < 0.5 + 1e-9 and r(side_set_nodes(m, dm, [997])).min() > 0.99
+
+
+def test_synthetic_cylinder_matches_reference_family():
+    m = hollow_cylinder_mesh(10, 110, 90)
+    assert m.nelem == 99000 and set(m.side_sets) == {996, 997, 998, 999}
+    rr = np.hypot(m.coords[:, 0], m.coords[:, 1])
+    assert abs(rr.min() - 0.5) < 1e-12 and abs(rr.max() - 1.0) < 1e-12
+    assert m.coords[:, 2].min() == -5.0 and m.coords[:, 2].max() == 5.0
+    small = hollow_cylinder_mesh(2, 8, 2)
+    dm = build_dofmap(small, 3)
+    assert dm.nnodes == (2 * 3 + 1) * (8 * 3) * (2 * 3 + 1)   # periodic in theta
+
+
+def test_boundary_nodes_and_masks():
+    m = box_mesh(3, 3, 3)
+    dm = build_dofmap(m, 2)
+    b = boundary_nodes(m, dm)
+    assert b.size == 7 ** 3 - 5 ** 3
+    mask = dirichlet_mask(dm, side_set_nodes(m, dm, [1]))
+    assert mask.sum() == 3 * 49 and mask.size == dm.lsize
+    z0 = np.nonzero(mask.reshape(-1, 3)[:, 0])[0]
+    assert np.allclose(dm.node_coords[z0, 2], 0.0)
+
+
+def test_partition_keys_identify_shared_nodes():
+    m = hollow_cylinder_mesh(2, 6, 4)
+    parts = partition_slabs(m, 2)
+    assert sum(len(p) for p in parts) == m.nelem
+    subs = [submesh(m, p) for p in parts]
+    dms = [build_dofmap(s, 3) for s in subs]
+    k = [key_bytes(d.node_keys[boundary_nodes(s, d)]) for s, d in zip(subs, dms)]
+    shared = np.intersect1d(k[0], k[1])
+    assert shared.size == (2 * 3 + 1) * (6 * 3)     # one z-layer of nodes
+    full = build_dofmap(m, 3)
+    assert dms[0].nnodes + dms[1].nnodes - shared.size == full.nnodes

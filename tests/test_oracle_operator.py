@@ -1,0 +1,155 @@
+"""Operator-level properties of the oracle through the harness (SURVEY 4's known-answer list):
+volume, FD-consistency of the tangent, symmetry, rigid-body null space, adjointness of the
+p-multigrid transfer, diagonal, overwrite semantics, the sizeof(pointer) context quirk,
+and the MMS check of BASELINE config 1."""
+import numpy as np
+import pytest
+
+from ceedpetscsolid_amd import ceed as cd
+from ceedpetscsolid_amd.mesh import box_mesh, hollow_cylinder_mesh
+from ceedpetscsolid_amd.solid import SolidProblem, level_degrees
+from conftest import rel_err
+
+
+def distorted(nx, ny, nz, seed=0):
+    m = box_mesh(nx, ny, nz)
+    m.coords += 0.03 * np.random.default_rng(seed).uniform(-1, 1, m.coords.shape)
+    return m
+
+
+def test_level_degrees():
+    assert level_degrees(4) == [1, 2, 4] and level_degrees(6) == [1, 2, 4, 6] and level_degrees(3) == [1, 2, 3]
+    assert level_degrees(3, "uniform") == [1, 2, 3] and level_degrees(5, "none") == [5] and level_degrees(2) == [1, 2]
+
+
+def test_volume_from_qdata(oracle):
+    p = SolidProblem(oracle, box_mesh(3, 2, 2), 2, "linElas")
+    qd = p.qdata.to_numpy().reshape(12, 10, -1)
+    assert abs(qd[:, 0, :].sum() - 1.0) < 1e-13
+    c = SolidProblem(oracle, hollow_cylinder_mesh(3, 48, 2), 3, "linElas", multigrid="none")
+    vol = c.qdata.to_numpy().reshape(c.mesh.nelem, 10, -1)[:, 0, :].sum()
+    facet = 48 / 2 * np.sin(2 * np.pi / 48)            # area of the inscribed 48-gon / r^2
+    assert abs(vol - facet * (1.0 - 0.25) * 10) < 1e-10
+
+
+@pytest.mark.parametrize("problem,fdtol", [("linElas", 1e-9), ("hyperSS", 1e-7), ("hyperFS", 1e-7)])
+def test_tangent_is_consistent_symmetric_and_has_rigid_null_space(oracle, problem, fdtol):
+    mesh = distorted(3, 2, 2)
+    p = SolidProblem(oracle, mesh, 3, problem, nu=0.3, E=2.0, bc_sides=[1])
+    n, c = p.lsize(), oracle
+    rng = np.random.default_rng(1)
+    free = p.levels[p.fine].mask == 0
+    u = p.smooth_state(0.1)
+    X, Y = c.vector(n), c.vector(n)
+    res = lambda z: (X.set_array(z), p.form_residual(X, Y), Y.to_numpy())[2]
+    dx, w = rng.uniform(-1, 1, n) * free, rng.uniform(-1, 1, n) * free
+    eps = 1e-6
+    fd = (res(u + eps * dx) - res(u - eps * dx)) / (2 * eps)
+    res(u)                                                 # restore the stored state at u
+    J = lambda z: (X.set_array(z), p.apply_jacobian(p.fine, X, Y), Y.to_numpy())[2]
+    jx, jw = J(dx), J(w)
+    assert rel_err(fd, jx) < fdtol
+    assert np.all(jx[~free] == 0.0)
+    assert abs(dx @ jw - w @ jx) < 1e-12 * abs(dx @ jw)
+    q = SolidProblem(oracle, mesh, 3, problem, nu=0.3, E=2.0)           # no BCs
+    X.set_array(np.tile([0.3, -0.2, 0.1], n // 3)); q.form_residual(X, Y)
+    assert np.abs(Y.to_numpy()).max() < 1e-13
+    if problem == "hyperFS":   # finite strain: rigid rotations are stress free too
+        th = 0.3
+        R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+        xyz = q.levels[q.fine].dofmap.node_coords
+        X.set_array((xyz @ R.T - xyz).reshape(-1)); q.form_residual(X, Y)
+        assert np.abs(Y.to_numpy()).max() < 1e-12
+
+
+def test_transfer_is_adjoint_and_reproduces_coarse_polynomials(oracle):
+    p = SolidProblem(oracle, distorted(2, 2, 2), 4, "linElas")             # levels 1, 2, 4; no BCs
+    c, rng = oracle, np.random.default_rng(3)
+    for lv in (1, 2):
+        nc, nf = p.lsize(lv - 1), p.lsize(lv)
+        xc, xf = rng.uniform(-1, 1, nc), rng.uniform(-1, 1, nf)
+        Xc, Yf, Xf, Yc = c.vector(nc).set_array(xc), c.vector(nf), c.vector(nf).set_array(xf), c.vector(nc)
+        p.prolong(lv, Xc, Yf); p.restrict(lv, Xf, Yc)
+        assert abs(Yf.to_numpy() @ xf - Yc.to_numpy() @ xc) < 1e-13 * abs(Yf.to_numpy() @ xf)
+    # a trilinear field on the (undistorted) coarse level prolongs exactly
+    q = SolidProblem(oracle, box_mesh(2, 2, 2), 4, "linElas")
+    f = lambda X: np.stack([1 + X[:, 0] * X[:, 1], 2 * X[:, 2] - X[:, 0], X[:, 0] * X[:, 1] * X[:, 2]], axis=1).reshape(-1)
+    Xc = c.vector(q.lsize(0)).set_array(f(q.levels[0].dofmap.node_coords))
+    Y1, Y2 = c.vector(q.lsize(1)), c.vector(q.lsize(2))
+    q.prolong(1, Xc, Y1); q.prolong(2, Y1, Y2)
+    assert np.abs(Y2.to_numpy() - f(q.levels[2].dofmap.node_coords)).max() < 1e-13
+
+
+def test_diagonal_matches_unit_vector_applies_and_overwrites(oracle):
+    p = SolidProblem(oracle, distorted(2, 2, 1), 2, "hyperFS", nu=0.3, E=1.5, bc_sides=[1])
+    n, c = p.lsize(), oracle
+    X, Y, D = c.vector(n).set_array(p.smooth_state(0.1)), c.vector(n), c.vector(n)
+    p.form_residual(X, Y)
+    D.set_value(123.0)
+    for lv in range(len(p.levels)):
+        nl = p.lsize(lv)
+        Dl, Xl, Yl = c.vector(nl).set_value(5.0), c.vector(nl), c.vector(nl)
+        p.get_diag(lv, Dl)
+        d = Dl.to_numpy()
+        free = np.nonzero(p.levels[lv].mask == 0)[0]
+        for i in free[:: max(1, free.size // 12)]:
+            e = np.zeros(nl); e[i] = 1.0
+            Xl.set_array(e); p.apply_jacobian(lv, Xl, Yl)
+            assert abs(Yl.to_numpy()[i] - d[i]) < 1e-12 * abs(d[i])
+        assert np.all(d[p.levels[lv].mask != 0] == 0.0)
+
+
+def test_operator_apply_overwrites_and_context_is_borrowed(oracle):
+    """CeedOperatorApply overwrites; CeedQFunctionSetContext keeps the pointer and the
+    reported size is not trusted (setuplibceed.c:826 passes sizeof(pointer))."""
+    p = SolidProblem(oracle, box_mesh(2, 1, 1), 2, "linElas", nu=0.3, E=1.0)
+    n, c = p.lsize(), oracle
+    x = np.random.default_rng(0).uniform(-1, 1, n)
+    X, Y = c.vector(n).set_array(x), c.vector(n).set_value(99.0)
+    p.apply_jacobian(p.fine, X, Y)
+    y1 = Y.to_numpy()
+    p.apply_jacobian(p.fine, X, Y)
+    assert np.array_equal(Y.to_numpy(), y1)
+    p.levels[p.fine].qfJacob._ctx[1] = 2.0                 # E doubles through the borrowed pointer
+    p.apply_jacobian(p.fine, X, Y)
+    assert rel_err(Y.to_numpy(), 2.0 * y1) < 1e-14
+
+
+def test_config1_mms_linear_elasticity(oracle):
+    """BASELINE config 1: linElas, box 4x4x4, degree 2, MMS forcing, BCMMS on the whole boundary.
+    Solve K u = f with CG on the oracle operator; the reference's gate is a relative L2 error
+    <= 0.05 (elasticity.c:807); expect far below."""
+    mesh = box_mesh(4, 4, 4)
+    nu, E = 0.3, 1e6
+    p = SolidProblem(oracle, mesh, 2, "linElas", nu=nu, E=E, bc_all_boundary=True, multigrid="none")
+    c, lv = oracle, p.levels[0]
+    n, P, Q = p.lsize(), 3, 3
+    assert mesh.nelem == 64 and lv.dofmap.nnodes == 729 and n == 2187
+    # forcing operator (setuplibceed.c:555-583)
+    qf = c.qfunction("SetupMMSForce", source="qfunctions/manufacturedForce.h:SetupMMSForce")
+    qf.add_input("x", 3, cd.EVAL_INTERP).add_input("qdata", 10, cd.EVAL_NONE).add_output("force", 3, cd.EVAL_INTERP)
+    qf.set_context(p.phys)
+    op = c.operator(qf)
+    op.set_field("x", p.Erestrictx, p.basisx, "active")
+    op.set_field("qdata", p.Erestrictqdi, None, p.qdata)
+    op.set_field("force", lv.Erestrictu, lv.basisu, "active")
+    F = c.vector(n); op.apply(p.xcoord, F)
+    f = F.to_numpy()
+    X = lv.dofmap.node_coords
+    ut = np.stack([np.exp(2 * X[:, 0]) * np.sin(3 * X[:, 1]) * np.cos(4 * X[:, 2]),
+                   np.exp(3 * X[:, 1]) * np.sin(4 * X[:, 2]) * np.cos(2 * X[:, 0]),
+                   np.exp(4 * X[:, 2]) * np.sin(2 * X[:, 0]) * np.cos(3 * X[:, 1])], axis=1).reshape(-1) / 1e8
+    free = lv.mask == 0
+    ubc = np.where(free, 0.0, ut)                      # BCMMS values on the boundary (boundary.c:31-50)
+    Xv, Yv = c.vector(n), c.vector(n)
+    Xv.set_array(ubc); p.form_residual(Xv, Yv)         # K [0; u_bc], constrained rows dropped
+    rhs = (f - Yv.to_numpy()) * free
+    A = lambda z: (Xv.set_array(z * free), p.apply_jacobian(0, Xv, Yv), Yv.to_numpy())[2]
+    u = np.zeros(n); r = rhs.copy(); d = r.copy(); rr = r @ r
+    for it in range(2000):
+        Ad = A(d); alpha = rr / (d @ Ad); u += alpha * d; r -= alpha * Ad
+        rn = r @ r
+        if rn < 1e-26 * (rhs @ rhs): break
+        d = r + rn / rr * d; rr = rn
+    err = np.linalg.norm((u + ubc) - ut) / np.linalg.norm(ut)
+    assert err < 0.05 and err < 5e-3, err
