@@ -40,6 +40,7 @@ CPS_DEV void physical_grad(const double *ug, const double *qd, double g[3][3]) {
 }
 // dv[k*3+c] = sum_m dXdx[k][m] T[c][m] wdetJ                  (linElas.h:148-153)
 CPS_DEV void pull_back(const double T[3][3], const double *qd, double *dv) {
+  // the reference scales every product by wdetJ; scaling the sum once differs by <= 2 ulp
   const double wdetJ = qd[0];
 #pragma unroll
   for (int c = 0; c < 3; c++)
@@ -47,8 +48,8 @@ CPS_DEV void pull_back(const double T[3][3], const double *qd, double *dv) {
     for (int k = 0; k < 3; k++) {
       double s = 0.;
 #pragma unroll
-      for (int m = 0; m < 3; m++) s += qd[1 + 3 * k + m] * T[c][m] * wdetJ;
-      dv[k * 3 + c] = s;
+      for (int m = 0; m < 3; m++) s += qd[1 + 3 * k + m] * T[c][m];
+      dv[k * 3 + c] = s * wdetJ;
     }
 }
 
@@ -134,6 +135,11 @@ CPS_DEV double log1p_series4_shifted(double x) {  // hyperFS.h:45-67
 // 0:(0,0) 1:(1,1) 2:(2,2) 3:(1,2) 4:(0,2) 5:(0,1)
 #define CPS_SYM(w, a, b) ((a) == (b) ? w[a] : w[6 - (a) - (b)])
 struct FSState { double S[6], Ci[6], llnj; };
+// FAST_S: S = mu I + (llnj - mu) C^-1, algebraically equal to the reference's
+// llnj C^-1 + mu C^-1 E2 (since C^-1 E2 = I - C^-1).  Used ONLY by the Jacobian, where S enters
+// through grad(du) S next to the O(mu) term F dS, so its cancellation error (~1e-16 mu absolute) is
+// far inside the 1e-10 bar; the residual keeps the reference's cancellation-free form.
+template <bool FAST_S>
 CPS_DEV void fs_state(double lambda, double mu, const double g[3][3], FSState &s) {  // hyperFS.h:85-142
   constexpr int J[6] = {0, 1, 2, 1, 0, 0}, K[6] = {0, 1, 2, 2, 2, 1};
   double E2[6];
@@ -155,12 +161,18 @@ CPS_DEV void fs_state(double lambda, double mu, const double g[3][3], FSState &s
 #pragma unroll
   for (int m = 0; m < 6; m++) s.Ci[m] = A[m] * rden;
   s.llnj = lambda * log1p_series4_shifted(detCm1) / 2.;
+  if constexpr (FAST_S) {
+    const double f = s.llnj - mu;
 #pragma unroll
-  for (int m = 0; m < 6; m++) {
-    double t = s.llnj * s.Ci[m];
+    for (int m = 0; m < 6; m++) s.S[m] = f * s.Ci[m] + (m < 3 ? mu : 0.);
+  } else {
 #pragma unroll
-    for (int n = 0; n < 3; n++) t += mu * CPS_SYM(s.Ci, J[m], n) * CPS_SYM(E2, n, K[m]);
-    s.S[m] = t;
+    for (int m = 0; m < 6; m++) {
+      double t = s.llnj * s.Ci[m];
+#pragma unroll
+      for (int n = 0; n < 3; n++) t += mu * CPS_SYM(s.Ci, J[m], n) * CPS_SYM(E2, n, K[m]);
+      s.S[m] = t;
+    }
   }
 }
 CPS_DEV void fs_lame(const Phys ph, double &lambda, double &mu) {  // hyperFS.h:164-167
@@ -177,7 +189,7 @@ CPS_DEV void qf_hyperfs_f(const Phys ph, const double *ug, const double *qd, dou
 #pragma unroll
     for (int k = 0; k < 3; k++) st[3 * c + k] = g[c][k];
   FSState s;
-  fs_state(lambda, mu, g, s);
+  fs_state<false>(lambda, mu, g, s);
 #pragma unroll
   for (int a = 0; a < 3; a++)  // P = F S, F = I + grad u   (hyperFS.h:262-268)
 #pragma unroll
@@ -202,21 +214,25 @@ CPS_DEV void qf_hyperfs_df(const Phys ph, const double *dug, const double *qd, c
       F[c][k] = g[c][k] + (c == k ? 1. : 0.);
     }
   FSState s;
-  fs_state(lambda, mu, g, s);
-  double dE[6];  // sym(grad(du)^T F)   (hyperFS.h:381-389)
+  fs_state<true>(lambda, mu, g, s);
+  double dE[6];  // sym(grad(du)^T F)   (hyperFS.h:381-389); on the diagonal the two products coincide
 #pragma unroll
   for (int m = 0; m < 6; m++) {
     double t = 0.;
+    if (J[m] == K[m]) {
 #pragma unroll
-    for (int n = 0; n < 3; n++) t += (dg[n][J[m]] * F[n][K[m]] + F[n][J[m]] * dg[n][K[m]]) / 2.;
+      for (int n = 0; n < 3; n++) t += dg[n][J[m]] * F[n][J[m]];
+    } else {
+#pragma unroll
+      for (int n = 0; n < 3; n++) t += dg[n][J[m]] * F[n][K[m]] + F[n][J[m]] * dg[n][K[m]];
+      t *= 0.5;
+    }
     dE[m] = t;
   }
-  double CidE = 0.;  // C^-1 : dE
-#pragma unroll
-  for (int a = 0; a < 3; a++)
-#pragma unroll
-    for (int b = 0; b < 3; b++) CidE += CPS_SYM(s.Ci, a, b) * CPS_SYM(dE, a, b);
-  double dECi[3][3], dS[3][3], dP[3][3];
+  // C^-1 : dE  (symmetric: diagonal + twice the off-diagonal)
+  const double CidE = s.Ci[0] * dE[0] + s.Ci[1] * dE[1] + s.Ci[2] * dE[2] +
+                      2. * (s.Ci[3] * dE[3] + s.Ci[4] * dE[4] + s.Ci[5] * dE[5]);
+  double dECi[3][3], dS[6], dP[3][3];
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -226,23 +242,21 @@ CPS_DEV void qf_hyperfs_df(const Phys ph, const double *dug, const double *qd, c
       for (int m = 0; m < 3; m++) t += CPS_SYM(dE, a, m) * CPS_SYM(s.Ci, m, b);
       dECi[a][b] = t;
     }
-  const double llnj_m = s.llnj - mu;
+  const double llnj_m2 = 2. * (s.llnj - mu), lCidE = lambda * CidE;
 #pragma unroll
-  for (int a = 0; a < 3; a++)
+  for (int m = 0; m < 6; m++) {  // dS = lambda (C^-1:dE) C^-1 - 2 (llnj - mu) C^-1 dE C^-1: symmetric, 6 entries
+    double t = 0.;
 #pragma unroll
-    for (int b = 0; b < 3; b++) {
-      double t = 0.;
-#pragma unroll
-      for (int m = 0; m < 3; m++) t += CPS_SYM(s.Ci, a, m) * dECi[m][b];
-      dS[a][b] = lambda * CidE * CPS_SYM(s.Ci, a, b) - 2. * llnj_m * t;  // hyperFS.h:438-442
-    }
+    for (int n = 0; n < 3; n++) t += CPS_SYM(s.Ci, J[m], n) * dECi[n][K[m]];
+    dS[m] = lCidE * s.Ci[m] - llnj_m2 * t;  // hyperFS.h:438-442
+  }
 #pragma unroll
   for (int a = 0; a < 3; a++)  // dP = grad(du) S + F dS    (hyperFS.h:444-451)
 #pragma unroll
     for (int b = 0; b < 3; b++) {
       double t = 0.;
 #pragma unroll
-      for (int m = 0; m < 3; m++) t += dg[a][m] * CPS_SYM(s.S, m, b) + F[a][m] * dS[m][b];
+      for (int m = 0; m < 3; m++) t += dg[a][m] * CPS_SYM(s.S, m, b) + F[a][m] * CPS_SYM(dS, m, b);
       dP[a][b] = t;
     }
   pull_back(dP, qd, dv);
