@@ -100,7 +100,7 @@ def cpu_baseline(args, nr, nth):
     while True:
         p.apply_jacobian(p.fine, X, Y); k += 1
         el = time.perf_counter() - t0
-        if el > args.cpu_seconds or k >= 200:
+        if el > args.cpu_seconds or k >= 5000:
             break
     return {"value": 1e-6 * p.n_free() * k / el, "unit": "MDoF/s", "cores": cores, "kind": "port",
             "sample": f"{mesh.nelem}-element z-slab ({nr}x{nth}x{nz}) of the same cylinder, degree {args.degree} "
@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-sample-layers", type=int, default=3)
+    ap.add_argument("--calibrate-traffic", action="store_true",
+                    help="also launch k_axpby over a 1 GiB vector (known byte count) for PMC calibration")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,11 +132,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    ngpu_visible = torch.cuda.device_count()
+    local_rank = local_rank % max(1, ngpu_visible)   # rehearsal: several ranks may share the one visible GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")   # "gloo": single-GPU rehearsal of the N > 1 path
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     lib = cd.CeedLib(cd.PRODUCT_LIB)          # fails loudly if the HIP library is missing
     ceed = cd.Ceed(lib, "/gpu/hip/mi355x")
@@ -164,6 +172,13 @@ def main():
         prob.apply_jacobian(prob.fine, X, Y)   # memset(y) + fused kernel on `stream`
         halo.add(yt)                            # interface sum (no-op at N = 1)
 
+    if args.calibrate_traffic:   # known traffic for tools/collect_traffic.py: reads 2 GiB, writes 1 GiB
+        import ctypes as C
+        ncal = 2 ** 27
+        va, vb = ceed.vector(ncal).set_value(1.0), ceed.vector(ncal).set_value(2.0)
+        for _ in range(3):
+            lib.chk(lib.lib.CeedXVectorAXPBY(va.h, C.c_double(0.5), vb.h, C.c_double(0.25)))
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     op.set_timing(True)
@@ -180,7 +195,7 @@ def main():
     kernel_ms, launches = op.get_timing()
     op.set_timing(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

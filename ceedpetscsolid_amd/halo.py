@@ -38,6 +38,9 @@ class HaloExchange:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device = torch.device(device)
+        # gloo cannot move device tensors point-to-point: stage through the host (CPU tests and
+        # single-GPU rehearsals only; the GPU node uses "nccl" = RCCL, device buffers end to end)
+        self.stage_host = (dist.is_initialized() and dist.get_backend(group) == "gloo" and self.device.type == "cuda")
         self.dm = dm
         self.neigh: List[Neighbour] = []
         self.owner_weight = np.ones(dm.lsize)   # 1 on dofs this rank owns (lowest sharing rank)
@@ -62,7 +65,8 @@ class HaloExchange:
             nodes = cand_sorted[pos].astype(np.int64)
             dofs = (nodes[:, None] * nc + np.arange(nc)[None, :]).ravel()
             idx = torch.from_numpy(dofs).to(self.device)
-            buf = lambda: torch.zeros(dofs.size, dtype=torch.float64, device=self.device)
+            bdev = torch.device("cpu") if self.stage_host else self.device
+            buf = lambda: torch.zeros(dofs.size, dtype=torch.float64, device=bdev)
             self.neigh.append(Neighbour(r, idx, buf(), buf()))
             if r < self.rank:
                 self.owner_weight[dofs] = 0.0
@@ -77,21 +81,24 @@ class HaloExchange:
             return
         ops = []
         for n in self.neigh:
-            torch.index_select(y, 0, n.dof_idx, out=n.send)
+            if self.stage_host:
+                n.send.copy_(torch.index_select(y, 0, n.dof_idx))
+            else:
+                torch.index_select(y, 0, n.dof_idx, out=n.send)
         for n in self.neigh:
             ops.append(dist.P2POp(dist.isend, n.send, n.rank, group=self.group))
             ops.append(dist.P2POp(dist.irecv, n.recv, n.rank, group=self.group))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
         for n in self.neigh:
-            y.index_add_(0, n.dof_idx, n.recv)
+            y.index_add_(0, n.dof_idx, n.recv.to(y.device) if self.stage_host else n.recv)
 
     def global_count(self, local_mask_free: np.ndarray) -> int:
         """Number of distinct unconstrained dofs over all ranks (the reference's Ugsz)."""
         mine = float((local_mask_free * self.owner_weight).sum())
         if self.world == 1:
             return int(round(mine))
-        t = torch.tensor([mine], dtype=torch.float64, device=self.device)
+        t = torch.tensor([mine], dtype=torch.float64, device="cpu" if self.stage_host else self.device)
         dist.all_reduce(t, group=self.group)
         return int(round(t.item()))
 

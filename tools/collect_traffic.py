@@ -1,0 +1,43 @@
+"""Reduce rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes, as MI355X_MICROARCH.md
+prescribes) into profiles/r01_traffic.json.  gfx950 corrections applied:
+  * FETCH_SIZE counts 64 B per 128-B fabric read request: doubled for wide coalesced streaming reads.
+    Our reads are 8 B/lane (512 B contiguous per wave-instruction), an access width the guide calls
+    uncalibrated, so the factor is CALIBRATED in the same run on a kernel with a known byte count
+    (k_axpby over a 1 GiB vector: reads 2 x 8 B/lane streams, writes one).
+  * WRITE_SIZE is taken as exact for streaming stores after the same calibration.
+Usage (on the GPU box):  python tools/collect_traffic.py <fetch_pass_dir> <write_pass_dir> <bench_json>
+"""
+import csv, glob, json, os, sys, collections
+
+def load(d):
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+def mean(v): return sum(v) / len(v)
+
+fetch, write, bench = load(sys.argv[1]), load(sys.argv[2]), json.load(open(sys.argv[3]))
+def find(agg, key):
+    return [k for k in agg if key in k]
+cal_known = float(os.environ.get("CAL_BYTES", str(2 ** 30)))   # vector bytes of the calibration axpby
+kax = find(fetch, "k_axpby")
+f_cal = w_cal = None
+if kax:
+    f_cal = 2 * cal_known / (mean(fetch[kax[0]]["FETCH_SIZE"]) * 1024.0)      # true read bytes / counted
+    w_cal = 1 * cal_known / (mean(write[find(write, "k_axpby")[0]]["WRITE_SIZE"]) * 1024.0)
+out = {"kernel": bench["config"]["kernel"], "elements_per_gpu": bench["config"]["elements_per_gpu"],
+       "fetch_calibration_factor": f_cal, "write_calibration_factor": w_cal, "per_kernel": {}}
+tot = 0.0
+for name in ("k_fused_grad<5, 5, 6>", "k_assemble"):
+    kf, kw = find(fetch, name), find(write, name)
+    if not kf: continue
+    fb = mean(fetch[kf[0]]["FETCH_SIZE"]) * 1024.0 * (f_cal or 2.0)
+    wb = mean(write[kw[0]]["WRITE_SIZE"]) * 1024.0 * (w_cal or 1.0)
+    out["per_kernel"][name] = {"fetch_bytes": fb, "write_bytes": wb}
+    tot += fb + wb
+out["hbm_bytes_per_apply"] = tot
+out["algorithmic_bytes_per_apply"] = bench["roofline"]["algorithmic_bytes_per_launch"]
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r01_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
