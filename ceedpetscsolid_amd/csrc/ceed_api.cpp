@@ -66,6 +66,7 @@ struct Ceed_private {
   double *evec = nullptr;
   size_t evec_len = 0;
   bool atomic_scatter = false;  // CEED_MI355X_SCATTER=atomic: f64 atomics instead of E-vector + assembly
+  double *d_scalar = nullptr;   // device scalar for reductions
 };
 
 struct CeedVector_private {
@@ -185,7 +186,7 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   return 0;
 }
 static void ceed_ref(Ceed c) { c->refcount++; }
-static void ceed_unref(Ceed c) { if (--c->refcount == 0) { if (c->evec) (void)hipFree(c->evec); delete c; } }
+static void ceed_unref(Ceed c) { if (--c->refcount == 0) { if (c->evec) (void)hipFree(c->evec); if (c->d_scalar) (void)hipFree(c->d_scalar); delete c; } }
 extern "C" int CeedDestroy(Ceed *ceed) {
   if (!ceed || !*ceed) return 0;
   ceed_unref(*ceed);
@@ -1040,11 +1041,11 @@ extern "C" int CeedXVectorDot(CeedVector x, CeedVector y, CeedVector weight, dou
   CHK(vec_dev(x, false, &px)); CHK(vec_dev(y, false, &py));
   if (weight && weight != CEED_VECTOR_NONE) CHK(vec_dev(weight, false, &pw));
   hipStream_t s = x->ceed->stream;
-  HIPCHK(hipMalloc((void **)&dres, sizeof(double)));
+  if (!x->ceed->d_scalar) HIPCHK(hipMalloc((void **)&x->ceed->d_scalar, sizeof(double)));
+  dres = x->ceed->d_scalar;
   HIPCHK(hipMemsetAsync(dres, 0, sizeof(double), s));
   HIPCHK(launch_dot(px, py, pw, (size_t)x->length, dres, s));
   HIPCHK(hipMemcpyAsync(result, dres, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  HIPCHK(hipFree(dres));
   return 0;
 }

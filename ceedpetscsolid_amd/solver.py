@@ -1,0 +1,335 @@
+"""Newton - CG - p-multigrid solve on top of the operator path (BASELINE config 3).
+
+The reference wires this out of PETSc objects (elasticity.c:386-673): SNES Newton with the
+critical-point line search (:596-601) over load increments (:637-673); KSPCG in the natural norm,
+rtol 1e-10 (:504-507); PCMG multiplicative V-cycle with 3 Chebyshev(+Jacobi) smoothing steps per
+level, eigenvalue bounds (0, 0.1, 0, 1.1) x the estimate (:539-552, :588-590); prolongation /
+restriction MatShells (Prolong_Ceed / Restrict_Ceed); a coarse solve by GAMG on the FD-coloured
+p=1 matrix (:457-483,:568-585).  PETSc is absent here, so this is this build's own control flow with
+the same structure; every vector and operator operation runs on the device through the C ABI
+(CeedOperatorApply, CeedOperatorLinearAssembleDiagonal, CeedX vector helpers).  The coarse level is
+solved by Jacobi-preconditioned CG on the p=1 operator itself (no assembled matrix, no AMG); because
+that makes the preconditioner mildly non-linear the outer Krylov method is the flexible
+(Polak-Ribiere) CG, which coincides with CG for a fixed preconditioner.
+
+Iteration counts are therefore this build's own, not PETSc's; the throughput figure reported is the
+reference's "DoFs/Sec in SNES" = 1e-6 * Ugsz * (total KSP iterations) / (solve time)
+(elasticity.c:755-764).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import ceed as cd
+from .solid import SolidProblem
+
+
+# ---- boundary functions (src/boundary.c) -------------------------------------------------------
+def bc_mms(X: np.ndarray, load: float) -> np.ndarray:
+    """BCMMS, boundary.c:31-50."""
+    x, y, z = X[:, 0], X[:, 1], X[:, 2]
+    return np.stack([np.exp(2 * x) * np.sin(3 * y) * np.cos(4 * z), np.exp(3 * y) * np.sin(4 * z) * np.cos(2 * x),
+                     np.exp(4 * z) * np.sin(2 * x) * np.cos(3 * y)], axis=1) / 1e8 * load
+
+
+def bc_clamp(X: np.ndarray, load: float, translate=(0., 0., 0.), axis=(0., 0., 1.), angle_over_pi: float = 0.0) -> np.ndarray:
+    """BCClamp, boundary.c:53-74: translation + rotation about `axis` by angle_over_pi*pi, scaled by the load
+    fraction.  The x-component's (1-c) term is reproduced AS WRITTEN at boundary.c:69
+    (`-ky*ky + kz*kz*x + ...`)."""
+    x, y, z = X[:, 0], X[:, 1], X[:, 2]
+    lx, ly, lz = (t * load for t in translate)
+    kx, ky, kz = axis
+    th = angle_over_pi * np.pi * load
+    c, s = np.cos(th), np.sin(th)
+    u0 = lx + s * (-kz * y + ky * z) + (1 - c) * (-ky * ky + kz * kz * x + kx * ky * y + kx * kz * z)
+    u1 = ly + s * (kz * x + -kx * z) + (1 - c) * (kx * ky * x - (kx * kx + kz * kz) * y + ky * kz * z)
+    u2 = lz + s * (-ky * x + kx * y) + (1 - c) * (kx * kz * x + ky * kz * y - (kx * kx + ky * ky) * z)
+    return np.stack([u0, u1, u2], axis=1)
+
+
+@dataclass
+class SolveStats:
+    newton_its: int = 0
+    ksp_its: int = 0
+    coarse_its: int = 0
+    jacobian_applies: int = 0
+    residual_evals: int = 0
+    seconds: float = 0.0
+    increments: int = 0
+    converged: bool = True
+    history: list = field(default_factory=list)
+
+
+class Vec:
+    """Thin helpers over CeedVector + the CeedX vector extensions (stand-ins for PETSc Vec calls)."""
+
+    def __init__(self, ceed: cd.Ceed, n: int):
+        self.v = ceed.vector(n).set_value(0.0)
+        self.n = n
+
+
+class NewtonPMG:
+    def __init__(self, prob: SolidProblem, clamp: Optional[Dict[int, dict]] = None, mms: bool = False,
+                 halo=None, smooth_its: int = 3, coarse_rtol: float = 1e-3, coarse_maxit: int = 200,
+                 ksp_rtol: float = 1e-10, snes_rtol: float = 1e-8, snes_maxit: int = 50, verbose: bool = False):
+        """``clamp``: {side_set_id: dict(translate=(..), axis=(..), angle_over_pi=..)} as
+        -bc_clamp_<id>_translate / _rotate (cloptions.c:86-131); ids present in the problem's Dirichlet
+        set but absent here are held at zero."""
+        self.p, self.ceed, self.L = prob, prob.ceed, prob.ceed.L
+        self.clamp, self.mms, self.halo = clamp or {}, mms, halo
+        self.smooth_its, self.coarse_rtol, self.coarse_maxit = smooth_its, coarse_rtol, coarse_maxit
+        self.ksp_rtol, self.snes_rtol, self.snes_maxit, self.verbose = ksp_rtol, snes_rtol, snes_maxit, verbose
+        self.nlev = len(prob.levels)
+        c = self.ceed
+        mk = lambda lv: c.vector(prob.lsize(lv)).set_value(0.0)
+        self.w = [{k: mk(lv) for k in ("x", "b", "r", "d", "t", "dinv", "z")} for lv in range(self.nlev)]
+        self.emax = [1.0] * self.nlev
+        n = prob.lsize()
+        self.U, self.R, self.dU, self.Xloc, self.bcv, self.Rtry, self.Utry = (c.vector(n).set_value(0.0) for _ in range(7))
+        self.kp, self.kz, self.kAp, self.kzold = (c.vector(n).set_value(0.0) for _ in range(4))
+        lvf = prob.levels[prob.fine]
+        self.free = (lvf.mask == 0)
+        self.weight = None
+        if halo is not None and halo.world > 1:
+            self.weight = c.vector(n).set_array(halo.owner_weight * self.free)
+        self.stats = SolveStats()
+        self._bc_nodes = self._collect_bc_nodes()
+
+    # ---- vector helpers ---------------------------------------------------------------------
+    def axpby(self, y, a, x, b):
+        self.L.chk(self.L.lib.CeedXVectorAXPBY(y.h, C.c_double(a), x.h, C.c_double(b)))
+
+    def copy(self, dst, src):
+        self.axpby(dst, 1.0, src, 0.0)
+
+    def pmult(self, w, x, y):
+        self.L.chk(self.L.lib.CeedXVectorPointwiseMult(w.h, x.h, y.h))
+
+    def dot(self, x, y, fine_weight=False) -> float:
+        r = C.c_double()
+        wv = self.weight.h if (fine_weight and self.weight is not None) else None
+        self.L.chk(self.L.lib.CeedXVectorDot(x.h, y.h, wv, C.byref(r)))
+        v = r.value
+        if self.halo is not None and self.halo.world > 1:
+            import torch, torch.distributed as dist
+            t = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(t)
+            v = float(t.item())
+        return v
+
+    def _halo_add(self, vec):
+        if self.halo is not None and self.halo.world > 1:
+            raise NotImplementedError("multi-rank solve: wrap the vectors' device buffers as torch tensors and call halo.add")
+
+    # ---- operators ---------------------------------------------------------------------------
+    def A(self, lv, x, y):
+        self.p.apply_jacobian(lv, x, y)
+        self.stats.jacobian_applies += 1
+
+    def _collect_bc_nodes(self):
+        from .mesh import side_set_nodes
+        lv = self.p.levels[self.p.fine]
+        out = {}
+        for sid in self.clamp:
+            out[sid] = side_set_nodes(self.p.mesh, lv.dofmap, [sid])
+        return out
+
+    def bc_values(self, load: float) -> np.ndarray:
+        """DMPlexInsertBoundaryValues at `time = loadIncrement` (matops.c:70-72)."""
+        lv = self.p.levels[self.p.fine]
+        v = np.zeros((lv.dofmap.nnodes, 3))
+        if self.mms:
+            nodes = np.nonzero(lv.mask.reshape(-1, 3)[:, 0])[0]
+            v[nodes] = bc_mms(lv.dofmap.node_coords[nodes], load)
+        for sid, par in self.clamp.items():
+            nodes = self._bc_nodes[sid]
+            v[nodes] = bc_clamp(lv.dofmap.node_coords[nodes], load, **par)
+        return (v.reshape(-1) * (lv.mask != 0))
+
+    def residual(self, U, R):
+        """FormResidual_Ceed: Xloc = free part of U + boundary values; R = F(Xloc), constrained rows dropped."""
+        self.copy(self.Xloc, U)
+        self.axpby(self.Xloc, 1.0, self.bcv, 1.0)
+        self.p.form_residual(self.Xloc, R)
+        self.stats.residual_evals += 1
+
+    # ---- multigrid preconditioner ---------------------------------------------------------------
+    def setup_preconditioner(self):
+        """Per Newton step: diagonals (GetDiag_Ceed), Chebyshev eigenvalue estimates."""
+        rng = np.random.default_rng(1234)
+        for lv in range(self.nlev):
+            w = self.w[lv]
+            self.p.get_diag(lv, w["dinv"])
+            d = w["dinv"].to_numpy()
+            mask = self.p.levels[lv].mask != 0
+            d[mask] = 1.0                       # constrained rows: identity
+            w["dinv"].set_array(1.0 / d)
+            # largest eigenvalue of D^-1 A by power iteration from a noisy start (the reference lets
+            # PETSc estimate it with a few CG-Lanczos steps on a noisy right-hand side, :546-549)
+            x = rng.uniform(-1, 1, d.size) * (~mask)
+            w["x"].set_array(x / np.linalg.norm(x))
+            lam = 1.0
+            for _ in range(12):
+                self.A(lv, w["x"], w["t"])
+                self.pmult(w["t"], w["t"], w["dinv"])
+                lam = np.sqrt(self.dot(w["t"], w["t"]))
+                self.axpby(w["x"], 1.0 / lam, w["t"], 0.0)
+            self.emax[lv] = lam
+
+    def chebyshev(self, lv, b, x, its, zero_guess):
+        """Chebyshev iteration on D^-1 A with bounds [0.1, 1.1] x emax (KSPChebyshevEstEigSet(0,0.1,0,1.1))."""
+        w = self.w[lv]
+        lmin, lmax = 0.1 * self.emax[lv], 1.1 * self.emax[lv]
+        theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+        sigma = theta / delta
+        rho = 1.0 / sigma
+        r, d, t = w["r"], w["d"], w["t"]
+        if zero_guess:
+            self.copy(r, b)
+            x.set_value(0.0)
+        else:
+            self.A(lv, x, t)
+            self.copy(r, b); self.axpby(r, -1.0, t, 1.0)
+        self.pmult(d, r, w["dinv"]); self.axpby(d, 1.0 / theta, d, 0.0)
+        for k in range(its):
+            self.axpby(x, 1.0, d, 1.0)
+            if k == its - 1:
+                break
+            self.A(lv, d, t)
+            self.axpby(r, -1.0, t, 1.0)
+            rho_new = 1.0 / (2.0 * sigma - rho)
+            self.pmult(t, r, w["dinv"])
+            self.axpby(d, 2.0 * rho_new / delta, t, rho_new * rho)
+            rho = rho_new
+
+    def coarse_solve(self, b, x):
+        """Jacobi-preconditioned CG on the coarsest operator (stands in for GAMG on the FD-coloured matrix)."""
+        w = self.w[0]
+        r, d, t, z = w["r"], w["d"], w["t"], w["z"]
+        x.set_value(0.0)
+        self.copy(r, b)
+        self.pmult(z, r, w["dinv"]); self.copy(d, z)
+        rz = self.dot(r, z)
+        rz0 = rz
+        if rz0 <= 0.0:
+            return
+        for it in range(self.coarse_maxit):
+            self.A(0, d, t)
+            alpha = rz / self.dot(d, t)
+            self.axpby(x, alpha, d, 1.0); self.axpby(r, -alpha, t, 1.0)
+            self.pmult(z, r, w["dinv"])
+            rz_new = self.dot(r, z)
+            self.stats.coarse_its += 1
+            if rz_new <= self.coarse_rtol ** 2 * rz0:
+                break
+            self.axpby(d, 1.0, z, rz_new / rz)
+            rz = rz_new
+
+    def vcycle(self, lv, b, x):
+        """PC_MG_MULTIPLICATIVE V-cycle, 3 smoothing steps down and up (elasticity.c:588-590)."""
+        if lv == 0:
+            if self.nlev == 1:
+                self.chebyshev(0, b, x, self.smooth_its, True)
+            else:
+                self.coarse_solve(b, x)
+            return
+        w, wc = self.w[lv], self.w[lv - 1]
+        self.chebyshev(lv, b, x, self.smooth_its, True)
+        self.A(lv, x, w["t"])
+        self.copy(w["z"], b); self.axpby(w["z"], -1.0, w["t"], 1.0)      # residual
+        self.p.restrict(lv, w["z"], wc["b"])                                # Restrict_Ceed
+        self.vcycle(lv - 1, wc["b"], wc["x"])
+        self.p.prolong(lv, wc["x"], w["z"])                                 # Prolong_Ceed
+        self.axpby(x, 1.0, w["z"], 1.0)
+        self.chebyshev(lv, b, x, self.smooth_its, False)
+
+    def precondition(self, r, z):
+        if self.nlev == 1:          # -multigrid none: Jacobi (elasticity.c:516-519)
+            self.pmult(z, r, self.w[0]["dinv"])
+        else:
+            self.vcycle(self.nlev - 1, r, z)
+
+    # ---- Krylov ---------------------------------------------------------------------------------
+    def fcg(self, b, x, rtol):
+        """Flexible preconditioned CG, natural-norm convergence test (KSP_NORM_NATURAL: sqrt(r'z))."""
+        fine = self.nlev - 1
+        r, z, p, Ap, zold = self.w[fine]["b"], self.kz, self.kp, self.kAp, self.kzold
+        x.set_value(0.0)
+        self.copy(r, b)
+        self.precondition(r, z)
+        self.copy(p, z)
+        rz = self.dot(r, z, True)
+        rz0 = rz
+        its = 0
+        if rz0 <= 0.0:
+            return 0
+        for its in range(1, 500):
+            self.A(fine, p, Ap)
+            alpha = rz / self.dot(p, Ap, True)
+            self.axpby(x, alpha, p, 1.0); self.axpby(r, -alpha, Ap, 1.0)
+            self.copy(zold, z)
+            self.precondition(r, z)
+            rz_new = self.dot(r, z, True)
+            if self.verbose:
+                print(f"      ksp {its:3d}  natural norm {np.sqrt(abs(rz_new)):.3e}")
+            if rz_new <= rtol ** 2 * rz0:
+                break
+            beta = (rz_new - self.dot(r, zold, True)) / rz   # Polak-Ribiere: flexible
+            self.axpby(p, 1.0, z, beta)
+            rz = rz_new
+        return its
+
+    # ---- Newton with load increments ---------------------------------------------------------------
+    def solve(self, num_increments: int = 10) -> SolveStats:
+        st = self.stats
+        t0 = time.perf_counter()
+        self.U.set_value(0.0)
+        for inc in range(1, num_increments + 1):
+            load = inc / num_increments
+            self.bcv.set_array(self.bc_values(load))
+            self.residual(self.U, self.R)
+            rnorm0 = np.sqrt(self.dot(self.R, self.R, True))
+            rnorm = rnorm0
+            if self.verbose:
+                print(f"increment {inc}/{num_increments}: |R| = {rnorm0:.6e}")
+            for it in range(self.snes_maxit):
+                if rnorm <= self.snes_rtol * rnorm0 or rnorm < 1e-50:
+                    break
+                self.setup_preconditioner()
+                self.axpby(self.Rtry, -1.0, self.R, 0.0)                 # rhs = -R
+                k = self.fcg(self.Rtry, self.dU, self.ksp_rtol)
+                st.ksp_its += k
+                # critical-point line search (SNESLINESEARCHCP): secant on phi(l) = dU . R(U + l dU)
+                lam, lam_old = 1.0, 0.0
+                phi_old = self.dot(self.dU, self.R, True)
+                for _ in range(3):
+                    self.copy(self.Utry, self.U); self.axpby(self.Utry, lam, self.dU, 1.0)
+                    self.residual(self.Utry, self.Rtry)
+                    phi = self.dot(self.dU, self.Rtry, True)
+                    if abs(phi) <= 1e-8 * abs(phi_old) or abs(phi - phi_old) < 1e-300:
+                        break
+                    lam_new = lam - phi * (lam - lam_old) / (phi - phi_old)
+                    if not np.isfinite(lam_new) or abs(lam_new - lam) < 1e-8 or lam_new <= 0.0 or lam_new > 10.0:
+                        break
+                    lam_old, phi_old, lam = lam, phi, lam_new
+                self.axpby(self.U, lam, self.dU, 1.0)
+                self.residual(self.U, self.R)                              # also refreshes the stored state
+                rnorm = np.sqrt(self.dot(self.R, self.R, True))
+                st.newton_its += 1
+                st.history.append((inc, it + 1, k, lam, rnorm))
+                if self.verbose:
+                    print(f"   newton {it + 1:2d}: ksp its {k:3d}  lambda {lam:.4f}  |R| = {rnorm:.6e}")
+            else:
+                st.converged = False
+            st.increments = inc
+            if not np.isfinite(rnorm) or not st.converged:
+                st.converged = False
+                break
+        self.ceed.synchronize()
+        st.seconds = time.perf_counter() - t0
+        return st
