@@ -30,8 +30,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from ceedpetscsolid_amd import ceed as cd  # noqa: E402
-from ceedpetscsolid_amd.halo import HaloExchange, slab_cylinder  # noqa: E402
-from ceedpetscsolid_amd.solid import SolidProblem  # noqa: E402
+from ceedpetscsolid_amd.halo import HaloExchange, slab_box, slab_cylinder  # noqa: E402
+from ceedpetscsolid_amd.harness import SolidApp  # noqa: E402
+from ceedpetscsolid_amd.solid import SolidProblem, smooth_displacement  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -117,6 +118,9 @@ def main():
     ap.add_argument("--nr", type=int, default=10)
     ap.add_argument("--nth", type=int, default=110)
     ap.add_argument("--nz", type=int, default=90)
+    ap.add_argument("--workload", default="cylinder", choices=["cylinder", "box"],
+                    help="cylinder: BASELINE config 4 (default, the metric's config); box: config 5 shape, "
+                         "nr x nth x nz elements per GPU (e.g. --workload box --nr 32 --nth 32 --nz 32 --degree 6)")
     ap.add_argument("--nu", type=float, default=0.3)
     ap.add_argument("--E", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -150,23 +154,29 @@ def main():
     ceed.set_stream(stream.cuda_stream)
 
     # ---- workload ---------------------------------------------------------
-    mesh = slab_cylinder(rank, world, args.nr, args.nth, args.nz)
-    bc = [s for s in (998, 999) if s in mesh.side_sets]
-    prob = SolidProblem(ceed, mesh, args.degree, args.problem, nu=args.nu, E=args.E, bc_sides=bc, multigrid="none")
-    lv = prob.levels[prob.fine]
+    if args.workload == "cylinder":
+        mesh = slab_cylinder(rank, world, args.nr, args.nth, args.nz)
+        bc = [s for s in (998, 999) if s in mesh.side_sets]
+    else:
+        mesh = slab_box(rank, world, args.nr, args.nth, args.nz)
+        bc = [s for s in (1, 2) if s in mesh.side_sets]
+    # host side = the C++ harness (csrc/solid_harness.cpp): SetupLibceedFineLevel / SetupLibceedLevel /
+    # ApplyJacobian_Ceed restated over include/ceed.h
+    prob = SolidApp(ceed, mesh, args.degree, args.problem, nu=args.nu, E=args.E, bc_sides=bc, multigrid="none")
+    dofmap, mask = prob.dofmaps[prob.fine], prob.masks[prob.fine]
     n = prob.lsize()
-    halo = HaloExchange(mesh, lv.dofmap, device=dev)
-    free = (lv.mask == 0).astype(np.float64)
+    halo = HaloExchange(mesh, dofmap, device=dev)
+    free = (mask == 0).astype(np.float64)
     n_global = halo.global_count(free)
 
     # state u (stores gradu through the residual), then the Jacobian input x
-    xt = torch.from_numpy(prob.smooth_state(0.1, origin=(-1.0, -1.0, 0.0), span=(2.0, 2.0, 10.0))).to(dev)
+    xt = torch.from_numpy(smooth_displacement(dofmap.node_coords, 0.1, origin=(-1.0, -1.0, 0.0), span=(2.0, 2.0, 10.0))).to(dev)
     yt = torch.zeros(n, dtype=torch.float64, device=dev)
-    X, Y = lv.xceed, lv.yceed
-    X.set_device_pointer(xt.data_ptr()); Y.set_device_pointer(yt.data_ptr())
+    X, Y = ceed.vector(n), ceed.vector(n)
+    X.set_device_pointer(xt.data_ptr()); Y.set_device_pointer(yt.data_ptr())   # matops.c:40-41, -memtype device
     prob.form_residual(X, Y)
-    xt.copy_(torch.from_numpy(coord_hash_vector(lv.dofmap.node_coords, lv.mask)).to(dev))
-    op = lv.opJacob
+    xt.copy_(torch.from_numpy(coord_hash_vector(dofmap.node_coords, mask)).to(dev))
+    op = prob.opJacob[prob.fine]
 
     def step():
         prob.apply_jacobian(prob.fine, X, Y)   # memset(y) + fused kernel on `stream`
@@ -205,7 +215,7 @@ def main():
 
     if rank == 0:
         P, Q = args.degree + 1, args.degree + 1
-        abytes = algorithmic_bytes(mesh.nelem, P, Q, n, prob.info["state"])
+        abytes = algorithmic_bytes(mesh.nelem, P, Q, n, args.problem != "linElas")
         avg_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = abytes / avg_s / 1e9
         out = {
@@ -216,9 +226,11 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"config 4: {args.problem}, hollow cylinder {args.nr}x{args.nth}x{args.nz} = "
-                                   f"{mesh.nelem} hex per GPU (stand-in for cylinder8_99Ke_4ss_us.exo), degree {args.degree}, "
-                                   f"Q={Q}, clamped ends, Jacobian apply y=J(u)x",
+            "config": {"workload": (f"config 4: {args.problem}, hollow cylinder {args.nr}x{args.nth}x{args.nz} = "
+                                    f"{mesh.nelem} hex per GPU (stand-in for cylinder8_99Ke_4ss_us.exo), degree {args.degree}, "
+                                    f"Q={Q}, clamped ends, Jacobian apply y=J(u)x") if args.workload == "cylinder" else
+                                   (f"config 5 shape: {args.problem}, box {args.nr}x{args.nth}x{args.nz} = {mesh.nelem} hex per GPU, "
+                                    f"degree {args.degree}, Q={Q}, z faces clamped, Jacobian apply y=J(u)x"),
                        "global_dofs": n_global, "elements_per_gpu": mesh.nelem, "ldofs_per_gpu": n,
                        "halo_dofs_rank0": halo.n_shared_dofs, "kernel": op.kernel_name,
                        "partition": "z-slabs, one per GPU" if world > 1 else "single GPU"},
@@ -229,7 +241,7 @@ def main():
                          "kernels": "k_fused_grad (gather..physics..E-vector) + k_assemble (deterministic per-node sum): the two launches of one CeedOperatorApply, timed together with hipEvents on their stream",
                          "peak_measured_copy_GBs": 6290.0},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "cylinder":
             try:
                 out["cpu_baseline"] = cpu_baseline(args, args.nr, args.nth)
             except Exception as e:  # the baseline is informational; never hide the GPU number

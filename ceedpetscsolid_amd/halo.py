@@ -127,3 +127,21 @@ def slab_cylinder(rank: int, world: int, nr: int, nth: int, nz: int, height_per_
         m.side_sets.pop(999, None)
     m.name = f"cylslab{rank}of{world}_{nr}x{nth}x{nz}"
     return m
+
+
+def slab_box(rank: int, world: int, nx: int, ny: int, nz: int) -> HexMesh:
+    """Weak-scaling box workload (BASELINE config 5 shape: `-dm_plex_box_faces`): rank's z-slab of
+    nx x ny x nz unit-spaced elements of a box `world` slabs tall; global vertex ids; face sets 1 (z-)
+    and 2 (z+) only on the bottom / top rank."""
+    from .mesh import box_mesh
+    h = 1.0 / nx
+    m = box_mesh(nx, ny, nz, lo=(0.0, 0.0, rank * nz * h), hi=(1.0, ny * h, (rank + 1) * nz * h))
+    per_layer = (nx + 1) * (ny + 1)
+    k = np.arange(m.nvert) // per_layer
+    m.vertex_gid = (k + rank * nz) * per_layer + np.arange(m.nvert) % per_layer
+    if rank != 0:
+        m.side_sets.pop(1, None)
+    if rank != world - 1:
+        m.side_sets.pop(2, None)
+    m.name = f"boxslab{rank}of{world}_{nx}x{ny}x{nz}"
+    return m

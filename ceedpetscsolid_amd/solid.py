@@ -50,6 +50,22 @@ def level_degrees(degree: int, multigrid: str = "logarithmic") -> List[int]:
     return [2 ** i for i in range(n - 1)] + [degree]
 
 
+def smooth_displacement(X: np.ndarray, amplitude: float = 0.1, origin=None, span=None) -> np.ndarray:
+    """A smooth displacement field with |grad u| ~ amplitude ("clamp-translate
+    profile + MMS-shaped perturbation") at node coordinates X; host array in L layout.  With
+    ``origin`` / ``span`` given it is a function of the absolute coordinates only, i.e. identical on
+    every rank that shares a node."""
+    origin = X.min(axis=0) if origin is None else np.asarray(origin, dtype=np.float64)
+    span = np.maximum(X.max(axis=0) - X.min(axis=0), 1e-12) if span is None else np.asarray(span, dtype=np.float64)
+    s = (X - origin) / span
+    k = 2.0 * np.pi
+    u = np.empty_like(X)
+    u[:, 0] = amplitude * span[0] / k * np.sin(k * s[:, 1]) * np.cos(k * s[:, 2]) + 0.02 * amplitude * span[0] * s[:, 2]
+    u[:, 1] = amplitude * span[1] / k * np.sin(k * s[:, 2]) * np.cos(k * s[:, 0]) - 0.05 * amplitude * span[1] * s[:, 2]
+    u[:, 2] = amplitude * span[2] / k * np.sin(k * s[:, 0]) * np.cos(k * s[:, 1]) * 0.2 + 0.03 * amplitude * span[2] * s[:, 2]
+    return u.reshape(-1)
+
+
 @dataclass
 class LevelData:  # CeedData, elasticity.h:218-240
     degree: int
@@ -245,20 +261,7 @@ class SolidProblem:
 
     # --------------------------------------------------------------- helpers
     def smooth_state(self, amplitude: float = 0.1, origin=None, span=None) -> np.ndarray:
-        """A smooth displacement field with |grad u| ~ amplitude on the fine level (SURVEY 8d,
-        config 4: "clamp-translate profile + MMS-shaped perturbation"); host array, L layout.
-        With ``origin`` / ``span`` given it is a function of the absolute coordinates only, i.e.
-        identical on every rank that shares a node."""
-        X = self.levels[self.fine].dofmap.node_coords
-        origin = X.min(axis=0) if origin is None else np.asarray(origin, dtype=np.float64)
-        span = np.maximum(X.max(axis=0) - X.min(axis=0), 1e-12) if span is None else np.asarray(span, dtype=np.float64)
-        s = (X - origin) / span
-        k = 2.0 * np.pi
-        u = np.empty_like(X)
-        u[:, 0] = amplitude * span[0] / k * np.sin(k * s[:, 1]) * np.cos(k * s[:, 2]) + 0.02 * amplitude * span[0] * s[:, 2]
-        u[:, 1] = amplitude * span[1] / k * np.sin(k * s[:, 2]) * np.cos(k * s[:, 0]) - 0.05 * amplitude * span[1] * s[:, 2]
-        u[:, 2] = amplitude * span[2] / k * np.sin(k * s[:, 0]) * np.cos(k * s[:, 1]) * 0.2 + 0.03 * amplitude * span[2] * s[:, 2]
-        return u.reshape(-1)
+        return smooth_displacement(self.levels[self.fine].dofmap.node_coords, amplitude, origin, span)
 
     def destroy(self):
         for lv in self.levels:
