@@ -63,7 +63,9 @@ class CeedLib:
         "CeedOperatorLinearAssembleDiagonal", "CeedOperatorDestroy",
         "CeedXSetErrorReturn", "CeedXLastError", "CeedXSetStream", "CeedXSynchronize",
         "CeedXOperatorGetKernelName", "CeedXOperatorSetDirichletMask",
-        "CeedXOperatorSetTiming", "CeedXOperatorGetTiming",
+        "CeedXOperatorSetTiming", "CeedXOperatorGetTiming", "CeedXOperatorSetDirichletMaskMode",
+        "CeedXOperatorSetFineScale", "CeedXOperatorSetOverlapSplit", "CeedXOperatorApplyPhase",
+        "CeedXVectorPointwiseMult", "CeedXVectorAXPBY", "CeedXVectorDot",
     ]
     DATA = [
         "CeedMemTypes", "CEED_VECTOR_ACTIVE", "CEED_VECTOR_NONE", "CEED_ELEMRESTRICTION_NONE",
@@ -379,6 +381,18 @@ class Operator:
             m = np.ascontiguousarray(mask, dtype=np.uint8)
             self.L.chk(self.L.lib.CeedXOperatorSetDirichletMask(
                 self.h, MEM_HOST, m.ctypes.data_as(C.POINTER(C.c_ubyte)), c_int(m.size)))
+
+    def set_overlap_split(self, n_leading_elems: int, priority: Optional[np.ndarray]):
+        """CeedXOperatorSetOverlapSplit: leading elements / priority L-vector entries of the split-phase apply."""
+        if priority is None:
+            self.L.chk(self.L.lib.CeedXOperatorSetOverlapSplit(self.h, c_int(0), None, c_int(0)))
+        else:
+            m = np.ascontiguousarray(priority, dtype=np.uint8)
+            self.L.chk(self.L.lib.CeedXOperatorSetOverlapSplit(
+                self.h, c_int(n_leading_elems), m.ctypes.data_as(C.POINTER(C.c_ubyte)), c_int(m.size)))
+
+    def apply_phase(self, vin: "Vector", vout: "Vector", phase: int):
+        self.L.chk(self.L.lib.CeedXOperatorApplyPhase(self.h, vin.h, vout.h, C.c_int(phase)))
 
     def set_timing(self, enable: bool):
         self.L.chk(self.L.lib.CeedXOperatorSetTiming(self.h, int(enable)))

@@ -78,6 +78,22 @@ struct CeedVector_private {
   bool h_valid = false, d_valid = false;
 };
 
+// Transpose map of an offsets restriction: distinct node offsets and, per node, the E-vector
+// positions (e*elemsize + n) of its contributors in element order.  Rows [0, nprio) are the
+// "priority" nodes when the map was built with a priority mask (split-phase apply).
+struct CsrMap {
+  bool built = false, full_cover = false;
+  int nnodes = 0, nprio = 0;
+  std::vector<uint32_t> h_node_off;
+  uint32_t *d_rowptr = nullptr, *d_cols = nullptr, *d_node_off = nullptr;
+  void release() {
+    if (d_rowptr) (void)hipFree(d_rowptr);
+    if (d_cols) (void)hipFree(d_cols);
+    if (d_node_off) (void)hipFree(d_node_off);
+    d_rowptr = d_cols = d_node_off = nullptr; built = false;
+  }
+};
+
 struct CeedElemRestriction_private {
   Ceed ceed = nullptr;
   int refcount = 1;
@@ -88,10 +104,7 @@ struct CeedElemRestriction_private {
   uint32_t *d_offsets = nullptr;  // plain (unflagged)
   // transpose map for the atomic-free scatter: distinct node offsets (ascending), their contributors
   // (E-vector positions e*elemsize + n, in element order) -- built on first use
-  bool csr_built = false, csr_full_cover = false;
-  int csr_nnodes = 0;
-  std::vector<uint32_t> h_node_off;
-  uint32_t *d_rowptr = nullptr, *d_cols = nullptr, *d_node_off = nullptr;
+  CsrMap csr;   // default map (nodes in ascending offset order)
 };
 
 struct CeedBasis_private {
@@ -134,11 +147,16 @@ struct CeedOperator_private {
   std::string kernel_name;
   // Dirichlet flags
   uint32_t *d_off_flagged_in = nullptr, *d_off_flagged_out = nullptr;  // same array unless transfer
-  unsigned char *d_node_flags = nullptr;  // per distinct node of the restriction's transpose map
+  unsigned char *d_node_flags = nullptr;      // per node of the restriction's transpose map
+  unsigned char *d_node_flags_ovl = nullptr;  // per node of the operator's own (priority-first) map
   std::vector<unsigned char> h_mask;      // copy of the output mask (node flags are derived lazily)
   int mask_mode = 0;
   // optional fine-side scale for transfers
   CeedVector scale = nullptr;
+  // split-phase apply (communication overlap): the first `ovl_lead` elements are the only
+  // contributors of the priority nodes, which come first in the operator's own transpose map
+  int ovl_lead = 0;
+  CsrMap ovl_csr;
   unsigned long long *stamps = nullptr;  // diagnostic builds only
   // timing
   bool timing = false;
@@ -401,9 +419,7 @@ extern "C" int CeedElemRestrictionDestroy(CeedElemRestriction *rstr) {
   if (r == CEED_ELEMRESTRICTION_NONE) return 0;
   if (--r->refcount > 0) return 0;
   if (r->d_offsets) (void)hipFree(r->d_offsets);
-  if (r->d_rowptr) (void)hipFree(r->d_rowptr);
-  if (r->d_cols) (void)hipFree(r->d_cols);
-  if (r->d_node_off) (void)hipFree(r->d_node_off);
+  r->csr.release();
   ceed_unref(r->ceed);
   delete r;
   return 0;
@@ -618,7 +634,8 @@ static void op_free_flags(CeedOperator o) {
   if (o->d_off_flagged_in) (void)hipFree(o->d_off_flagged_in);
   o->d_off_flagged_in = o->d_off_flagged_out = nullptr;
   if (o->d_node_flags) (void)hipFree(o->d_node_flags);
-  o->d_node_flags = nullptr;
+  if (o->d_node_flags_ovl) (void)hipFree(o->d_node_flags_ovl);
+  o->d_node_flags = o->d_node_flags_ovl = nullptr;
   o->h_mask.clear();
   o->mask_mode = 0;
 }
@@ -638,6 +655,7 @@ extern "C" int CeedOperatorDestroy(CeedOperator *op) {
     CeedQFunctionDestroy(&o->qf);
   }
   op_free_flags(o);
+  o->ovl_csr.release();
   CeedVectorDestroy(&o->scale);
   for (auto &ev : o->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   ceed_unref(o->ceed);
@@ -645,38 +663,40 @@ extern "C" int CeedOperatorDestroy(CeedOperator *op) {
   return 0;
 }
 
-// Transpose map of an offsets restriction (setup time, host): counting sort over the L-vector.
-static int rstr_build_csr(CeedElemRestriction r) {
-  if (r->csr_built) return 0;
+// Build a transpose map (setup time, host): counting sort over the L-vector.  With `prio`
+// (one byte per L-vector entry, tested at each node's component-0 offset) the flagged nodes
+// come first.
+static int build_csr(CeedElemRestriction r, CsrMap &M, const unsigned char *prio) {
+  if (M.built) return 0;
   const size_t n = r->h_offsets.size();
   std::vector<uint32_t> cnt((size_t)r->lsize + 1, 0u);
   for (size_t i = 0; i < n; i++) cnt[(size_t)r->h_offsets[i]]++;
   std::vector<uint32_t> slot((size_t)r->lsize, 0xFFFFFFFFu), rowptr;
-  r->h_node_off.clear();
+  M.h_node_off.clear();
   rowptr.push_back(0u);
-  for (CeedInt o = 0; o < r->lsize; o++)
-    if (cnt[o]) {
-      slot[o] = (uint32_t)r->h_node_off.size();
-      r->h_node_off.push_back((uint32_t)o);
+  M.nprio = 0;
+  for (int pass = prio ? 0 : 1; pass < 2; pass++)
+    for (CeedInt o = 0; o < r->lsize; o++) {
+      if (!cnt[o]) continue;
+      if (prio && ((prio[o] != 0) != (pass == 0))) continue;
+      slot[o] = (uint32_t)M.h_node_off.size();
+      M.h_node_off.push_back((uint32_t)o);
       rowptr.push_back(rowptr.back() + cnt[o]);
+      if (prio && pass == 0) M.nprio++;
     }
-  const int nn = (int)r->h_node_off.size();
-  std::vector<uint32_t> cursor(rowptr.begin(), rowptr.end() - 1), cols(n);
-  const size_t es = (size_t)r->elemsize, nc = (size_t)r->ncomp;
-  for (size_t i = 0; i < n; i++) {  // element order => each node's contributors are sorted by element
-    const size_t e = i / es, ln = i % es;
-    (void)e; (void)ln; (void)nc;
+  const int nn = (int)M.h_node_off.size();
+  std::vector<uint32_t> cursor(rowptr.begin(), rowptr.end() - 1), cols(n ? n : 1);
+  for (size_t i = 0; i < n; i++)  // element order => each node's contributors are sorted by element
     cols[cursor[slot[(size_t)r->h_offsets[i]]]++] = (uint32_t)i;  // E position e * elemsize + n
-  }
-  r->csr_nnodes = nn;
-  r->csr_full_cover = (size_t)nn * nc == (size_t)r->lsize;  // every L-vector entry is written by the assembly
-  HIPCHK(hipMalloc((void **)&r->d_rowptr, sizeof(uint32_t) * (nn + 1)));
-  HIPCHK(hipMalloc((void **)&r->d_cols, sizeof(uint32_t) * (n ? n : 1)));
-  HIPCHK(hipMalloc((void **)&r->d_node_off, sizeof(uint32_t) * (nn ? nn : 1)));
-  HIPCHK(hipMemcpy(r->d_rowptr, rowptr.data(), sizeof(uint32_t) * (nn + 1), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(r->d_cols, cols.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(r->d_node_off, r->h_node_off.data(), sizeof(uint32_t) * nn, hipMemcpyHostToDevice));
-  r->csr_built = true;
+  M.nnodes = nn;
+  M.full_cover = (size_t)nn * (size_t)r->ncomp == (size_t)r->lsize;  // every L-vector entry is written by the assembly
+  HIPCHK(hipMalloc((void **)&M.d_rowptr, sizeof(uint32_t) * (nn + 1)));
+  HIPCHK(hipMalloc((void **)&M.d_cols, sizeof(uint32_t) * cols.size()));
+  HIPCHK(hipMalloc((void **)&M.d_node_off, sizeof(uint32_t) * (nn ? nn : 1)));
+  HIPCHK(hipMemcpy(M.d_rowptr, rowptr.data(), sizeof(uint32_t) * (nn + 1), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(M.d_cols, cols.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(M.d_node_off, M.h_node_off.data(), sizeof(uint32_t) * nn, hipMemcpyHostToDevice));
+  M.built = true;
   return 0;
 }
 static int ceed_need_evec(Ceed c, size_t len) {
@@ -686,17 +706,6 @@ static int ceed_need_evec(Ceed c, size_t len) {
   c->evec_len = len;
   return 0;
 }
-static int op_need_node_flags(CeedOperator op, CeedElemRestriction r) {
-  if (op->d_node_flags || op->h_mask.empty()) return 0;
-  std::vector<unsigned char> fl((size_t)r->csr_nnodes, 0);
-  for (int i = 0; i < r->csr_nnodes; i++)
-    for (int c = 0; c < r->ncomp && c < 3; c++)
-      if (op->h_mask[(size_t)r->h_node_off[i] + (size_t)c * r->compstride]) fl[i] |= (unsigned char)(1u << c);
-  HIPCHK(hipMalloc((void **)&op->d_node_flags, fl.size() ? fl.size() : 1));
-  HIPCHK(hipMemcpy(op->d_node_flags, fl.data(), fl.size(), hipMemcpyHostToDevice));
-  return 0;
-}
-
 static void fill_tables(BasisTables &t, CeedBasis b) {
   memset(&t, 0, sizeof t);
   memcpy(t.interp, b->interp1d.data(), sizeof(double) * b->interp1d.size());
@@ -816,59 +825,88 @@ struct TimerScope {
   }
 };
 
+// The residual / Jacobian operator: k_fused_grad (+ k_assemble).  phase -1: whole apply; phase 0 / 1:
+// the two halves of a split-phase apply (CeedXOperatorApplyPhase).
+static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool add, int phase, const char **kname) {
+  CeedQFunction qf = op->qf;
+  hipStream_t s = op->ceed->stream;
+  OpField &ai = op->in[op->i_active];
+  CeedElemRestriction r = ai.rstr;
+  if (!in || in == CEED_VECTOR_NONE || !out || out == CEED_VECTOR_NONE) return ceed_error("active vectors required");
+  if (in->length < r->lsize || out->length < r->lsize) return ceed_error("active vector shorter than the restriction's L-size");
+  if (in == out) return ceed_error("in-place operator apply is not supported");
+  FusedGradArgs a{};
+  double *px, *py, *pq, *ps = nullptr;
+  CHK(vec_dev(in, false, &px));
+  CHK(vec_dev(out, true, &py));
+  CHK(vec_dev(op->in[op->i_qdata].vec, false, &pq));
+  a.offsets = op->d_off_flagged_in ? op->d_off_flagged_in : r->d_offsets;
+  a.x = px; a.y = py; a.qdata = pq;
+  if (op->i_state >= 0) { CHK(vec_dev(op->in[op->i_state].vec, false, &ps)); a.state_in = ps; }
+  if (op->o_state >= 0) {
+    CeedVector sv = op->out[op->o_state].vec;
+    if (!sv || sv == CEED_VECTOR_NONE || sv == CEED_VECTOR_ACTIVE) return ceed_error("state output needs a passive vector");
+    CHK(vec_dev(sv, true, &ps)); a.state_out = ps;  // every point is overwritten
+  }
+  a.mask_in = (op->mask_mode & 1) ? 1 : 0; a.mask_out = (op->mask_mode & 2) ? 1 : 0;
+  CHK(read_phys(qf, &a.nu, &a.E));
+  lame_constants(a.nu, a.E, &a.lambda, &a.TwoMu);
+  a.stamps = op->stamps;
+  const bool use_evec = !op->ceed->atomic_scatter;
+  const bool split = phase >= 0;
+  if (split && (!use_evec || add || op->ovl_lead <= 0 || !op->ovl_csr.built))
+    return ceed_error("split-phase apply needs CeedXOperatorSetOverlapSplit, the E-vector scatter and overwrite mode");
+  // element range and transpose-map rows of this launch
+  const CsrMap *M = nullptr;
+  int row0 = 0, nrows = 0;
+  a.elem_begin = 0; a.nelem = r->nelem;
+  if (use_evec) {  // atomic-free, deterministic scatter: element results -> E-vector -> per-node sums
+    if (split) M = &op->ovl_csr; else { CHK(build_csr(r, r->csr, nullptr)); M = &r->csr; }
+    unsigned char **flagsp = split ? &op->d_node_flags_ovl : &op->d_node_flags;
+    if (!*flagsp && !op->h_mask.empty()) {
+      std::vector<unsigned char> fl((size_t)M->nnodes, 0);
+      for (int i = 0; i < M->nnodes; i++)
+        for (int c = 0; c < r->ncomp && c < 3; c++)
+          if (op->h_mask[(size_t)M->h_node_off[i] + (size_t)c * r->compstride]) fl[i] |= (unsigned char)(1u << c);
+      HIPCHK(hipMalloc((void **)flagsp, fl.size() ? fl.size() : 1));
+      HIPCHK(hipMemcpy(*flagsp, fl.data(), fl.size(), hipMemcpyHostToDevice));
+    }
+    CHK(ceed_need_evec(op->ceed, (size_t)r->nelem * r->ncomp * r->elemsize));
+    a.evec = op->ceed->evec;
+    row0 = 0; nrows = M->nnodes;
+    if (split) {
+      if (phase == 0) { a.nelem = op->ovl_lead; nrows = M->nprio; }
+      else { a.elem_begin = op->ovl_lead; a.nelem = r->nelem - op->ovl_lead; row0 = M->nprio; nrows = M->nnodes - M->nprio; }
+    }
+    if (!add && !M->full_cover && phase <= 0) HIPCHK(hipMemsetAsync(py, 0, sizeof(double) * (size_t)out->length, s));
+  } else if (!add) {
+    HIPCHK(hipMemsetAsync(py, 0, sizeof(double) * (size_t)out->length, s));
+  }
+  {
+    TimerScope ts(op, s);
+    hipError_t e = launch_fused_grad(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, a, s, kname);
+    if (e == hipErrorInvalidValue && !**kname)
+      return ceed_error("no fused kernel instantiated for P=%d Q=%d QFunction %s", ai.basis->P1d, ai.basis->Q1d, qf->name.c_str());
+    HIPCHK(e);
+    if (use_evec) {  // timed together with the fused kernel: the two launches ARE the operator apply
+      const unsigned char *fl = (op->mask_mode & 2) ? (split ? op->d_node_flags_ovl : op->d_node_flags) : nullptr;
+      HIPCHK(launch_assemble(M->d_rowptr + row0, M->d_cols, M->d_node_off + row0, fl ? fl + row0 : nullptr, a.evec, py,
+                             nrows, r->elemsize, add ? 1 : 0, s));
+    }
+  }
+  op->launches++;
+  return 0;
+}
+
 static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool add) {
   CHK(op_plan(op));
   CeedQFunction qf = op->qf;
   hipStream_t s = op->ceed->stream;
   const char *kname = "";
   switch (op->plan) {
-  case PLAN_FUSED_GRAD: {
-    OpField &ai = op->in[op->i_active];
-    CeedElemRestriction r = ai.rstr;
-    if (!in || in == CEED_VECTOR_NONE || !out || out == CEED_VECTOR_NONE) return ceed_error("active vectors required");
-    if (in->length < r->lsize || out->length < r->lsize) return ceed_error("active vector shorter than the restriction's L-size");
-    if (in == out) return ceed_error("in-place operator apply is not supported");
-    FusedGradArgs a{};
-    double *px, *py, *pq, *ps = nullptr;
-    CHK(vec_dev(in, false, &px));
-    CHK(vec_dev(out, true, &py));
-    CHK(vec_dev(op->in[op->i_qdata].vec, false, &pq));
-    a.offsets = op->d_off_flagged_in ? op->d_off_flagged_in : r->d_offsets;
-    a.x = px; a.y = py; a.qdata = pq;
-    if (op->i_state >= 0) { CHK(vec_dev(op->in[op->i_state].vec, false, &ps)); a.state_in = ps; }
-    if (op->o_state >= 0) {
-      CeedVector sv = op->out[op->o_state].vec;
-      if (!sv || sv == CEED_VECTOR_NONE || sv == CEED_VECTOR_ACTIVE) return ceed_error("state output needs a passive vector");
-      CHK(vec_dev(sv, true, &ps)); a.state_out = ps;  // every point is overwritten
-    }
-    a.nelem = r->nelem;
-    a.mask_in = (op->mask_mode & 1) ? 1 : 0; a.mask_out = (op->mask_mode & 2) ? 1 : 0;
-    CHK(read_phys(qf, &a.nu, &a.E));
-    lame_constants(a.nu, a.E, &a.lambda, &a.TwoMu);
-    a.stamps = op->stamps;
-    const bool use_evec = !op->ceed->atomic_scatter;
-    if (use_evec) {  // atomic-free, deterministic scatter: element results -> E-vector -> per-node sums
-      CHK(rstr_build_csr(r));
-      CHK(op_need_node_flags(op, r));
-      CHK(ceed_need_evec(op->ceed, (size_t)r->nelem * r->ncomp * r->elemsize));
-      a.evec = op->ceed->evec;
-      if (!add && !r->csr_full_cover) HIPCHK(hipMemsetAsync(py, 0, sizeof(double) * (size_t)out->length, s));
-    } else if (!add) {
-      HIPCHK(hipMemsetAsync(py, 0, sizeof(double) * (size_t)out->length, s));
-    }
-    {
-      TimerScope ts(op, s);
-      hipError_t e = launch_fused_grad(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, a, s, &kname);
-      if (e == hipErrorInvalidValue && !*kname)
-        return ceed_error("no fused kernel instantiated for P=%d Q=%d QFunction %s", ai.basis->P1d, ai.basis->Q1d, qf->name.c_str());
-      HIPCHK(e);
-      if (use_evec)  // timed together with the fused kernel: the two launches ARE the operator apply
-        HIPCHK(launch_assemble(r->d_rowptr, r->d_cols, r->d_node_off, (op->mask_mode & 2) ? op->d_node_flags : nullptr,
-                               a.evec, py, r->csr_nnodes, r->elemsize, add ? 1 : 0, s));
-    }
-    op->launches++;
+  case PLAN_FUSED_GRAD:
+    CHK(apply_fused_grad(op, in, out, add, -1, &kname));
     break;
-  }
   case PLAN_SETUP_GEO: {
     OpField &x = op->in[0];
     if (!in || in->length < x.rstr->lsize) return ceed_error("coordinate vector too short");
@@ -1017,6 +1055,40 @@ extern "C" int CeedXOperatorGetTiming(CeedOperator op, double *ms, int64_t *laun
   }
   op->events.clear();
   *ms = op->ms_accum; *launches = op->launches;
+  return 0;
+}
+
+// Split-phase apply for communication overlap (the halo sum of matops.c:57 hidden under the interior
+// elements): the first `n_leading_elems` elements must be the ONLY contributors of the nodes flagged in
+// `priority` (one byte per L-vector entry, read at each node's first component).  Phase 0 computes those
+// elements and finishes the flagged nodes; phase 1 does the rest.  Phase 0 then 1 == CeedOperatorApply.
+extern "C" int CeedXOperatorSetOverlapSplit(CeedOperator op, CeedInt n_leading_elems, const unsigned char *priority,
+                                            CeedInt lsize) {
+  if (op->composite) return ceed_error("set the overlap split on the sub-operators");
+  CHK(op_plan(op));
+  if (op->plan != PLAN_FUSED_GRAD) return ceed_error("overlap split is provided for the residual / Jacobian operators");
+  CeedElemRestriction r = op->in[op->i_active].rstr;
+  op->ovl_csr.release();
+  if (op->d_node_flags_ovl) { (void)hipFree(op->d_node_flags_ovl); op->d_node_flags_ovl = nullptr; }
+  op->ovl_lead = 0;
+  if (!priority) return 0;
+  if (lsize < r->lsize || n_leading_elems < 0 || n_leading_elems > r->nelem) return ceed_error("bad overlap split arguments");
+  // check the contract: every contributor of a priority node is a leading element
+  const size_t es = (size_t)r->elemsize;
+  for (size_t i = 0; i < r->h_offsets.size(); i++)
+    if (priority[(size_t)r->h_offsets[i]] && i / es >= (size_t)n_leading_elems)
+      return ceed_error("element %zu touches a priority node but is not among the %d leading elements", i / es, n_leading_elems);
+  CHK(build_csr(r, op->ovl_csr, priority));
+  op->ovl_lead = n_leading_elems;
+  return 0;
+}
+extern "C" int CeedXOperatorApplyPhase(CeedOperator op, CeedVector in, CeedVector out, int phase) {
+  if (op->composite) return ceed_error("split-phase apply of a composite operator is not supported");
+  CHK(op_plan(op));
+  if (op->plan != PLAN_FUSED_GRAD || (phase != 0 && phase != 1)) return ceed_error("bad split-phase apply");
+  const char *kname = "";
+  CHK(apply_fused_grad(op, in, out, false, phase, &kname));
+  op->kernel_name = kname;
   return 0;
 }
 

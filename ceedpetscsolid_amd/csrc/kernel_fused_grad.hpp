@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
 
   // All global loads are unconditional and in-bounds (indices clamped, results selected
   // afterwards): no exec-mask branches around loads, so a wave's loads issue back to back.
-  auto elem_of = [&](int g) { const int ee = g * EPW + el; return ee < a.nelem ? ee : a.nelem - 1; };
+  auto elem_of = [&](int g) { const int ee = g * EPW + el; return a.elem_begin + (ee < a.nelem ? ee : a.nelem - 1); };
   // q-point data lives in NSET register sets used round-robin by the point slots; a set is
   // refilled (for the slot NSET positions further down the element/slot stream) as soon as the
   // physics of its current slot is done, so every q-point load has a full element of work to hide under.
@@ -218,9 +218,9 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
 
   for (;; ) {
   CPS_STAMP();
-  const int e = grp * EPW + el;
-  const bool live = e < a.nelem;
-  const int ec = live ? e : a.nelem - 1;
+  const bool live = grp * EPW + el < a.nelem;
+  const int e = a.elem_begin + grp * EPW + el;
+  const int ec = live ? e : a.elem_begin + a.nelem - 1;
   const int grp_nx = grp + wper;
   const bool more = grp_nx < gend;                           // wave-uniform
   const int ec_nx = elem_of(more ? grp_nx : grp);

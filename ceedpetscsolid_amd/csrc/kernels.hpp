@@ -42,7 +42,8 @@ struct FusedGradArgs {
   const double *qdata;      // [nelem][10][Q^3]
   const double *state_in;   // [nelem][9][Q^3] or null
   double *state_out;        // [nelem][9][Q^3] or null
-  int nelem;
+  int nelem;                // elements processed by this launch ...
+  int elem_begin;           // ... starting at this element (split-phase apply)
   int mask_in, mask_out;    // honour the Dirichlet flags on gather / scatter
   double nu, E, lambda, TwoMu;
   unsigned long long *stamps;  // diagnostic builds only (-DCPS_STAMPS): 8 s_memtime stamps per wave

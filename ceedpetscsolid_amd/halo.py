@@ -93,6 +93,37 @@ class HaloExchange:
         for n in self.neigh:
             y.index_add_(0, n.dof_idx, n.recv.to(y.device) if self.stage_host else n.recv)
 
+    # -- split form for communication overlap: start() after the interface nodes are complete
+    # (CeedXOperatorApplyPhase 0), finish() after the interior work has been queued -----------------
+    def start(self, y: torch.Tensor):
+        self._works = []
+        if not self.neigh:
+            return
+        ops = []
+        for n in self.neigh:
+            if self.stage_host:
+                n.send.copy_(torch.index_select(y, 0, n.dof_idx))
+            else:
+                torch.index_select(y, 0, n.dof_idx, out=n.send)
+        for n in self.neigh:
+            ops.append(dist.P2POp(dist.isend, n.send, n.rank, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, n.recv, n.rank, group=self.group))
+        self._works = dist.batch_isend_irecv(ops)
+
+    def finish(self, y: torch.Tensor):
+        for w in getattr(self, "_works", []):
+            w.wait()
+        for n in self.neigh:
+            y.index_add_(0, n.dof_idx, n.recv.to(y.device) if self.stage_host else n.recv)
+        self._works = []
+
+    def interface_dof_mask(self) -> np.ndarray:
+        """uint8 mask over the L-vector: 1 on every dof shared with another rank."""
+        m = np.zeros(self.dm.lsize, dtype=np.uint8)
+        for n in self.neigh:
+            m[n.dof_idx.cpu().numpy()] = 1
+        return m
+
     def global_count(self, local_mask_free: np.ndarray) -> int:
         """Number of distinct unconstrained dofs over all ranks (the reference's Ugsz)."""
         mine = float((local_mask_free * self.owner_weight).sum())
@@ -108,6 +139,31 @@ class HaloExchange:
         if self.world > 1:
             dist.all_reduce(s, group=self.group)
         return float(s.item())
+
+
+def interface_elements(mesh: HexMesh, group=None) -> np.ndarray:
+    """bool per element: True if the element has a vertex that another rank also holds (its nodes may
+    need the halo sum).  Collective; uses global vertex ids only."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return np.zeros(mesh.nelem, dtype=bool)
+    g = mesh.gid()
+    # boundary vertices of the local mesh: on a face owned by a single local element
+    gc = g[mesh.cells]
+    faces = []
+    for f in range(6):
+        axis, side = f // 2, f % 2
+        cs = [c for c in range(8) if ((c >> axis) & 1) == side]
+        faces.append(gc[:, cs])
+    allf = np.concatenate(faces, axis=0)
+    _, inv, cnt = np.unique(np.sort(allf, axis=1), axis=0, return_inverse=True, return_counts=True)
+    bverts = np.unique(allf[cnt[inv] == 1])
+    gathered: List[Optional[np.ndarray]] = [None] * dist.get_world_size(group)
+    dist.all_gather_object(gathered, bverts, group=group)
+    me = dist.get_rank(group)
+    others = np.unique(np.concatenate([v for r, v in enumerate(gathered) if r != me] or [np.zeros(0, dtype=np.int64)]))
+    shared = np.intersect1d(bverts, others)
+    vmask = np.isin(g, shared)
+    return vmask[mesh.cells].any(axis=1)
 
 
 def slab_cylinder(rank: int, world: int, nr: int, nth: int, nz: int, height_per_rank: float = 10.0) -> HexMesh:

@@ -406,6 +406,16 @@ def submesh(mesh: HexMesh, elems: np.ndarray) -> HexMesh:
                    vertex_gid=mesh.gid()[used], name=mesh.name + f"[{elems.size}e]")
 
 
+def reorder_elements_first(mesh: HexMesh, first: np.ndarray) -> HexMesh:
+    """Same mesh with the elements flagged in ``first`` (bool per element) moved to the front, order
+    otherwise preserved (split-phase apply: interface-touching elements lead)."""
+    first = np.asarray(first, dtype=bool)
+    perm = np.concatenate([np.nonzero(first)[0], np.nonzero(~first)[0]])
+    inv = np.empty_like(perm); inv[perm] = np.arange(perm.size)
+    ss = {sid: np.stack([inv[fs[:, 0]], fs[:, 1]], axis=1) if len(fs) else fs for sid, fs in mesh.side_sets.items()}
+    return HexMesh(mesh.coords, mesh.cells[perm], ss, vertex_gid=mesh.vertex_gid, name=mesh.name + "[reordered]")
+
+
 def key_bytes(keys: np.ndarray) -> np.ndarray:
     """Topological keys as fixed-size byte strings (hashable / sortable across ranks)."""
     k = np.ascontiguousarray(keys, dtype=np.int64)

@@ -247,6 +247,16 @@ CEED_EXTERN int CeedXOperatorSetDirichletMaskMode(CeedOperator op,
 /* into the fine scatter (Prolong_Ceed, matops.c:149) or gather               */
 /* (Restrict_Ceed, matops.c:176).  NULL / CEED_VECTOR_NONE clears.            */
 CEED_EXTERN int CeedXOperatorSetFineScale(CeedOperator op, CeedVector scale);
+/* Split-phase apply, to hide the inter-GPU halo sum (the DMLocalToGlobal(ADD)  */
+/* of matops.c:57) under the interior elements.  The first n_leading_elems      */
+/* elements must be the only contributors of the L-vector nodes flagged in      */
+/* `priority` (one byte per L-vector entry; all components of a node alike).    */
+/* Phase 0 computes those elements and completes the flagged nodes, phase 1 the  */
+/* rest; phase 0 followed by phase 1 equals CeedOperatorApply.  NULL clears.     */
+CEED_EXTERN int CeedXOperatorSetOverlapSplit(CeedOperator op,
+    CeedInt n_leading_elems, const unsigned char *priority, CeedInt lsize);
+CEED_EXTERN int CeedXOperatorApplyPhase(CeedOperator op, CeedVector in,
+                                        CeedVector out, int phase);
 /* Stand-ins for the PETSc Vec calls of src/matops.c / src/misc.c on backend   */
 /* memory: w = x .* y (VecPointwiseMult), y = a x + b y, weighted dot.        */
 CEED_EXTERN int CeedXVectorPointwiseMult(CeedVector w, CeedVector x,

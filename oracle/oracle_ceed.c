@@ -133,6 +133,8 @@ struct CeedOperator_private {
   CeedInt       mask_in_len, mask_out_len;
   int           mask_mode;
   CeedVector    scale;
+  unsigned char *priority;   /* split-phase apply (CeedXOperatorSetOverlapSplit) */
+  CeedInt       priority_len;
 };
 
 /* Sentinels: distinct addresses that are never dereferenced. */
@@ -724,7 +726,7 @@ int CeedOperatorDestroy(CeedOperator *op) {
     }
     CeedQFunction q = o->qf; CeedQFunctionDestroy(&q);
   }
-  free(o->mask_in); free(o->mask_out);
+  free(o->mask_in); free(o->mask_out); free(o->priority);
   CeedVectorDestroy(&o->scale);
   ceed_unref(o->ceed);
   free(o);
@@ -1035,6 +1037,31 @@ int CeedXOperatorSetDirichletMaskMode(CeedOperator op, CeedMemType mtype, const 
 }
 int CeedXOperatorSetDirichletMask(CeedOperator op, CeedMemType mtype, const unsigned char *mask, CeedInt lsize) {
   return CeedXOperatorSetDirichletMaskMode(op, mtype, mask, lsize, NULL, 0, 3);
+}
+/* Split-phase apply restated on the host: both phases evaluate the whole operator; phase 0 keeps
+ * the priority entries (others zero), phase 1 fills in the remaining entries. */
+int CeedXOperatorSetOverlapSplit(CeedOperator op, CeedInt n_leading_elems, const unsigned char *priority, CeedInt lsize) {
+  (void)n_leading_elems;
+  free(op->priority); op->priority = NULL; op->priority_len = 0;
+  if (priority) {
+    op->priority = malloc((size_t)lsize + 1); memcpy(op->priority, priority, (size_t)lsize);
+    op->priority_len = lsize;
+  }
+  return 0;
+}
+int CeedXOperatorApplyPhase(CeedOperator op, CeedVector in, CeedVector out, int phase) {
+  if (!op->priority) return oracle_error("CeedXOperatorSetOverlapSplit was not called");
+  CeedVector tmp;
+  vec_ensure(out);
+  CHK(CeedVectorCreate(op->ceed, out->length, &tmp));
+  CHK(CeedOperatorApply(op, in, tmp, CEED_REQUEST_IMMEDIATE));
+  for (CeedInt i = 0; i < out->length; i++) {
+    const int pr = i < op->priority_len && op->priority[i];
+    if (phase == 0) out->array[i] = pr ? tmp->array[i] : 0.;
+    else if (!pr) out->array[i] = tmp->array[i];
+  }
+  CeedVectorDestroy(&tmp);
+  return 0;
 }
 int CeedXOperatorSetFineScale(CeedOperator op, CeedVector scale) {
   CeedVectorDestroy(&op->scale);

@@ -46,6 +46,10 @@ CASES = [  # (mesh factory, degree, problem, bc)
     ("cyl p4 ss", lambda: hollow_cylinder_mesh(2, 8, 3), 4, "hyperSS", dict(bc_sides=[998])),
     ("box p6 fs", lambda: distorted_box(2, 2, 2), 6, "hyperFS", dict(bc_sides=[1])),              # config 5 shape
     ("ragged", lambda: distorted_box(5, 1, 1), 4, "hyperFS", dict()),   # nelem not a multiple of the block's elements; no BC
+    ("ragged p2", lambda: distorted_box(3, 1, 1), 2, "hyperSS", dict(bc_sides=[6])),   # Q=3: two elements per wave, 3 elements
+    ("ragged p1", lambda: distorted_box(3, 1, 1), 1, "hyperFS", dict(bc_sides=[6])),   # Q=2: eight elements per wave, 3 elements
+    ("single element", lambda: distorted_box(1, 1, 1), 3, "hyperFS", dict()),
+    ("uniform ladder", lambda: distorted_box(2, 2, 2), 4, "linElas", dict(bc_sides=[1], multigrid="uniform")),  # P = 2,3,4,5 at Q = 5
 ]
 
 
@@ -209,3 +213,38 @@ def test_unsupported_graphs_fail_loudly(gpu):
     b = gpu.basis_lagrange(3, 3, 3, 3, cd.GAUSS)
     with pytest.raises(cd.CeedError):
         b.apply(1, cd.NOTRANSPOSE, cd.EVAL_INTERP, gpu.vector(81), gpu.vector(81))
+
+
+def test_split_phase_apply_equals_full_apply(gpu):
+    """CeedXOperatorApplyPhase 0 then 1 == CeedOperatorApply (communication-overlap form, used at N > 1)."""
+    from ceedpetscsolid_amd.mesh import build_dofmap, reorder_elements_first
+    mesh = distorted_box(4, 4, 4)
+    zc = mesh.coords[mesh.cells][:, :, 2]
+    lead = (zc.min(axis=1) < 0.5 + 1e-9) & (zc.max(axis=1) > 0.5 - 1e-9)       # elements touching the plane z = 0.5
+    lead_far = np.abs(mesh.coords[mesh.cells][:, :, 2] - 0.5).min(axis=1) < 0.2  # (distortion tolerance)
+    mesh = reorder_elements_first(mesh, lead_far)
+    p = SolidProblem(gpu, mesh, 3, "hyperFS", nu=0.3, E=1.0, bc_sides=[1], multigrid="none")
+    lv = p.levels[p.fine]
+    n = p.lsize()
+    # priority nodes: every node all of whose elements are leading elements and that lies near the plane
+    nlead = int(lead_far.sum())
+    touched_by_rest = np.zeros(lv.dofmap.nnodes, dtype=bool)
+    touched_by_rest[lv.dofmap.elem_nodes[nlead:].ravel()] = True
+    near = np.abs(lv.dofmap.node_coords[:, 2] - 0.5) < 0.05
+    prio_nodes = near & ~touched_by_rest
+    assert prio_nodes.sum() > 0
+    prio = np.repeat(prio_nodes.astype(np.uint8), 3)
+    X, Y, Y2 = gpu.vector(n), gpu.vector(n), gpu.vector(n)
+    X.set_array(p.smooth_state(0.1)); p.form_residual(X, Y)
+    X.set_array(np.random.default_rng(2).uniform(-1, 1, n))
+    p.apply_jacobian(p.fine, X, Y)
+    op = lv.opJacob
+    op.set_overlap_split(nlead, prio)
+    Y2.set_value(7.0)
+    op.apply_phase(X, Y2, 0)
+    y0 = Y2.to_numpy()
+    assert np.array_equal(y0[prio == 1], Y.to_numpy()[prio == 1])               # interface nodes complete after phase 0
+    op.apply_phase(X, Y2, 1)
+    assert np.array_equal(Y2.to_numpy(), Y.to_numpy())                          # deterministic scatter: bitwise
+    with pytest.raises(cd.CeedError):                                            # contract check
+        op.set_overlap_split(1, prio)
