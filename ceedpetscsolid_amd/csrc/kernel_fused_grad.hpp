@@ -46,7 +46,13 @@ template <int P, int Q> struct WaveGeom {
   static constexpr int Q3 = Q * Q * Q;
   static constexpr int TPE = Q3 <= 32 ? next_pow2(Q3) : ((Q3 + 63) / 64) * 64;  // point slots per element
   static constexpr int EPW = TPE >= 64 ? 1 : 64 / TPE;                           // elements per wave
-  static constexpr int SLOTS = TPE >= 64 ? TPE / 64 : 1;                         // point slots per lane
+  // Waves per element.  One wave owns its element(s) outright up to Q = 5 (2 point slots per lane at
+  // Q = 5).  From Q = 6 the LDS slab (47 KB at Q = 7) would leave 3 single-wave workgroups per CU, so
+  // TPE/128 waves share an element -- always 2 point slots per lane -- with a raw s_barrier behind an
+  // LDS-only wait at the phase boundaries: Q = 6: 2 waves, Q = 7: 3 (6 waves per CU), Q = 8: 4.
+  static constexpr int WPE = TPE >= 256 ? TPE / 128 : 1;
+  static constexpr int NT = 64 * WPE;                                            // lanes per workgroup
+  static constexpr int SLOTS = TPE >= NT ? TPE / NT : 1;                         // point slots per lane
   static constexpr int LD = pad2(Q), LDP = pad2(P);                              // padded row lengths
   static constexpr int BLK = 3 * Q * Q * LD;                                     // one 3-component block
   static constexpr int SLAB = 5 * BLK;                                           // doubles of LDS per element
@@ -58,9 +64,17 @@ template <int P, int Q> struct WaveGeom {
 // A wavefront-scope fence does exactly that and emits no instruction; in particular it
 // does not drain vmcnt, so the q-point loads issued at kernel entry stay in flight across
 // the whole interpolation.
+// With two waves per element (WPE = 2) the boundary is a raw s_barrier behind an LDS-only wait:
+// __syncthreads() would also drain vmcnt and with it the q-point prefetch.
+template <int WPE>
 CPS_DEV void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  if constexpr (WPE > 1) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __builtin_amdgcn_wave_barrier();
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
@@ -88,8 +102,9 @@ CPS_DEV void row_load(const double *row, double *r) {
 }
 
 template <int P, int Q, int QF>
-__global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const FusedGradArgs a) {
+__global__ __launch_bounds__((WaveGeom<P, Q>::NT)) void k_fused_grad(const BasisTables tab, const FusedGradArgs a) {
   using G = WaveGeom<P, Q>;
+  constexpr int NT = G::NT, WPE = G::WPE;
   constexpr int Q3 = G::Q3, P3 = P * P * P, TPE = G::TPE, EPW = G::EPW, SLOTS = G::SLOTS;
   constexpr int LD = G::LD, LDP = G::LDP, BLK = G::BLK;
   constexpr bool ST_IN = QFTraits<QF>::state_in, ST_OUT = QFTraits<QF>::state_out;
@@ -111,18 +126,18 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
 #endif
   const int lane = threadIdx.x;
   const int el = EPW > 1 ? lane / TPE : 0;
-  const int q0 = EPW > 1 ? lane % TPE : lane;  // slot s handles point q0 + 64 s
+  const int q0 = EPW > 1 ? lane % TPE : lane;  // slot s handles point q0 + NT s
   // five 3-component blocks, reused along the pipeline (who is dead when is noted at each phase)
   double *B0 = slab[el], *B1 = B0 + BLK, *B2 = B0 + 2 * BLK, *B3 = B0 + 3 * BLK, *B4 = B0 + 4 * BLK;
 
   // coefficient tables: staged once per wave, reused for every element it processes
-  for (int i = lane; i < Q * P; i += 64) {
+  for (int i = lane; i < Q * P; i += NT) {
     const int qq = i / P, pp = i % P;
     sB[qq * LDP + pp] = tab.interp[i];
     sG[qq * LDP + pp] = tab.grad[i];
     sBt[pp * LD + qq] = tab.interp[i];
   }
-  for (int i = lane; i < Q * Q; i += 64) {
+  for (int i = lane; i < Q * Q; i += NT) {
     const int qq = i / Q, mm = i % Q;
     sD[qq * LD + mm] = tab.colo[i];
     sDt[mm * LD + qq] = tab.colo[i];
@@ -164,7 +179,7 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   auto load_offsets = [&](int ec, uint32_t *o) {
 #pragma unroll
     for (int s = 0; s < SLOTS; s++) {
-      const int n = q0 + 64 * s;
+      const int n = q0 + NT * s;
       o[s] = a.offsets[(size_t)ec * P3 + (n < P3 ? n : P3 - 1)];
     }
   };
@@ -192,7 +207,7 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   } ix[SLOTS];
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
-    const int q = q0 + 64 * s;
+    const int q = q0 + NT * s;
     SlotIdx &I = ix[s];
     { const int i = q % P, kj = q / P; I.g_w = kj * LDP + i; I.xt_r = kj * LD; I.xt_c = i * LD; }
     { const int i = q % Q, kj = q / Q, j = kj % P, k = kj / P;
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   load_offsets(elem_of(grp), off);
   load_x(off, xin);
 #pragma unroll
-  for (int t = 0; t < NSET; t++) load_point(qd[t], st[t], elem_of(grp), q0 + 64 * t);
+  for (int t = 0; t < NSET; t++) load_point(qd[t], st[t], elem_of(grp), q0 + NT * t);
 
   for (;; ) {
   CPS_STAMP();
@@ -229,21 +244,21 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   // XA = B0: [c][k][j][i], i fastest (row length LDP)
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
-    const int n = q0 + 64 * s;
+    const int n = q0 + NT * s;
     if (n < P3) {
       const uint32_t fl = (a.mask_in && live) ? (off[s] >> OFF_FLAG_SHIFT) : (live ? 0u : 7u);
 #pragma unroll
       for (int c = 0; c < 3; c++) B0[c * CPP + ix[s].g_w] = ((fl >> c) & 1u) ? 0. : xin[s][c];
     }
   }
-  wave_sync();
+  wave_sync<WPE>();
   CPS_STAMP();  // 1: gather landed in LDS
 
   // ---- B: nodes -> points ------------------------------------------------------------------
   // x: XA[c][k][j][:] -> RB = B1: [c][k][i'][j], j fastest
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
-    const int q = q0 + 64 * s;
+    const int q = q0 + NT * s;
     if (q < P * P * Q) {
       double b[P];
       row_load<P>(sB + ix[s].x_c, b);
@@ -251,11 +266,11 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
       for (int c = 0; c < 3; c++) B1[c * CPQ + ix[s].x_w] = row_dot<P>(b, B0 + c * CPP + ix[s].x_r);
     }
   }
-  wave_sync();
+  wave_sync<WPE>();
   // y: RB[c][k][i'][:] -> RC = B2: [c][j'][i'][k], k fastest
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
-    const int q = q0 + 64 * s;
+    const int q = q0 + NT * s;
     if (q < P * Q * Q) {
       double b[P];
       row_load<P>(sB + ix[s].y_c, b);
@@ -263,13 +278,13 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
       for (int c = 0; c < 3; c++) B2[c * CQQ + ix[s].y_w] = row_dot<P>(b, B1 + c * CPQ + ix[s].y_r);
     }
   }
-  wave_sync();
+  wave_sync<WPE>();
   // z: RC[c][j'][i'][:] -> U and, from the same row, dU/dz (grad1d row).  U is stored twice:
   // UX = B0 [c][k'][j'][i'] (i fastest) and UY = B1 [c][k'][i'][j'] (j fastest).
   double uz[SLOTS][3];
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
-    const int q = q0 + 64 * s;
+    const int q = q0 + NT * s;
     if (q < Q3) {
       double b[P], g[P];
       row_load<P>(sB + ix[s].z_c, b);
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
       }
     }
   }
-  wave_sync();
+  wave_sync<WPE>();
   CPS_STAMP();  // 2: interpolated
   load_x(off_nx, xin);                                       // next element's x (its offsets have landed)
 
@@ -295,7 +310,7 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   // reads UX = B0, UY = B1; writes GX = B2 (i fastest), GY = B3 (j fastest), GZ = B4 (k fastest)
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
-    const int q = q0 + 64 * s;
+    const int q = q0 + NT * s;
     double ug[9], dv[9], sto[9];
     if (q < Q3) {
       double d0[Q], d1[Q];
@@ -319,8 +334,8 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
 #pragma unroll
       for (int c = 0; c < 9; c++) dv[c] = 0.;
     }
-    if (s + NSET < SLOTS) load_point(qd[s % NSET], st[s % NSET], ec, q + 64 * NSET);       // same element, NSET slots on
-    else load_point(qd[s % NSET], st[s % NSET], ec_nx, q0 + 64 * (s + NSET - SLOTS));      // next element
+    if (s + NSET < SLOTS) load_point(qd[s % NSET], st[s % NSET], ec, q + NT * NSET);       // same element, NSET slots on
+    else load_point(qd[s % NSET], st[s % NSET], ec_nx, q0 + NT * (s + NSET - SLOTS));      // next element
     if (q < Q3) {
 #pragma unroll
       for (int c = 0; c < 3; c++) {
@@ -330,13 +345,13 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
       }
     }
   }
-  wave_sync();
+  wave_sync<WPE>();
   CPS_STAMP();  // 3: physics done
 
   // ---- gradient^T: GX, GY, GZ -> WZ = B0 [c][j][i][k], k fastest (UX is dead) -----------------
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
-    const int q = q0 + 64 * s;
+    const int q = q0 + NT * s;
     if (q < Q3) {
       double d0[Q], d1[Q], d2[Q];
       row_load<Q>(sDt + ix[s].qi * LD, d0);
@@ -350,14 +365,14 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
       }
     }
   }
-  wave_sync();
+  wave_sync<WPE>();
   CPS_STAMP();  // 4: gradient^T done
 
   // ---- B^T: points -> nodes, then scatter-add -----------------------------------------------
   // z^T: WZ[c][j'][i'][:] -> TY = B1 [c][k][i'][j'], j fastest (UY is dead)
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
-    const int q = q0 + 64 * s;
+    const int q = q0 + NT * s;
     if (q < P * Q * Q) {
       double b[Q];
       row_load<Q>(sBt + ix[s].zt_c, b);
@@ -365,11 +380,11 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
       for (int c = 0; c < 3; c++) B1[c * DPQ + ix[s].zt_w] = row_dot<Q>(b, B0 + c * DQQ + ix[s].zt_r);
     }
   }
-  wave_sync();
+  wave_sync<WPE>();
   // y^T: TY[c][k][i'][:] -> TX = B2 [c][k][j][i'], i fastest (GX is dead)
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
-    const int q = q0 + 64 * s;
+    const int q = q0 + NT * s;
     if (q < P * P * Q) {
       double b[Q];
       row_load<Q>(sBt + ix[s].yt_c, b);
@@ -377,11 +392,11 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
       for (int c = 0; c < 3; c++) B2[c * DPP + ix[s].yt_w] = row_dot<Q>(b, B1 + c * DPQ + ix[s].yt_r);
     }
   }
-  wave_sync();
+  wave_sync<WPE>();
   // x^T + scatter
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
-    const int n = q0 + 64 * s;
+    const int n = q0 + NT * s;
     if (live && n < P3) {
       double b[Q];
       row_load<Q>(sBt + ix[s].xt_c, b);
@@ -415,7 +430,7 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
   grp = grp_nx;
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) off[s] = off_nx[s];
-  wave_sync();  // WAR: the next element's gather overwrites B0, which x^T's source B2 does not alias
+  wave_sync<WPE>();  // WAR: the next element's gather overwrites B0, which x^T's source B2 does not alias
   }  // element loop
 }
 
@@ -423,8 +438,9 @@ __global__ __launch_bounds__(64) void k_fused_grad(const BasisTables tab, const 
 template <int P, int Q> constexpr int fused_waves_per_cu() {
   using G = WaveGeom<P, Q>;
   constexpr int lds = (G::EPW * G::SLAB + 2 * Q * G::LDP + P * G::LD + 2 * Q * G::LD) * 8;
-  constexpr int by_lds = (160 * 1024) / lds;
-  return by_lds < 1 ? 1 : (by_lds > 8 ? 8 : by_lds);   // 8 = 2 waves per SIMD at <= 256 VGPRs
+  constexpr int by_lds = (160 * 1024) / lds;          // workgroups per CU by LDS
+  constexpr int by_vgpr = 8 / G::WPE;                 // 8 waves per CU = 2 per SIMD at <= 256 VGPRs
+  return by_lds < 1 ? 1 : (by_lds > by_vgpr ? by_vgpr : by_lds);
 }
 
 template <int P, int Q, int QF>
@@ -441,7 +457,7 @@ hipError_t launch_fused_grad_t(const BasisTables &t, const FusedGradArgs &a, hip
   }
   int grid = ncu * fused_waves_per_cu<P, Q>();   // persistent: a multiple of 8 on MI355X (256 CUs)
   if (grid > ngroups) grid = ngroups;
-  hipLaunchKernelGGL((k_fused_grad<P, Q, QF>), dim3(grid), dim3(64), 0, s, t, a);
+  hipLaunchKernelGGL((k_fused_grad<P, Q, QF>), dim3(grid), dim3(G::NT), 0, s, t, a);
   return hipGetLastError();
 }
 
