@@ -50,7 +50,10 @@ template <int P, int Q> struct WaveGeom {
   // Q = 5).  From Q = 6 the LDS slab (47 KB at Q = 7) would leave 3 single-wave workgroups per CU, so
   // TPE/128 waves share an element -- always 2 point slots per lane -- with a raw s_barrier behind an
   // LDS-only wait at the phase boundaries: Q = 6: 2 waves, Q = 7: 3 (6 waves per CU), Q = 8: 4.
-  static constexpr int WPE = TPE >= 256 ? TPE / 128 : 1;
+#ifndef CPS_WPE_128   // waves per element when the element has exactly 128 point slots (Q = 5)
+#define CPS_WPE_128 1
+#endif
+  static constexpr int WPE = TPE >= 256 ? TPE / 128 : (TPE == 128 ? CPS_WPE_128 : 1);
   static constexpr int NT = 64 * WPE;                                            // lanes per workgroup
   static constexpr int SLOTS = TPE >= NT ? TPE / NT : 1;                         // point slots per lane
   static constexpr int LD = pad2(Q), LDP = pad2(P);                              // padded row lengths
@@ -101,8 +104,11 @@ CPS_DEV void row_load(const double *row, double *r) {
   if (N & 1) r[N - 1] = row[N - 1];
 }
 
+#ifndef CPS_FUSED_MINW
+#define CPS_FUSED_MINW 1
+#endif
 template <int P, int Q, int QF>
-__global__ __launch_bounds__((WaveGeom<P, Q>::NT)) void k_fused_grad(const BasisTables tab, const FusedGradArgs a) {
+__global__ __launch_bounds__((WaveGeom<P, Q>::NT), CPS_FUSED_MINW) void k_fused_grad(const BasisTables tab, const FusedGradArgs a) {
   using G = WaveGeom<P, Q>;
   constexpr int NT = G::NT, WPE = G::WPE;
   constexpr int Q3 = G::Q3, P3 = P * P * P, TPE = G::TPE, EPW = G::EPW, SLOTS = G::SLOTS;
