@@ -76,6 +76,7 @@ class Vec:
 class NewtonPMG:
     def __init__(self, prob: SolidProblem, clamp: Optional[Dict[int, dict]] = None, mms: bool = False,
                  halo=None, smooth_its: int = 3, coarse_rtol: float = 1e-3, coarse_maxit: int = 200,
+                 coarse: str = "cg", coarse_cheb_its: int = 40, coarse_cheb_ratio: float = 100.0,
                  ksp_rtol: float = 1e-10, snes_rtol: float = 1e-8, snes_maxit: int = 50, verbose: bool = False):
         """``clamp``: {side_set_id: dict(translate=(..), axis=(..), angle_over_pi=..)} as
         -bc_clamp_<id>_translate / _rotate (cloptions.c:86-131); ids present in the problem's Dirichlet
@@ -83,6 +84,10 @@ class NewtonPMG:
         self.p, self.ceed, self.L = prob, prob.ceed, prob.ceed.L
         self.clamp, self.mms, self.halo = clamp or {}, mms, halo
         self.smooth_its, self.coarse_rtol, self.coarse_maxit = smooth_its, coarse_rtol, coarse_maxit
+        # coarse solver: "cg" (Jacobi-PCG to coarse_rtol: accurate, but two host-synchronised dots per
+        # iteration) or "chebyshev" (fixed polynomial over [emax/ratio, 1.1 emax]: no reductions, no host
+        # sync, a fixed linear operator; the few lowest modes are left to the outer Krylov method)
+        self.coarse, self.coarse_cheb_its, self.coarse_cheb_ratio = coarse, coarse_cheb_its, coarse_cheb_ratio
         self.ksp_rtol, self.snes_rtol, self.snes_maxit, self.verbose = ksp_rtol, snes_rtol, snes_maxit, verbose
         self.nlev = len(prob.levels)
         c = self.ceed
@@ -181,10 +186,10 @@ class NewtonPMG:
                 self.axpby(w["x"], 1.0 / lam, w["t"], 0.0)
             self.emax[lv] = lam
 
-    def chebyshev(self, lv, b, x, its, zero_guess):
+    def chebyshev(self, lv, b, x, its, zero_guess, lmin_frac=0.1):
         """Chebyshev iteration on D^-1 A with bounds [0.1, 1.1] x emax (KSPChebyshevEstEigSet(0,0.1,0,1.1))."""
         w = self.w[lv]
-        lmin, lmax = 0.1 * self.emax[lv], 1.1 * self.emax[lv]
+        lmin, lmax = lmin_frac * self.emax[lv], 1.1 * self.emax[lv]
         theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
         sigma = theta / delta
         rho = 1.0 / sigma
@@ -235,6 +240,9 @@ class NewtonPMG:
         if lv == 0:
             if self.nlev == 1:
                 self.chebyshev(0, b, x, self.smooth_its, True)
+            elif self.coarse == "chebyshev":
+                self.chebyshev(0, b, x, self.coarse_cheb_its, True, 1.0 / self.coarse_cheb_ratio)
+                self.stats.coarse_its += self.coarse_cheb_its
             else:
                 self.coarse_solve(b, x)
             return

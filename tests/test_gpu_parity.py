@@ -248,3 +248,42 @@ def test_split_phase_apply_equals_full_apply(gpu):
     assert np.array_equal(Y2.to_numpy(), Y.to_numpy())                          # deterministic scatter: bitwise
     with pytest.raises(cd.CeedError):                                            # contract check
         op.set_overlap_split(1, prio)
+
+
+def test_apply_is_bitwise_reproducible(gpu):
+    """The E-vector + k_assemble scatter sums each node's contributors in a fixed (element) order:
+    repeated applies are bitwise identical (f64 atomics would not be)."""
+    mesh = hollow_cylinder_mesh(3, 12, 6)
+    p = SolidProblem(gpu, mesh, 4, "hyperFS", nu=0.3, E=1.0, bc_sides=[998, 999], multigrid="none")
+    n = p.lsize()
+    X, Y = gpu.vector(n), gpu.vector(n)
+    X.set_array(p.smooth_state(0.1)); p.form_residual(X, Y)
+    r0 = Y.to_numpy()
+    X.set_array(np.random.default_rng(4).uniform(-1, 1, n))
+    outs = []
+    for _ in range(4):
+        p.apply_jacobian(p.fine, X, Y)
+        outs.append(Y.to_numpy())
+    assert all(np.array_equal(o, outs[0]) for o in outs[1:])
+    X.set_array(p.smooth_state(0.1)); p.form_residual(X, Y)
+    assert np.array_equal(Y.to_numpy(), r0)
+
+
+def test_apply_add_and_empty_vectors(gpu):
+    """CeedOperatorApplyAdd accumulates (y += J x); zero-length vectors are legal objects."""
+    import ctypes as C
+    mesh = distorted_box(2, 2, 1)
+    p = SolidProblem(gpu, mesh, 2, "linElas", nu=0.3, E=1.0, bc_sides=[1], multigrid="none")
+    n = p.lsize()
+    x = np.random.default_rng(9).uniform(-1, 1, n)
+    X, Y = gpu.vector(n).set_array(x), gpu.vector(n)
+    p.apply_jacobian(p.fine, X, Y)
+    jx = Y.to_numpy()
+    y0 = np.random.default_rng(10).uniform(-1, 1, n)
+    Y.set_array(y0)
+    L = gpu.L
+    op = p.levels[p.fine].opJacob
+    L.chk(L.lib.CeedOperatorApplyAdd(op.h, X.h, Y.h, C.c_void_p(L.REQUEST_IMMEDIATE)))
+    assert rel_err(Y.to_numpy(), y0 + jx) < 1e-14
+    e = gpu.vector(0)
+    assert e.to_numpy().size == 0
