@@ -24,6 +24,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# A threaded host BLAS leaves its worker pool (one thread per core of the HOST, not of this job's CPU
+# share) spinning for ~0.1 s after every call; under a cgroup CPU quota that throttles the whole
+# process, including the thread that launches and waits for the device.  Nothing here needs host BLAS.
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+os.environ.setdefault("MKL_NUM_THREADS", "1")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -65,7 +65,8 @@ class CeedLib:
         "CeedXOperatorGetKernelName", "CeedXOperatorSetDirichletMask",
         "CeedXOperatorSetTiming", "CeedXOperatorGetTiming", "CeedXOperatorSetDirichletMaskMode",
         "CeedXOperatorSetFineScale", "CeedXOperatorSetOverlapSplit", "CeedXOperatorApplyPhase",
-        "CeedXVectorPointwiseMult", "CeedXVectorAXPBY", "CeedXVectorDot",
+        "CeedXVectorPointwiseMult", "CeedXVectorAXPBY", "CeedXVectorDot", "CeedXVectorChebyshevUpdate",
+        "CeedXGraphBeginCapture", "CeedXGraphEndCapture", "CeedXGraphLaunch", "CeedXGraphDestroy",
     ]
     DATA = [
         "CeedMemTypes", "CEED_VECTOR_ACTIVE", "CEED_VECTOR_NONE", "CEED_ELEMRESTRICTION_NONE",
@@ -114,6 +115,19 @@ def _np_f64(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+class Graph:
+    def __init__(self, L, h):
+        self.L, self.h = L, h
+
+    def launch(self):
+        self.L.chk(self.L.lib.CeedXGraphLaunch(self.h))
+
+    def destroy(self):
+        if self.h:
+            self.L.lib.CeedXGraphDestroy(C.byref(self.h))
+            self.h = None
+
+
 class Ceed:
     def __init__(self, lib: CeedLib, resource: str):
         self.L = lib
@@ -137,6 +151,17 @@ class Ceed:
 
     def synchronize(self):
         self.L.chk(self.L.lib.CeedXSynchronize(self.h))
+
+    def capture(self, fn) -> "Graph":
+        """Record the device work `fn()` queues on this Ceed into a hipGraph (CeedXGraph*)."""
+        self.L.chk(self.L.lib.CeedXGraphBeginCapture(self.h))
+        try:
+            fn()
+        finally:
+            g = C.c_void_p()
+            rc = self.L.lib.CeedXGraphEndCapture(self.h, C.byref(g))
+        self.L.chk(rc)
+        return Graph(self.L, g)
 
     def destroy(self):
         if self.h:

@@ -67,6 +67,16 @@ struct Ceed_private {
   size_t evec_len = 0;
   bool atomic_scatter = false;  // CEED_MI355X_SCATTER=atomic: f64 atomics instead of E-vector + assembly
   double *d_scalar = nullptr;   // device scalar for reductions
+  double *h_scalar = nullptr;   // pinned host landing slot for it (pageable targets make the runtime stage + pin per copy)
+  // hipGraph capture (CeedXGraphBeginCapture): device work is recorded on `capture_stream`
+  hipStream_t capture_stream = nullptr, saved_stream = nullptr;
+  bool capturing = false;
+};
+struct CeedXGraph_private {
+  Ceed ceed = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  size_t nodes = 0;
 };
 
 struct CeedVector_private {
@@ -204,7 +214,7 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   return 0;
 }
 static void ceed_ref(Ceed c) { c->refcount++; }
-static void ceed_unref(Ceed c) { if (--c->refcount == 0) { if (c->evec) (void)hipFree(c->evec); if (c->d_scalar) (void)hipFree(c->d_scalar); delete c; } }
+static void ceed_unref(Ceed c) { if (--c->refcount == 0) { if (c->capture_stream) (void)hipStreamDestroy(c->capture_stream); if (c->evec) (void)hipFree(c->evec); if (c->d_scalar) (void)hipFree(c->d_scalar); if (c->h_scalar) (void)hipHostFree(c->h_scalar); delete c; } }
 extern "C" int CeedDestroy(Ceed *ceed) {
   if (!ceed || !*ceed) return 0;
   ceed_unref(*ceed);
@@ -214,12 +224,67 @@ extern "C" int CeedDestroy(Ceed *ceed) {
 extern "C" int CeedGetResource(Ceed ceed, const char **resource) { *resource = ceed->resource.c_str(); return 0; }
 extern "C" int CeedGetPreferredMemType(Ceed, CeedMemType *type) { *type = CEED_MEM_DEVICE; return 0; }
 extern "C" int CeedXSetStream(Ceed ceed, void *s) { ceed->stream = (hipStream_t)s; return 0; }
-extern "C" int CeedXSynchronize(Ceed ceed) { HIPCHK(hipStreamSynchronize(ceed->stream)); return 0; }
+extern "C" int CeedXSynchronize(Ceed ceed) {
+  if (ceed->capturing) return ceed_error("CeedXSynchronize during graph capture");
+  HIPCHK(hipStreamSynchronize(ceed->stream));
+  return 0;
+}
+extern "C" int CeedXGraphBeginCapture(Ceed ceed) {
+  if (ceed->capturing) return ceed_error("graph capture already in progress");
+  HIPCHK(hipStreamSynchronize(ceed->stream));
+  if (!ceed->capture_stream) HIPCHK(hipStreamCreateWithFlags(&ceed->capture_stream, hipStreamNonBlocking));
+  ceed->saved_stream = ceed->stream;
+  ceed->stream = ceed->capture_stream;
+  HIPCHK(hipStreamBeginCapture(ceed->stream, hipStreamCaptureModeRelaxed));
+  ceed->capturing = true;
+  return 0;
+}
+extern "C" int CeedXGraphEndCapture(Ceed ceed, CeedXGraph *graph) {
+  if (!ceed->capturing) return ceed_error("no graph capture in progress");
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(ceed->stream, &g);
+  ceed->stream = ceed->saved_stream;
+  ceed->capturing = false;
+  if (e != hipSuccess || !g) return ceed_error("graph capture failed: %s", hipGetErrorString(e));
+  CeedXGraph G = new CeedXGraph_private;
+  G->ceed = ceed; G->graph = g;
+  (void)hipGraphGetNodes(g, nullptr, &G->nodes);
+  e = hipGraphInstantiate(&G->exec, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGraphDestroy(g); delete G; return ceed_error("hipGraphInstantiate: %s", hipGetErrorString(e)); }
+  ceed_ref(ceed);
+  *graph = G;
+  return 0;
+}
+extern "C" int CeedXGraphLaunch(CeedXGraph G) {
+  if (G->ceed->capturing) return ceed_error("CeedXGraphLaunch during graph capture");
+  HIPCHK(hipGraphLaunch(G->exec, G->ceed->stream));
+  return 0;
+}
+extern "C" int CeedXGraphDestroy(CeedXGraph *graph) {
+  if (!graph || !*graph) return 0;
+  CeedXGraph G = *graph;
+  (void)hipStreamSynchronize(G->ceed->stream);
+  if (G->exec) (void)hipGraphExecDestroy(G->exec);
+  if (G->graph) (void)hipGraphDestroy(G->graph);
+  ceed_unref(G->ceed);
+  delete G;
+  *graph = nullptr;
+  return 0;
+}
 
 // ---------------------------------------------------------------------------
 // CeedVector: host and device mirrors with validity flags
 // ---------------------------------------------------------------------------
 static size_t vbytes(CeedVector v) { return sizeof(double) * (size_t)(v->length > 0 ? v->length : 1); }
+// Zero `n` doubles on the Ceed's stream.  While a hipGraph is being recorded this is a fill KERNEL, not
+// hipMemsetAsync: on ROCm 7.2 a recorded memset node was observed to lose its ordering against the
+// neighbouring kernel nodes on replay (tools/graph_replay_check.py), kernel nodes do not.
+static int dev_zero(Ceed c, double *p, size_t n) {
+  if (!n) return 0;
+  if (c->capturing) HIPCHK(launch_set_value(p, n, 0.0, c->stream));
+  else HIPCHK(hipMemsetAsync(p, 0, sizeof(double) * n, c->stream));
+  return 0;
+}
 static int vec_need_host(CeedVector v) {
   if (!v->h) { v->h = (double *)calloc(vbytes(v), 1); v->h_owned = true; }
   return 0;
@@ -233,6 +298,7 @@ static int vec_sync_to(CeedVector v, CeedMemType m) {
   if (m == CEED_MEM_HOST) {
     CHK(vec_need_host(v));
     if (!v->h_valid && v->d_valid) {
+      if (v->ceed->capturing) return ceed_error("host access to a device vector during graph capture");
       HIPCHK(hipMemcpyAsync(v->h, v->d, sizeof(double) * (size_t)v->length, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
     }
@@ -240,10 +306,11 @@ static int vec_sync_to(CeedVector v, CeedMemType m) {
   } else {
     CHK(vec_need_dev(v));
     if (!v->d_valid && v->h_valid) {
+      if (v->ceed->capturing) return ceed_error("host-to-device vector upload during graph capture");
       HIPCHK(hipMemcpyAsync(v->d, v->h, sizeof(double) * (size_t)v->length, hipMemcpyHostToDevice, s));
       HIPCHK(hipStreamSynchronize(s));  // the host buffer may be reused by the caller
     } else if (!v->d_valid && !v->h_valid) {
-      HIPCHK(hipMemsetAsync(v->d, 0, vbytes(v), s));
+      CHK(dev_zero(v->ceed, v->d, (size_t)v->length));
     }
     v->d_valid = true;
   }
@@ -305,7 +372,7 @@ extern "C" int CeedVectorTakeArray(CeedVector v, CeedMemType mtype, CeedScalar *
 }
 extern "C" int CeedVectorSetValue(CeedVector v, CeedScalar value) {
   CHK(vec_need_dev(v));
-  if (value == 0.) HIPCHK(hipMemsetAsync(v->d, 0, vbytes(v), v->ceed->stream));
+  if (value == 0.) CHK(dev_zero(v->ceed, v->d, (size_t)v->length));
   else HIPCHK(launch_set_value(v->d, (size_t)v->length, value, v->ceed->stream));
   v->d_valid = true; v->h_valid = false;
   return 0;
@@ -878,9 +945,9 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
       if (phase == 0) { a.nelem = op->ovl_lead; nrows = M->nprio; }
       else { a.elem_begin = op->ovl_lead; a.nelem = r->nelem - op->ovl_lead; row0 = M->nprio; nrows = M->nnodes - M->nprio; }
     }
-    if (!add && !M->full_cover && phase <= 0) HIPCHK(hipMemsetAsync(py, 0, sizeof(double) * (size_t)out->length, s));
+    if (!add && !M->full_cover && phase <= 0) CHK(dev_zero(op->ceed, py, (size_t)out->length));
   } else if (!add) {
-    HIPCHK(hipMemsetAsync(py, 0, sizeof(double) * (size_t)out->length, s));
+    CHK(dev_zero(op->ceed, py, (size_t)out->length));
   }
   {
     TimerScope ts(op, s);
@@ -941,7 +1008,7 @@ static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool 
     a.off_f = pro ? (fout ? fout : rf->d_offsets) : (fin ? fin : rf->d_offsets);
     a.x = px; a.y = py; a.scale_f = psc; a.nelem = rc->nelem;
     a.mask_in = (op->mask_mode & 1) ? 1 : 0; a.mask_out = (op->mask_mode & 2) ? 1 : 0;
-    if (!add) HIPCHK(hipMemsetAsync(py, 0, sizeof(double) * (size_t)out->length, s));
+    if (!add) CHK(dev_zero(op->ceed, py, (size_t)out->length));
     TimerScope ts(op, s);
     hipError_t e = launch_transfer(b->P1d, b->Q1d, pro, op->tables, a, s, &kname);
     if (e == hipErrorInvalidValue && !*kname) return ceed_error("no transfer kernel for Pc=%d Pf=%d", b->P1d, b->Q1d);
@@ -985,7 +1052,7 @@ extern "C" int CeedOperatorLinearAssembleDiagonal(CeedOperator op, CeedVector as
   a.diag = pd; a.qdata = pq; a.state_in = ps; a.nelem = ai.rstr->nelem; a.mask_out = (op->mask_mode & 2) ? 1 : 0;
   CHK(read_phys(qf, &a.nu, &a.E));
   lame_constants(a.nu, a.E, &a.lambda, &a.TwoMu);
-  HIPCHK(hipMemsetAsync(pd, 0, sizeof(double) * (size_t)assembled->length, s));  // overwrite semantics (matops.c:227)
+  CHK(dev_zero(op->ceed, pd, (size_t)assembled->length));  // overwrite semantics (matops.c:227)
   const char *kname = "";
   hipError_t e = launch_diag(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, a, s, &kname);
   if (e == hipErrorInvalidValue && !*kname) return ceed_error("no diagonal kernel for P=%d Q=%d %s", ai.basis->P1d, ai.basis->Q1d, qf->name.c_str());
@@ -1108,16 +1175,31 @@ extern "C" int CeedXVectorAXPBY(CeedVector y, double a, CeedVector x, double b) 
   HIPCHK(launch_axpby(py, a, px, b, (size_t)y->length, y->ceed->stream));
   return 0;
 }
+extern "C" int CeedXVectorChebyshevUpdate(CeedVector x, CeedVector d, CeedVector r, CeedVector t, CeedVector dinv,
+                                          double c1, double c2, int assign_x) {
+  double *px, *pd, *pr, *pt = nullptr, *pi;
+  const CeedInt n = x->length;
+  if (d->length != n || r->length != n || dinv->length != n || (t && t != CEED_VECTOR_NONE && t->length != n))
+    return ceed_error("CeedXVectorChebyshevUpdate: vector lengths differ");
+  CHK(vec_dev(dinv, false, &pi));
+  if (t && t != CEED_VECTOR_NONE) CHK(vec_dev(t, false, &pt));
+  CHK(vec_dev(r, pt != nullptr, &pr)); CHK(vec_dev(d, true, &pd)); CHK(vec_dev(x, true, &px));
+  HIPCHK(launch_cheb_update(px, pd, pr, pt, pi, c1, c2, assign_x, (size_t)n, x->ceed->stream));
+  return 0;
+}
 extern "C" int CeedXVectorDot(CeedVector x, CeedVector y, CeedVector weight, double *result) {
   double *px, *py, *pw = nullptr, *dres;
   CHK(vec_dev(x, false, &px)); CHK(vec_dev(y, false, &py));
   if (weight && weight != CEED_VECTOR_NONE) CHK(vec_dev(weight, false, &pw));
   hipStream_t s = x->ceed->stream;
+  if (x->ceed->capturing) return ceed_error("CeedXVectorDot during graph capture (it returns a host value)");
   if (!x->ceed->d_scalar) HIPCHK(hipMalloc((void **)&x->ceed->d_scalar, sizeof(double)));
+  if (!x->ceed->h_scalar) HIPCHK(hipHostMalloc((void **)&x->ceed->h_scalar, sizeof(double), hipHostMallocDefault));
   dres = x->ceed->d_scalar;
   HIPCHK(hipMemsetAsync(dres, 0, sizeof(double), s));
   HIPCHK(launch_dot(px, py, pw, (size_t)x->length, dres, s));
-  HIPCHK(hipMemcpyAsync(result, dres, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(x->ceed->h_scalar, dres, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  *result = *x->ceed->h_scalar;
   return 0;
 }

@@ -96,6 +96,8 @@ hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const u
 
 // Vector / restriction utilities.
 hipError_t launch_set_value(double *v, size_t n, double val, hipStream_t s);
+hipError_t launch_cheb_update(double *x, double *d, double *r, const double *t, const double *dinv, double c1, double c2,
+                              int assign_x, size_t n, hipStream_t s);
 hipError_t launch_reciprocal(double *v, size_t n, hipStream_t s);
 hipError_t launch_pointwise_mult(double *w, const double *x, const double *y, size_t n, hipStream_t s);
 hipError_t launch_axpby(double *y, double a, const double *x, double b, size_t n, hipStream_t s);

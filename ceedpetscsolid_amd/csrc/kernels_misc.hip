@@ -275,6 +275,16 @@ __global__ void k_axpby(double *y, double a, const double *x, double b, size_t n
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     y[i] = a * x[i] + (b == 0. ? 0. : b * y[i]);
 }
+__global__ void k_cheb_update(double *x, double *d, double *r, const double *t, const double *dinv, double c1, double c2,
+                              int assign_x, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    double ri = r[i];
+    if (t) { ri -= t[i]; r[i] = ri; }
+    const double di = c1 * dinv[i] * ri + (c2 == 0. ? 0. : c2 * d[i]);
+    d[i] = di;
+    x[i] = assign_x ? di : x[i] + di;
+  }
+}
 __global__ void k_masked_copy(double *dst, const double *src, const unsigned char *mask, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     dst[i] = mask[i] ? 0. : src[i];
@@ -340,6 +350,12 @@ hipError_t launch_pointwise_mult(double *w, const double *x, const double *y, si
 hipError_t launch_axpby(double *y, double a, const double *x, double b, size_t n, hipStream_t s) {
   if (!n) return hipSuccess;
   hipLaunchKernelGGL(k_axpby, stream_grid(n), dim3(256), 0, s, y, a, x, b, n);
+  return hipGetLastError();
+}
+hipError_t launch_cheb_update(double *x, double *d, double *r, const double *t, const double *dinv, double c1, double c2,
+                              int assign_x, size_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_cheb_update, stream_grid(n), dim3(256), 0, s, x, d, r, t, dinv, c1, c2, assign_x, n);
   return hipGetLastError();
 }
 hipError_t launch_masked_copy(double *dst, const double *src, const unsigned char *mask, size_t n, hipStream_t s) {

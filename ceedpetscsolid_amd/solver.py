@@ -76,7 +76,7 @@ class Vec:
 class NewtonPMG:
     def __init__(self, prob: SolidProblem, clamp: Optional[Dict[int, dict]] = None, mms: bool = False,
                  halo=None, smooth_its: int = 3, coarse_rtol: float = 1e-3, coarse_maxit: int = 200,
-                 coarse: str = "cg", coarse_cheb_its: int = 40, coarse_cheb_ratio: float = 100.0,
+                 coarse: str = "cg", coarse_cheb_its: int = 40, coarse_cheb_ratio: float = 100.0, graph: bool = False,
                  ksp_rtol: float = 1e-10, snes_rtol: float = 1e-8, snes_maxit: int = 50, verbose: bool = False):
         """``clamp``: {side_set_id: dict(translate=(..), axis=(..), angle_over_pi=..)} as
         -bc_clamp_<id>_translate / _rotate (cloptions.c:86-131); ids present in the problem's Dirichlet
@@ -88,12 +88,20 @@ class NewtonPMG:
         # iteration) or "chebyshev" (fixed polynomial over [emax/ratio, 1.1 emax]: no reductions, no host
         # sync, a fixed linear operator; the few lowest modes are left to the outer Krylov method)
         self.coarse, self.coarse_cheb_its, self.coarse_cheb_ratio = coarse, coarse_cheb_its, coarse_cheb_ratio
+        # graph=True: record the V-cycle (a fixed sequence of ~150 small launches once the eigenvalue
+        # estimates are known) into a hipGraph per Newton step and replay it per Krylov iteration;
+        # needs the reduction-free Chebyshev coarse solver
+        self.graph = bool(graph)
+        if self.graph and coarse != "chebyshev":
+            raise ValueError("graph=True needs coarse='chebyshev' (the CG coarse solve reads dot products on the host)")
+        self._pc_graph, self._pc_graph_io, self._pc_graph_counts, self._pc_warm = None, None, (0, 0), False
         self.ksp_rtol, self.snes_rtol, self.snes_maxit, self.verbose = ksp_rtol, snes_rtol, snes_maxit, verbose
         self.nlev = len(prob.levels)
         c = self.ceed
         mk = lambda lv: c.vector(prob.lsize(lv)).set_value(0.0)
         self.w = [{k: mk(lv) for k in ("x", "b", "r", "d", "t", "dinv", "z")} for lv in range(self.nlev)]
         self.emax = [1.0] * self.nlev
+        self._x0 = {}
         n = prob.lsize()
         self.U, self.R, self.dU, self.Xloc, self.bcv, self.Rtry, self.Utry = (c.vector(n).set_value(0.0) for _ in range(7))
         self.kp, self.kz, self.kAp, self.kzold = (c.vector(n).set_value(0.0) for _ in range(4))
@@ -166,7 +174,6 @@ class NewtonPMG:
     # ---- multigrid preconditioner ---------------------------------------------------------------
     def setup_preconditioner(self):
         """Per Newton step: diagonals (GetDiag_Ceed), Chebyshev eigenvalue estimates."""
-        rng = np.random.default_rng(1234)
         for lv in range(self.nlev):
             w = self.w[lv]
             self.p.get_diag(lv, w["dinv"])
@@ -175,9 +182,13 @@ class NewtonPMG:
             d[mask] = 1.0                       # constrained rows: identity
             w["dinv"].set_array(1.0 / d)
             # largest eigenvalue of D^-1 A by power iteration from a noisy start (the reference lets
-            # PETSc estimate it with a few CG-Lanczos steps on a noisy right-hand side, :546-549)
-            x = rng.uniform(-1, 1, d.size) * (~mask)
-            w["x"].set_array(x / np.linalg.norm(x))
+            # PETSc estimate it with a few CG-Lanczos steps on a noisy right-hand side, :546-549).
+            # The start vector is drawn once per level; no BLAS on the host (a threaded BLAS call
+            # leaves its worker pool spinning, which starves a CPU-quota'd process for ~0.1 s a call).
+            if lv not in self._x0:
+                x = np.random.default_rng(1234 + lv).uniform(-1, 1, d.size) * (~mask)
+                self._x0[lv] = x / np.sqrt(np.square(x).sum())
+            w["x"].set_array(self._x0[lv])
             lam = 1.0
             for _ in range(12):
                 self.A(lv, w["x"], w["t"])
@@ -194,22 +205,19 @@ class NewtonPMG:
         sigma = theta / delta
         rho = 1.0 / sigma
         r, d, t = w["r"], w["d"], w["t"]
+        upd = self.L.lib.CeedXVectorChebyshevUpdate
+        # first step: r = b - A x;  d = dinv r / theta;  x (+)= d      (fused: one pass over the vectors)
+        self.copy(r, b)
         if zero_guess:
-            self.copy(r, b)
-            x.set_value(0.0)
+            self.L.chk(upd(x.h, d.h, r.h, None, w["dinv"].h, C.c_double(1.0 / theta), C.c_double(0.0), 1))
         else:
             self.A(lv, x, t)
-            self.copy(r, b); self.axpby(r, -1.0, t, 1.0)
-        self.pmult(d, r, w["dinv"]); self.axpby(d, 1.0 / theta, d, 0.0)
-        for k in range(its):
-            self.axpby(x, 1.0, d, 1.0)
-            if k == its - 1:
-                break
+            self.L.chk(upd(x.h, d.h, r.h, t.h, w["dinv"].h, C.c_double(1.0 / theta), C.c_double(0.0), 0))
+        for k in range(1, its):
             self.A(lv, d, t)
-            self.axpby(r, -1.0, t, 1.0)
             rho_new = 1.0 / (2.0 * sigma - rho)
-            self.pmult(t, r, w["dinv"])
-            self.axpby(d, 2.0 * rho_new / delta, t, rho_new * rho)
+            # r -= A d;  d = (2 rho'/delta) dinv r + (rho' rho) d;  x += d
+            self.L.chk(upd(x.h, d.h, r.h, t.h, w["dinv"].h, C.c_double(2.0 * rho_new / delta), C.c_double(rho_new * rho), 0))
             rho = rho_new
 
     def coarse_solve(self, b, x):
@@ -256,7 +264,29 @@ class NewtonPMG:
         self.axpby(x, 1.0, w["z"], 1.0)
         self.chebyshev(lv, b, x, self.smooth_its, False)
 
+    def record_preconditioner(self, r, z):
+        """Capture vcycle(r -> z) for the current diagonals / eigenvalue bounds (call after setup_preconditioner)."""
+        if self._pc_graph is not None:
+            self._pc_graph.destroy()
+            self._pc_graph = None
+        if not self.graph or self.nlev == 1:
+            return
+        top = self.nlev - 1
+        if not self._pc_warm:                      # first-use setup (CSR maps, scratch) must not be recorded
+            self.vcycle(top, r, z)
+            self._pc_warm = True
+        j0, c0 = self.stats.jacobian_applies, self.stats.coarse_its
+        self._pc_graph = self.ceed.capture(lambda: self.vcycle(top, r, z))
+        self._pc_graph_counts = (self.stats.jacobian_applies - j0, self.stats.coarse_its - c0)
+        self.stats.jacobian_applies, self.stats.coarse_its = j0, c0
+        self._pc_graph_io = (r, z)
+
     def precondition(self, r, z):
+        if self._pc_graph is not None and self._pc_graph_io[0] is r and self._pc_graph_io[1] is z:
+            self._pc_graph.launch()
+            self.stats.jacobian_applies += self._pc_graph_counts[0]
+            self.stats.coarse_its += self._pc_graph_counts[1]
+            return
         if self.nlev == 1:          # -multigrid none: Jacobi (elasticity.c:516-519)
             self.pmult(z, r, self.w[0]["dinv"])
         else:
@@ -309,6 +339,7 @@ class NewtonPMG:
                 if rnorm <= self.snes_rtol * rnorm0 or rnorm < 1e-50:
                     break
                 self.setup_preconditioner()
+                self.record_preconditioner(self.w[self.nlev - 1]["b"], self.kz)
                 self.axpby(self.Rtry, -1.0, self.R, 0.0)                 # rhs = -R
                 k = self.fcg(self.Rtry, self.dU, self.ksp_rtol)
                 st.ksp_its += k
@@ -340,4 +371,7 @@ class NewtonPMG:
                 break
         self.ceed.synchronize()
         st.seconds = time.perf_counter() - t0
+        if self._pc_graph is not None:
+            self._pc_graph.destroy()
+            self._pc_graph = None
         return st

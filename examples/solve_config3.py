@@ -8,6 +8,8 @@ README-style boundary conditions (README.rst:63): -bc_clamp 998,999 -bc_clamp_99
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")   # see bench.py: a spinning host BLAS pool throttles the launching thread
+os.environ.setdefault("MKL_NUM_THREADS", "1")
 import numpy as np
 from ceedpetscsolid_amd import ceed as cd
 from ceedpetscsolid_amd.mesh import load_mesh_npz
@@ -26,6 +28,7 @@ ap.add_argument("--nu", type=float, default=0.3)
 ap.add_argument("--oracle", action="store_true", help="TESTS ONLY: run the same solve on the CPU oracle")
 ap.add_argument("--verbose", action="store_true")
 ap.add_argument("--coarse", default="cg", choices=["cg", "chebyshev"])
+ap.add_argument("--graph", action="store_true", help="replay the V-cycle as a hipGraph")
 ap.add_argument("--coarse-cheb-its", type=int, default=40)
 ap.add_argument("--coarse-cheb-ratio", type=float, default=100.0)
 ap.add_argument("--coarse-maxit", type=int, default=200)
@@ -41,14 +44,14 @@ t0 = time.perf_counter()
 prob = SolidProblem(ceed, mesh, args.degree, args.problem, nu=args.nu, E=args.E, bc_sides=[998, 999])
 tr = tuple(float(t) for t in args.translate.split(","))
 solver = NewtonPMG(prob, clamp={998: dict(translate=tr), 999: dict()}, verbose=args.verbose,
-                   coarse_maxit=args.coarse_maxit, coarse_rtol=args.coarse_rtol, coarse=args.coarse,
+                   coarse_maxit=args.coarse_maxit, coarse_rtol=args.coarse_rtol, coarse=args.coarse, graph=args.graph,
                    coarse_cheb_its=args.coarse_cheb_its, coarse_cheb_ratio=args.coarse_cheb_ratio)
 t_setup = time.perf_counter() - t0
 st = solver.solve(args.increments)
 u = solver.U.to_numpy().reshape(-1, 3)
 out = {"resource": ceed.resource, "problem": args.problem, "mesh": os.path.basename(args.mesh), "elements": mesh.nelem,
        "level_degrees": prob.degrees, "global_dofs_per_level": [prob.n_free(l) for l in range(len(prob.levels))],
-       "translate_998": list(tr), "coarse_solver": args.coarse, "load_increments": st.increments, "converged": st.converged, "snes_its": st.newton_its, "ksp_its": st.ksp_its,
+       "translate_998": list(tr), "coarse_solver": args.coarse, "vcycle_graph": args.graph, "load_increments": st.increments, "converged": st.converged, "snes_its": st.newton_its, "ksp_its": st.ksp_its,
        "coarse_cg_its": st.coarse_its, "jacobian_applies": st.jacobian_applies, "residual_evals": st.residual_evals,
        "setup_s": t_setup, "snes_solve_s": st.seconds,
        "MDoFs_per_s_in_SNES": 1e-6 * prob.n_free() * st.ksp_its / st.seconds,   # elasticity.c:755-764

@@ -227,6 +227,18 @@ CEED_EXTERN const char *CeedXLastError(void);
 CEED_EXTERN int CeedXSetStream(Ceed ceed, void *hip_stream);
 /* Block until all device work queued by this Ceed has finished.              */
 CEED_EXTERN int CeedXSynchronize(Ceed ceed);
+/* hipGraph capture of a launch-bound sequence (e.g. one multigrid V-cycle:   */
+/* ~150 small kernels).  Between Begin and End every CeedOperatorApply /      */
+/* CeedX vector helper on this Ceed is recorded instead of run; nothing that  */
+/* needs the host (CeedXVectorDot, host array access, first-use setup) may be */
+/* called, so run the sequence once eagerly first.  Scalars passed to the     */
+/* recorded calls are baked in; vectors are referenced by device address.     */
+/* Launch replays the recording on the Ceed's stream.                         */
+typedef struct CeedXGraph_private *CeedXGraph;
+CEED_EXTERN int CeedXGraphBeginCapture(Ceed ceed);
+CEED_EXTERN int CeedXGraphEndCapture(Ceed ceed, CeedXGraph *graph);
+CEED_EXTERN int CeedXGraphLaunch(CeedXGraph graph);
+CEED_EXTERN int CeedXGraphDestroy(CeedXGraph *graph);
 /* Name of the kernel family an operator was lowered to, e.g.                 */
 /* "fused_grad<P=5,Q=5,HyperFSdF>" (empty before the first apply).            */
 CEED_EXTERN int CeedXOperatorGetKernelName(CeedOperator op, const char **name);
@@ -265,6 +277,13 @@ CEED_EXTERN int CeedXVectorAXPBY(CeedVector y, double a, CeedVector x,
                                  double b);
 CEED_EXTERN int CeedXVectorDot(CeedVector x, CeedVector y,
                                CeedVector weight /* or NULL */, double *result);
+/* One Jacobi-Chebyshev smoother update in a single pass over the vectors     */
+/* (the KSPCHEBYSHEV + PCJACOBI smoother of elasticity.c:539-552):            */
+/*   r -= t (skipped if t is NULL);  d = c1 * dinv .* r + c2 * d;             */
+/*   x = d if assign_x else x + d.                                            */
+CEED_EXTERN int CeedXVectorChebyshevUpdate(CeedVector x, CeedVector d, CeedVector r,
+                                           CeedVector t /* or NULL */, CeedVector dinv,
+                                           double c1, double c2, int assign_x);
 /* Accumulated device time (ms) and launch count of the operator's dominant   */
 /* kernel since the last reset; measured with hipEvents on the Ceed's stream  */
 /* when timing is enabled.                                                    */

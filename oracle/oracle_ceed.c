@@ -185,6 +185,12 @@ int CeedGetPreferredMemType(Ceed ceed, CeedMemType *type) {
 }
 int CeedXSetStream(Ceed ceed, void *s) { (void)ceed; (void)s; return 0; }
 int CeedXSynchronize(Ceed ceed) { (void)ceed; return 0; }
+/* the CPU oracle has no device queue to record: capture is refused, callers run eagerly */
+typedef struct CeedXGraph_private *CeedXGraph;
+int CeedXGraphBeginCapture(Ceed ceed) { (void)ceed; return 1; }
+int CeedXGraphEndCapture(Ceed ceed, CeedXGraph *g) { (void)ceed; (void)g; return 1; }
+int CeedXGraphLaunch(CeedXGraph g) { (void)g; return 1; }
+int CeedXGraphDestroy(CeedXGraph *g) { if (g) *g = 0; return 0; }
 
 /* ------------------------------------------------------------------------- */
 /* CeedVector                                                                 */
@@ -1076,6 +1082,19 @@ int CeedXVectorPointwiseMult(CeedVector w, CeedVector x, CeedVector y) {
 int CeedXVectorAXPBY(CeedVector y, double a, CeedVector x, double b) {
   vec_ensure(x); vec_ensure(y);
   for (CeedInt i = 0; i < y->length; i++) y->array[i] = a * x->array[i] + (b == 0. ? 0. : b * y->array[i]);
+  return 0;
+}
+int CeedXVectorChebyshevUpdate(CeedVector x, CeedVector d, CeedVector r, CeedVector t, CeedVector dinv,
+                               double c1, double c2, int assign_x) {
+  vec_ensure(x); vec_ensure(d); vec_ensure(r); vec_ensure(dinv);
+  const int have_t = t && t != CEED_VECTOR_NONE;
+  if (have_t) vec_ensure(t);
+  for (CeedInt i = 0; i < x->length; i++) {
+    if (have_t) r->array[i] -= t->array[i];
+    const double di = c1 * dinv->array[i] * r->array[i] + (c2 == 0. ? 0. : c2 * d->array[i]);
+    d->array[i] = di;
+    x->array[i] = assign_x ? di : x->array[i] + di;
+  }
   return 0;
 }
 int CeedXVectorDot(CeedVector x, CeedVector y, CeedVector weight, double *result) {

@@ -51,3 +51,41 @@ def test_device_solve_matches_oracle_solve(oracle, gpu):
         sols.append((s.U.to_numpy(), st.newton_its))
     assert sols[0][1] == sols[1][1]
     assert rel_err(sols[1][0], sols[0][0]) < 1e-8
+
+
+def test_chebyshev_coarse_solver_converges_on_oracle(oracle):
+    mesh = hollow_cylinder_mesh(1, 6, 2, z0=-1.0, z1=1.0)
+    p = SolidProblem(oracle, mesh, 2, "hyperSS", nu=0.3, E=10.0, bc_sides=[998, 999])
+    ref = NewtonPMG(p, clamp=CLAMP)
+    assert ref.solve(1).converged
+    s = NewtonPMG(p, clamp=CLAMP, coarse="chebyshev", coarse_cheb_its=20, coarse_cheb_ratio=50.0)
+    assert s.solve(1).converged
+    assert rel_err(s.U.to_numpy(), ref.U.to_numpy()) < 1e-8
+    with pytest.raises(ValueError):
+        NewtonPMG(p, clamp=CLAMP, coarse="cg", graph=True)
+
+
+@pytest.mark.gpu
+def test_graph_replayed_vcycle_matches_eager_vcycle(gpu):
+    """CeedXGraph*: a recorded V-cycle replays the same kernels on the same data, so the solve's
+    iterates match the eager solve; host-needing calls are refused while recording."""
+    from ceedpetscsolid_amd import ceed as cd
+    mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_672e_4ss_us.npz"))
+    out = []
+    for graph in (False, True):
+        p = SolidProblem(gpu, mesh, 4, "hyperSS", nu=0.3, E=1e3, bc_sides=[998, 999])
+        s = NewtonPMG(p, clamp=CLAMP, coarse="chebyshev", coarse_cheb_its=20, coarse_cheb_ratio=50.0, graph=graph)
+        st = s.solve(2)
+        assert st.converged
+        out.append((s.U.to_numpy(), st.newton_its, st.ksp_its, st.jacobian_applies))
+    assert out[0][1] == out[1][1] and abs(out[0][2] - out[1][2]) <= 2
+    # Restrict_Ceed sums with f64 atomics (order varies run to run), so agreement is to solver tolerance
+    assert rel_err(out[1][0], out[0][0]) < 1e-8
+    x, y = gpu.vector(8).set_value(1.0), gpu.vector(8).set_value(2.0)
+
+    def bad():
+        x.dot(y) if hasattr(x, "dot") else gpu.L.chk(gpu.L.lib.CeedXVectorDot(x.h, y.h, None, cd.C.byref(cd.C.c_double())))
+    with pytest.raises(cd.CeedError):
+        gpu.capture(bad)
+    x.set_value(3.0)                       # the Ceed is usable again after the refused recording
+    assert np.all(x.to_numpy() == 3.0)
