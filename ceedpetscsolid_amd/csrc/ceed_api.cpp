@@ -66,6 +66,7 @@ struct Ceed_private {
   double *evec = nullptr;
   size_t evec_len = 0;
   bool atomic_scatter = false;  // CEED_MI355X_SCATTER=atomic: f64 atomics instead of E-vector + assembly
+  int fused_variant = 1;        // CEED_MI355X_FUSED=rows: the first-generation row kernel (A/B); default pencil
   double *d_scalar = nullptr;   // device scalar for reductions
   double *h_scalar = nullptr;   // pinned host landing slot for it (pageable targets make the runtime stage + pin per copy)
   // hipGraph capture (CeedXGraphBeginCapture): device work is recorded on `capture_stream`
@@ -210,6 +211,8 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   HIPCHK(hipGetDevice(&c->device));
   const char *sc = getenv("CEED_MI355X_SCATTER");
   c->atomic_scatter = sc && !strcmp(sc, "atomic");
+  const char *fv = getenv("CEED_MI355X_FUSED");
+  c->fused_variant = (fv && !strcmp(fv, "rows")) ? 0 : 1;
   *ceed = c;
   return 0;
 }
@@ -919,6 +922,7 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
   CHK(read_phys(qf, &a.nu, &a.E));
   lame_constants(a.nu, a.E, &a.lambda, &a.TwoMu);
   a.stamps = op->stamps;
+  a.variant = op->ceed->fused_variant;
   const bool use_evec = !op->ceed->atomic_scatter;
   const bool split = phase >= 0;
   if (split && (!use_evec || add || op->ovl_lead <= 0 || !op->ovl_csr.built))

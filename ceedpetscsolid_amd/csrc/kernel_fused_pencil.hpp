@@ -1,0 +1,529 @@
+// kernel_fused_pencil.hpp -- second-generation fused operator kernel: PENCIL PER LANE.
+//
+// Same job as kernel_fused_grad.hpp (the whole CeedOperatorApply of the residual /
+// Jacobian operators, setuplibceed.c:517-542, :817-839, in one launch) with a different
+// mapping of the 1-D contractions onto the wave.
+//
+// Why.  The row kernel gives every lane one OUTPUT point of a contraction, so the Q lanes
+// that share an input row each read the whole row from LDS: Q-fold redundant LDS reads, and
+// per-lane coefficient rows that also come from LDS.  PMC + stamps put it at ~71 % LDS-pipe
+// busy; it is LDS bound, not HBM bound.  Here a lane owns a whole PENCIL (one line of the
+// element along the contraction direction, one component): it reads the NIN inputs once,
+// produces all NOUT outputs in registers and writes them back IN PLACE.  Every value is read
+// once and written once per pass, and the coefficients are wave-uniform, so they are scalar
+// operands (kernarg -> SGPR), not LDS traffic.  LDS cycles per element by the bank model of
+// tools/pencil_layout_search.py: ~960 against ~1 300 (conflict-free) / ~1 900 (measured) before.
+//
+// Pipeline for a group of E elements owned by ONE wave64 (no s_barrier anywhere; a wave's LDS
+// queue is in order).  Arrays A, BX, BZ: [c][k][j][i], strides (1, Q, Q^2, Q^3) doubles.
+//   gather  x -> A (nodes)                          node-owner lanes
+//   F1..F3  interpolate along i, j, k in place      pencil lanes;  F3 also writes dU/dz -> BZ (grad1d)
+//   F4, F5  collocated d/dx: A -> BX, d/dy: A -> A  pencil lanes
+//   QF      9 gradient entries in, 9 out, in place  point-owner lanes (q-point data prefetched
+//                                                   two point-rounds ahead, across groups)
+//   B1..B5  transposes of F5..F1, accumulating      pencil lanes
+//   final   A (nodes) -> E-vector / atomics         node-owner lanes
+//
+// All LDS accesses are explicit ds_read_b64 / ds_write_b64 with immediate offsets (inline asm):
+// hipcc would pair the strided pencil reads into ds_read2_b64, which runs at half the byte rate
+// of ds_read_b64 on gfx950 (MI355X_MICROARCH.md, LDS table).
+#pragma once
+#include "kernels_common.hpp"
+#include "qfunctions_device.hpp"
+
+namespace cps {
+
+template <int P, int Q> struct PencilGeom {
+  static constexpr int Q3 = Q * Q * Q, P3 = P * P * P;
+  static constexpr int E = Q <= 2 ? 8 : (Q <= 4 ? 4 : (Q == 5 ? 2 : 1));  // elements per wave
+  static constexpr int SJ = Q, SK = Q * Q, SC = Q3;                         // strides in doubles
+  static constexpr int ARR = 3 * SC;                                        // one 3-component array
+  static constexpr int PAD = Q == 5 ? 5 : 1;                                // tools/pencil_layout_search.py
+  static constexpr int SE = 3 * ARR + PAD;                                  // element slab: A, BX, BZ
+  static constexpr int RQ = (E * Q3 + 63) / 64;                             // point rounds per group
+  static constexpr int RN = (E * P3 + 63) / 64;                             // node rounds per group
+  static constexpr int LDS_BYTES = E * SE * 8;
+};
+
+// ---- LDS accessors: VOLATILE 8-byte accesses through an LDS pointer + constant offset ----------
+// Volatile does two jobs.  (1) hipcc keeps each access a separate ds_read_b64 / ds_write_b64 with an
+// immediate offset (it still tracks them and places counted s_waitcnt lgkmcnt(N) itself), instead of
+// pairing the strided pencil reads into half-rate ds_read2_b64.  (2) Volatile accesses are never
+// reordered against each other, which is all the ordering the passes need: they communicate through
+// LDS across lanes of ONE wave, whose LDS queue the hardware executes in order.
+// (Inline-asm ds_read + explicit waits were tried first: the compiler does not know an asm output is
+// still in flight, so it may copy or spill the register before the wait -- it did, silently.)
+typedef __attribute__((address_space(3))) double lds_double;
+typedef volatile lds_double *ldsp_t;
+template <int OFF>
+CPS_DEV double lds_rd(ldsp_t a) {
+  static_assert(OFF >= 0 && OFF < 65536 && OFF % 8 == 0, "ds offset field is 16 bits");
+  return a[OFF / 8];
+}
+template <int OFF>
+CPS_DEV void lds_wr(ldsp_t a, double v) {
+  static_assert(OFF >= 0 && OFF < 65536 && OFF % 8 == 0, "ds offset field is 16 bits");
+  a[OFF / 8] = v;
+}
+// N values at stride SB bytes from byte offset OFF
+template <int N, int SB, int OFF, int M = 0>
+CPS_DEV void pencil_ld(ldsp_t a, double *r) {
+  if constexpr (M < N) {
+    r[M] = lds_rd<OFF + M * SB>(a);
+    pencil_ld<N, SB, OFF, M + 1>(a, r);
+  }
+}
+template <int N, int SB, int OFF, int M = 0>
+CPS_DEV void pencil_st(ldsp_t a, const double *r) {
+  if constexpr (M < N) {
+    lds_wr<OFF + M * SB>(a, r[M]);
+    pencil_st<N, SB, OFF, M + 1>(a, r);
+  }
+}
+CPS_DEV void lds_wait() {}                    // the compiler counts the volatile reads itself
+template <int N> CPS_DEV void lds_pin(double *) {}
+
+// Coefficient tables are read straight from the kernarg segment (constant address space ->
+// s_load, SGPR operands of the FMAs).  Each pass takes a freshly "laundered" pointer, so the
+// compiler loads that pass's 25 coefficients inside the pass instead of hoisting all three tables
+// out of the element loop (150 SGPRs: it then spilled them to VGPR lanes, 900 v_readlane per group).
+typedef const __attribute__((address_space(4))) double *ktab_t;
+CPS_DEV ktab_t ktab_fresh(ktab_t p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+// out[o] += sum_m M(o, m) in[m];  M(o, m) = TR ? tab[m * LD + o] : tab[o * LD + m]  (wave-uniform -> SGPR operands)
+template <int NOUT, int NIN, int LD, bool TR>
+CPS_DEV void pencil_mac(ktab_t tab, const double *in, double *out) {
+#pragma unroll
+  for (int o = 0; o < NOUT; o++) {
+#pragma unroll
+    for (int m = 0; m < NIN; m++) out[o] += (TR ? tab[m * LD + o] : tab[o * LD + m]) * in[m];
+  }
+}
+
+#ifndef CPS_PENCIL_MINW
+#define CPS_PENCIL_MINW 2
+#endif
+template <int P, int Q, int QF>
+__global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const BasisTables tab_, const FusedGradArgs a) {
+  static_assert(offsetof(BasisTables, interp) == 0 && offsetof(BasisTables, colo) == 8 * MAXN1D * MAXN1D &&
+                offsetof(BasisTables, grad) == 16 * MAXN1D * MAXN1D, "kernarg layout of the tables");
+  (void)tab_;  // first kernel argument: lives at offset 0 of the kernarg segment, read through kt below
+  const ktab_t kt = (ktab_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const ktab_t ktB = kt, ktD = kt + MAXN1D * MAXN1D, ktG = kt + 2 * MAXN1D * MAXN1D;
+  using G = PencilGeom<P, Q>;
+  constexpr int Q3 = G::Q3, P3 = G::P3, E = G::E, RQ = G::RQ, RN = G::RN;
+  constexpr int SJ = G::SJ, SK = G::SK, SC = G::SC, SE = G::SE;
+  constexpr int BI = 8, BJ = 8 * SJ, BK = 8 * SK, BC = 8 * SC;        // byte strides
+  constexpr int oA = 0, oBX = 8 * G::ARR, oBZ = 16 * G::ARR;         // byte offsets of the arrays
+  constexpr bool ST_IN = QFTraits<QF>::state_in, ST_OUT = QFTraits<QF>::state_out;
+  static_assert(P <= Q, "interpolation to at least as many points as nodes");
+
+  __shared__ __attribute__((aligned(16))) double slab[E * SE];
+  const ldsp_t lds0 = (lds_double *)slab;
+  const int lane = threadIdx.x;
+
+  // ---- work list of this wave (XCD-aware, as in the row kernel) ---------------------------------
+  const int ngroups = (a.nelem + E - 1) / E;
+  const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1;
+  const int xcd = blockIdx.x % nxcd, wrank = blockIdx.x / nxcd, wper = gridDim.x / nxcd;
+  const int chunk = (ngroups + nxcd - 1) / nxcd;
+  const int gbeg = xcd * chunk, gend = min(ngroups, gbeg + chunk);
+  int grp = gbeg + wrank;
+  if (grp >= gend) return;
+
+  // ---- loop-invariant lane -> work maps -----------------------------------------------------
+  // pencil passes: task t = lane + 64 r over (element, component, b, a), a fastest; byte address of the
+  // pencil's first entry.  Five families: direction i over nodal / quadrature (j,k), direction j over
+  // (i' , nodal / quadrature k), direction k over (i', j').
+  auto pencil_addr = [&](int t, int NA, int NB, int sa, int sb) -> ldsp_t {
+    const int T = 3 * NA * NB;
+    const int el = t / T, tt = t % T, c = tt / (NA * NB), pen = tt % (NA * NB), ia = pen % NA, ib = pen / NA;
+    return lds0 + (el * SE + c * SC + (ia * sa + ib * sb) / 8);
+  };
+  constexpr int T_IP = 3 * P * P, T_IQ = 3 * Q * Q, T_JP = 3 * Q * P, T_JQ = 3 * Q * Q, T_K = 3 * Q * Q;
+  constexpr int R_IP = (E * T_IP + 63) / 64, R_IQ = (E * T_IQ + 63) / 64, R_JP = (E * T_JP + 63) / 64,
+                R_JQ = (E * T_JQ + 63) / 64, R_K = (E * T_K + 63) / 64;
+  ldsp_t aIP[R_IP], aIQ[R_IQ], aJP[R_JP], aJQ[R_JQ], aK[R_K];
+#pragma unroll
+  for (int r = 0; r < R_IP; r++) aIP[r] = pencil_addr(lane + 64 * r, P, P, BJ, BK);
+#pragma unroll
+  for (int r = 0; r < R_IQ; r++) aIQ[r] = pencil_addr(lane + 64 * r, Q, Q, BJ, BK);
+#pragma unroll
+  for (int r = 0; r < R_JP; r++) aJP[r] = pencil_addr(lane + 64 * r, Q, P, BI, BK);
+#pragma unroll
+  for (int r = 0; r < R_JQ; r++) aJQ[r] = pencil_addr(lane + 64 * r, Q, Q, BI, BK);
+#pragma unroll
+  for (int r = 0; r < R_K; r++) aK[r] = pencil_addr(lane + 64 * r, Q, Q, BI, BJ);
+  // point owners: q = lane + 64 r over (element, k, j, i); node owners likewise over P^3
+  ldsp_t aPt[RQ], aNd[RN];
+  // element-in-group and local index of owner slot t = lane + 64 r, recomputed where needed (a few
+  // compares) instead of held in registers through the physics
+  auto el_of = [&](int t, int n3) { int el = 0;
+#pragma unroll
+    for (int e = 1; e < E; e++) el += (t >= e * n3) ? 1 : 0;
+    return el; };
+#pragma unroll
+  for (int r = 0; r < RQ; r++) {
+    const int t = lane + 64 * r, el = t / Q3, q = t % Q3;
+    aPt[r] = lds0 + (el * SE + (q / (Q * Q)) * SK + ((q / Q) % Q) * SJ + q % Q);
+  }
+#pragma unroll
+  for (int r = 0; r < RN; r++) {
+    const int t = lane + 64 * r, el = t / P3, n = t % P3;
+    aNd[r] = lds0 + (el * SE + (n / (P * P)) * SK + ((n / P) % P) * SJ + n % P);
+  }
+  auto task_ok = [&](int r, int ntask) { return (r + 1) * 64 <= ntask ? true : lane + 64 * r < ntask; };
+
+  // ---- global-memory side: clamped, unconditional loads (as in the row kernel) ------------------
+  // Addressing: a wave-uniform 64-bit base per group (SGPRs) plus a 32-bit per-lane offset inside the
+  // group's block, so no per-lane 64-bit address arithmetic or loop-invariant address pairs.  Lanes of a
+  // dead element (only in the last, partial group) read the group's last live element instead.
+  auto nlive_of = [&](int g) { const int n = a.nelem - g * E; return n < E ? n : E; };  // uniform, >= 1
+#ifndef CPS_PENCIL_NSET
+#define CPS_PENCIL_NSET 1
+#endif
+  constexpr int NSET = RQ >= 2 ? CPS_PENCIL_NSET : 1;
+  double qd[NSET][10], st[NSET][9];
+  auto load_point = [&](double *qdv, double *stv, int g, int r) {
+    const int t = lane + 64 * r, el0 = el_of(t, Q3);
+    const int q = min(t - el0 * Q3, Q3 - 1), el = min(el0, nlive_of(g) - 1);
+    const size_t e0 = (size_t)(a.elem_begin + g * E);
+    const double *qb = a.qdata + e0 * (10 * Q3);
+    const uint32_t vo = (uint32_t)(el * (10 * Q3) + q);
+#ifdef CPS_ABLATE_QDATA  // timing-only build: no q-point stream (WRONG results)
+    for (int c = 0; c < 10; c++) qdv[c] = (c == 1 || c == 5 || c == 9 || c == 0) ? 1.0 + 1e-3 * q : 1e-3 * c;
+    for (int c = 0; c < 9; c++) stv[c] = 1e-3 * (c + lane);
+    return;
+#endif
+#pragma unroll
+    for (int c = 0; c < 10; c++) qdv[c] = (qb + c * Q3)[vo];
+    if constexpr (ST_IN) {
+      const double *sb = a.state_in + e0 * (9 * Q3);
+      const uint32_t vs = (uint32_t)(el * (9 * Q3) + q);
+#pragma unroll
+      for (int c = 0; c < 9; c++) stv[c] = (sb + c * Q3)[vs];
+    }
+  };
+  auto load_offsets = [&](int g, uint32_t *o) {
+    const uint32_t *ob = a.offsets + (size_t)(a.elem_begin + g * E) * P3;
+#pragma unroll
+    for (int r = 0; r < RN; r++) {
+      const int t = lane + 64 * r, el0 = el_of(t, P3);
+      const int n = min(t - el0 * P3, P3 - 1), el = min(el0, nlive_of(g) - 1);
+      o[r] = ob[(uint32_t)(el * P3 + n)];
+    }
+  };
+  auto load_x = [&](const uint32_t *o, double (*xv)[3]) {
+#pragma unroll
+    for (int r = 0; r < RN; r++) {
+      const uint32_t base = o[r] & OFF_MASK;
+#pragma unroll
+      for (int c = 0; c < 3; c++) xv[r][c] = a.x[base + c];
+    }
+  };
+
+  uint32_t off[RN], off_nx[RN];
+  double xin[RN][3];
+  load_offsets(grp, off);
+  load_x(off, xin);
+#pragma unroll
+  for (int t = 0; t < NSET; t++) load_point(qd[t], st[t], grp, t);
+
+  for (;;) {
+    const int grp_nx = grp + wper;
+    const bool more = grp_nx < gend;  // wave-uniform
+    const int g_nx = more ? grp_nx : grp;
+    load_offsets(g_nx, off_nx);
+
+    // ---- gather: x -> A at the nodes (Dirichlet flags applied; dead elements of the last group zero) ----
+#pragma unroll
+    for (int r = 0; r < RN; r++) {
+      if (task_ok(r, E * P3)) {
+        const bool live = grp * E + el_of(lane + 64 * r, P3) < a.nelem;
+        const uint32_t fl = live ? (a.mask_in ? (off[r] >> OFF_FLAG_SHIFT) : 0u) : 7u;
+        lds_wr<oA + 0 * BC>(aNd[r], (fl & 1u) ? 0. : xin[r][0]);
+        lds_wr<oA + 1 * BC>(aNd[r], (fl & 2u) ? 0. : xin[r][1]);
+        lds_wr<oA + 2 * BC>(aNd[r], (fl & 4u) ? 0. : xin[r][2]);
+      }
+    }
+
+    // ---- F1: along i, nodal (j,k):  A[i<P] -> A[i'<Q] ---------------------------------------------
+    {
+      const ktab_t tB = ktab_fresh(ktB);
+      double in[R_IP][P];
+#pragma unroll
+      for (int r = 0; r < R_IP; r++) if (task_ok(r, E * T_IP)) pencil_ld<P, BI, oA>(aIP[r], in[r]);
+      lds_wait();
+#pragma unroll
+      for (int r = 0; r < R_IP; r++) if (task_ok(r, E * T_IP)) {
+        lds_pin<P>(in[r]);
+        double out[Q] = {};
+        pencil_mac<Q, P, P, false>(tB, in[r], out);
+        pencil_st<Q, BI, oA>(aIP[r], out);
+      }
+    }
+    // ---- F2: along j, (i', nodal k) -----------------------------------------------------------------
+    {
+      const ktab_t tB = ktab_fresh(ktB);
+      double in[R_JP][P];
+#pragma unroll
+      for (int r = 0; r < R_JP; r++) if (task_ok(r, E * T_JP)) pencil_ld<P, BJ, oA>(aJP[r], in[r]);
+      lds_wait();
+#pragma unroll
+      for (int r = 0; r < R_JP; r++) if (task_ok(r, E * T_JP)) {
+        lds_pin<P>(in[r]);
+        double out[Q] = {};
+        pencil_mac<Q, P, P, false>(tB, in[r], out);
+        pencil_st<Q, BJ, oA>(aJP[r], out);
+      }
+    }
+    // ---- F3: along k, (i', j'):  U -> A in place, dU/dz -> BZ (grad1d on the nodal values) -----------
+    {
+      const ktab_t tB = ktab_fresh(ktB);
+      double in[R_K][P];
+#pragma unroll
+      for (int r = 0; r < R_K; r++) if (task_ok(r, E * T_K)) pencil_ld<P, BK, oA>(aK[r], in[r]);
+      lds_wait();
+#pragma unroll
+      for (int r = 0; r < R_K; r++) if (task_ok(r, E * T_K)) {
+        lds_pin<P>(in[r]);
+        double out[Q] = {};
+        pencil_mac<Q, P, P, false>(tB, in[r], out);
+        pencil_st<Q, BK, oA>(aK[r], out);
+      }
+      const ktab_t tG = ktab_fresh(ktG);
+#pragma unroll
+      for (int r = 0; r < R_K; r++) if (task_ok(r, E * T_K)) {
+        double dz[Q] = {};
+        pencil_mac<Q, P, P, false>(tG, in[r], dz);
+        pencil_st<Q, BK, oBZ>(aK[r], dz);
+      }
+    }
+    // ---- F4: d/dx (collocated) A -> BX;  F5: d/dy A -> A in place -------------------------------------
+    {
+      const ktab_t tD = ktab_fresh(ktD);
+      double in[R_IQ][Q];
+#pragma unroll
+      for (int r = 0; r < R_IQ; r++) if (task_ok(r, E * T_IQ)) pencil_ld<Q, BI, oA>(aIQ[r], in[r]);
+      lds_wait();
+#pragma unroll
+      for (int r = 0; r < R_IQ; r++) if (task_ok(r, E * T_IQ)) {
+        lds_pin<Q>(in[r]);
+        double out[Q] = {};
+        pencil_mac<Q, Q, Q, false>(tD, in[r], out);
+        pencil_st<Q, BI, oBX>(aIQ[r], out);
+      }
+    }
+    {
+      const ktab_t tD = ktab_fresh(ktD);
+      double in[R_JQ][Q];
+#pragma unroll
+      for (int r = 0; r < R_JQ; r++) if (task_ok(r, E * T_JQ)) pencil_ld<Q, BJ, oA>(aJQ[r], in[r]);
+      lds_wait();
+#pragma unroll
+      for (int r = 0; r < R_JQ; r++) if (task_ok(r, E * T_JQ)) {
+        lds_pin<Q>(in[r]);
+        double out[Q] = {};
+        pencil_mac<Q, Q, Q, false>(tD, in[r], out);
+        pencil_st<Q, BJ, oA>(aJQ[r], out);
+      }
+    }
+
+    // ---- physics: point owners, one round at a time; ug[d*3+c] from (BX, A, BZ), dv back in place ----
+#pragma unroll
+    for (int r = 0; r < RQ; r++) {
+      const bool okp = task_ok(r, E * Q3);
+      const int pel = el_of(lane + 64 * r, Q3), pq = lane + 64 * r - pel * Q3;
+      const bool live = okp && (grp * E + pel < a.nelem);
+      double ug[9], dv[9], sto[9];
+      if (okp) {
+        ug[0] = lds_rd<oBX + 0 * BC>(aPt[r]); ug[1] = lds_rd<oBX + 1 * BC>(aPt[r]); ug[2] = lds_rd<oBX + 2 * BC>(aPt[r]);
+        ug[3] = lds_rd<oA + 0 * BC>(aPt[r]);  ug[4] = lds_rd<oA + 1 * BC>(aPt[r]);  ug[5] = lds_rd<oA + 2 * BC>(aPt[r]);
+        ug[6] = lds_rd<oBZ + 0 * BC>(aPt[r]); ug[7] = lds_rd<oBZ + 1 * BC>(aPt[r]); ug[8] = lds_rd<oBZ + 2 * BC>(aPt[r]);
+      }
+      lds_wait();
+      if (live) {
+        lds_pin<9>(ug);
+        qf_point<QF>(Phys{a.nu, a.E, a.lambda, a.TwoMu}, ug, qd[r % NSET], st[r % NSET], dv, sto);
+        if constexpr (ST_OUT) {
+          double *sb = a.state_out + (size_t)(a.elem_begin + grp * E) * (9 * Q3);
+          const uint32_t vs = (uint32_t)(pel * (9 * Q3) + pq);
+#pragma unroll
+          for (int c = 0; c < 9; c++) (sb + c * Q3)[vs] = sto[c];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 9; c++) dv[c] = 0.;
+      }
+      // refill this register set for the round NSET further down the stream (this group or the next)
+      if (r + NSET < RQ) load_point(qd[r % NSET], st[r % NSET], grp, r + NSET);
+      else load_point(qd[r % NSET], st[r % NSET], g_nx, r + NSET - RQ);
+      if (okp) {
+        lds_wr<oBX + 0 * BC>(aPt[r], dv[0]); lds_wr<oBX + 1 * BC>(aPt[r], dv[1]); lds_wr<oBX + 2 * BC>(aPt[r], dv[2]);
+        lds_wr<oA + 0 * BC>(aPt[r], dv[3]);  lds_wr<oA + 1 * BC>(aPt[r], dv[4]);  lds_wr<oA + 2 * BC>(aPt[r], dv[5]);
+        lds_wr<oBZ + 0 * BC>(aPt[r], dv[6]); lds_wr<oBZ + 1 * BC>(aPt[r], dv[7]); lds_wr<oBZ + 2 * BC>(aPt[r], dv[8]);
+      }
+    }
+
+    // ---- B1: W1 = Dx^T g0, BX in place ----------------------------------------------------------------
+    {
+      const ktab_t tD = ktab_fresh(ktD);
+      double in[R_IQ][Q];
+#pragma unroll
+      for (int r = 0; r < R_IQ; r++) if (task_ok(r, E * T_IQ)) pencil_ld<Q, BI, oBX>(aIQ[r], in[r]);
+      lds_wait();
+#pragma unroll
+      for (int r = 0; r < R_IQ; r++) if (task_ok(r, E * T_IQ)) {
+        lds_pin<Q>(in[r]);
+        double out[Q] = {};
+        pencil_mac<Q, Q, Q, true>(tD, in[r], out);
+        pencil_st<Q, BI, oBX>(aIQ[r], out);
+      }
+    }
+    // ---- B2: W2 = W1 + Dy^T g1, A in place ----------------------------------------------------------------
+    {
+      // two-input passes are software-pipelined over the rounds (round r+1's reads are issued before
+      // round r is computed; two rounds of inputs live instead of all): tasks are disjoint pencils,
+      // so a later round's reads may pass an earlier round's in-place writes
+      const ktab_t tD = ktab_fresh(ktD);
+      double in[2][Q], acc[2][Q];
+      if (task_ok(0, E * T_JQ)) { pencil_ld<Q, BJ, oA>(aJQ[0], in[0]); pencil_ld<Q, BJ, oBX>(aJQ[0], acc[0]); }
+#pragma unroll
+      for (int r = 0; r < R_JQ; r++) {
+        lds_wait();
+        if (r + 1 < R_JQ && task_ok(r + 1, E * T_JQ)) {
+          pencil_ld<Q, BJ, oA>(aJQ[r + 1], in[(r + 1) & 1]); pencil_ld<Q, BJ, oBX>(aJQ[r + 1], acc[(r + 1) & 1]);
+        }
+        if (task_ok(r, E * T_JQ)) {
+          lds_pin<Q>(in[r & 1]); lds_pin<Q>(acc[r & 1]);
+          pencil_mac<Q, Q, Q, true>(tD, in[r & 1], acc[r & 1]);
+          pencil_st<Q, BJ, oA>(aJQ[r], acc[r & 1]);
+        }
+      }
+    }
+    // ---- B3: along k: A[k<P] = B^T W2 + G^T g2 ----------------------------------------------------------
+    {
+      // two sweeps over the rounds so that only ONE coefficient table is live in SGPRs at a time
+      // (both = 100 SGPRs = guaranteed SGPR spills): B^T W2 into out[], then + G^T g2 and store
+      double out[R_K][P];
+      {
+        const ktab_t tB = ktab_fresh(ktB);
+        double in[2][Q];
+        if (task_ok(0, E * T_K)) pencil_ld<Q, BK, oA>(aK[0], in[0]);
+#pragma unroll
+        for (int r = 0; r < R_K; r++) {
+          if (r + 1 < R_K && task_ok(r + 1, E * T_K)) pencil_ld<Q, BK, oA>(aK[r + 1], in[(r + 1) & 1]);
+#pragma unroll
+          for (int m = 0; m < P; m++) out[r][m] = 0.;
+          if (task_ok(r, E * T_K)) pencil_mac<P, Q, P, true>(tB, in[r & 1], out[r]);
+        }
+      }
+      {
+        const ktab_t tG = ktab_fresh(ktG);
+        double in2[2][Q];
+        if (task_ok(0, E * T_K)) pencil_ld<Q, BK, oBZ>(aK[0], in2[0]);
+#pragma unroll
+        for (int r = 0; r < R_K; r++) {
+          if (r + 1 < R_K && task_ok(r + 1, E * T_K)) pencil_ld<Q, BK, oBZ>(aK[r + 1], in2[(r + 1) & 1]);
+          if (task_ok(r, E * T_K)) {
+            pencil_mac<P, Q, P, true>(tG, in2[r & 1], out[r]);
+            pencil_st<P, BK, oA>(aK[r], out[r]);
+          }
+        }
+      }
+    }
+    load_x(off_nx, xin);  // next group's x (its offsets landed long ago): issued this late so its 6 RN registers
+                          // are not live across the physics and the register-hungry passes; B4, B5, the
+                          // final store and the next gather's address work hide most of its latency
+    // ---- B4: along j ----------------------------------------------------------------------------------
+    {
+      const ktab_t tB = ktab_fresh(ktB);
+      double in[R_JP][Q];
+#pragma unroll
+      for (int r = 0; r < R_JP; r++) if (task_ok(r, E * T_JP)) pencil_ld<Q, BJ, oA>(aJP[r], in[r]);
+      lds_wait();
+#pragma unroll
+      for (int r = 0; r < R_JP; r++) if (task_ok(r, E * T_JP)) {
+        lds_pin<Q>(in[r]);
+        double out[P] = {};
+        pencil_mac<P, Q, P, true>(tB, in[r], out);
+        pencil_st<P, BJ, oA>(aJP[r], out);
+      }
+    }
+    // ---- B5: along i ----------------------------------------------------------------------------------
+    {
+      const ktab_t tB = ktab_fresh(ktB);
+      double in[R_IP][Q];
+#pragma unroll
+      for (int r = 0; r < R_IP; r++) if (task_ok(r, E * T_IP)) pencil_ld<Q, BI, oA>(aIP[r], in[r]);
+      lds_wait();
+#pragma unroll
+      for (int r = 0; r < R_IP; r++) if (task_ok(r, E * T_IP)) {
+        lds_pin<Q>(in[r]);
+        double out[P] = {};
+        pencil_mac<P, Q, P, true>(tB, in[r], out);
+        pencil_st<P, BI, oA>(aIP[r], out);
+      }
+    }
+    // ---- final: node owners -> E-vector (plain coalesced stores) or f64 atomics ---------------------------
+    {
+      double v[RN][3];
+#pragma unroll
+      for (int r = 0; r < RN; r++) if (task_ok(r, E * P3)) {
+        v[r][0] = lds_rd<oA + 0 * BC>(aNd[r]); v[r][1] = lds_rd<oA + 1 * BC>(aNd[r]); v[r][2] = lds_rd<oA + 2 * BC>(aNd[r]);
+      }
+      lds_wait();
+#pragma unroll
+      for (int r = 0; r < RN; r++) {
+        const int nel = el_of(lane + 64 * r, P3), nn = lane + 64 * r - nel * P3;
+        if (task_ok(r, E * P3) && grp * E + nel < a.nelem) {
+          lds_pin<3>(v[r]);
+          if (a.evec) {
+            double *eb = a.evec + (size_t)(a.elem_begin + grp * E) * (3 * P3);
+            const uint32_t ve = (uint32_t)((nel * P3 + nn) * 3);
+            eb[ve] = v[r][0]; (eb + 1)[ve] = v[r][1]; (eb + 2)[ve] = v[r][2];
+          } else {
+            const uint32_t base = off[r] & OFF_MASK;
+            const uint32_t fl = a.mask_out ? (off[r] >> OFF_FLAG_SHIFT) : 0u;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+              if (!((fl >> c) & 1u)) atomic_add_f64(a.y + base + c, v[r][c]);
+          }
+        }
+      }
+    }
+    if (!more) break;
+    grp = grp_nx;
+#pragma unroll
+    for (int r = 0; r < RN; r++) off[r] = off_nx[r];
+  }
+}
+
+template <int P, int Q> constexpr int pencil_waves_per_cu() {
+  constexpr int by_lds = (160 * 1024) / PencilGeom<P, Q>::LDS_BYTES;
+  return by_lds < 1 ? 1 : (by_lds > 8 ? 8 : by_lds);  // 8 waves per CU = 2 per SIMD at <= 256 VGPRs
+}
+
+template <int P, int Q, int QF>
+hipError_t launch_fused_pencil_t(const BasisTables &t, const FusedGradArgs &a, hipStream_t s) {
+  using G = PencilGeom<P, Q>;
+  if (a.nelem <= 0) return hipSuccess;
+  const int ngroups = (a.nelem + G::E - 1) / G::E;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    ncu = prop.multiProcessorCount;
+  }
+  static int wpc = 0;  // tuning hook: CEED_MI355X_PENCIL_WAVES=<persistent waves per CU>
+  if (!wpc) { const char *e = getenv("CEED_MI355X_PENCIL_WAVES"); wpc = e && atoi(e) > 0 ? atoi(e) : -1; }
+  int grid = ncu * (wpc > 0 ? wpc : pencil_waves_per_cu<P, Q>());
+  if (grid > ngroups) grid = ngroups;
+  hipLaunchKernelGGL((k_fused_pencil<P, Q, QF>), dim3(grid), dim3(64), 0, s, t, a);
+  return hipGetLastError();
+}
+
+}  // namespace cps

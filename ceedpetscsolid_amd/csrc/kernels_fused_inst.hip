@@ -7,6 +7,7 @@
 // use degrees 1, 2, 4 (logarithmic) with the FINE quadrature (setuplibceed.c:757).
 // Residual kernels (which write the stored state) only exist on the fine level.
 #include "kernel_fused_grad.hpp"
+#include "kernel_fused_pencil.hpp"
 
 #ifndef CPS_Q
 #error "compile with -DCPS_Q=<points per direction>"
@@ -21,12 +22,13 @@ namespace cps {
 
 template <int P, int QF>
 static hipError_t go(const BasisTables &t, const FusedGradArgs &a, hipStream_t s) {
-  return launch_fused_grad_t<P, CPS_Q, QF>(t, a, s);
+  return a.variant == 1 ? launch_fused_pencil_t<P, CPS_Q, QF>(t, a, s) : launch_fused_grad_t<P, CPS_Q, QF>(t, a, s);
 }
 
 #define CPS_CASE(Pv, QFv, QFname)                                                   \
   if (P == Pv && qf == QFv) {                                                       \
-    *name = "fused_grad<P=" #Pv ",Q=" CPS_STR(CPS_Q) "," QFname ">";                \
+    *name = a.variant == 1 ? "fused_grad<P=" #Pv ",Q=" CPS_STR(CPS_Q) "," QFname ">/pencil"   \
+                           : "fused_grad<P=" #Pv ",Q=" CPS_STR(CPS_Q) "," QFname ">";         \
     return go<Pv, QFv>(t, a, s);                                                    \
   }
 #define CPS_JACOBIANS(Pv)              \
