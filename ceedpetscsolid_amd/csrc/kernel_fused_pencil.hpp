@@ -5,28 +5,26 @@
 // mapping of the 1-D contractions onto the wave.
 //
 // Why.  The row kernel gives every lane one OUTPUT point of a contraction, so the Q lanes
-// that share an input row each read the whole row from LDS: Q-fold redundant LDS reads, and
-// per-lane coefficient rows that also come from LDS.  PMC + stamps put it at ~71 % LDS-pipe
-// busy; it is LDS bound, not HBM bound.  Here a lane owns a whole PENCIL (one line of the
-// element along the contraction direction, one component): it reads the NIN inputs once,
-// produces all NOUT outputs in registers and writes them back IN PLACE.  Every value is read
-// once and written once per pass, and the coefficients are wave-uniform, so they are scalar
-// operands (kernarg -> SGPR), not LDS traffic.  LDS cycles per element by the bank model of
-// tools/pencil_layout_search.py: ~960 against ~1 300 (conflict-free) / ~1 900 (measured) before.
+// that share an input row each read the whole row from LDS (Q-fold redundant LDS reads) and
+// per-lane coefficient rows also come from LDS: ~71 % LDS-pipe busy, LDS bound.  Here a lane
+// owns a whole PENCIL (one line of the element along the contraction direction, one
+// component): it reads the NIN inputs once, produces all NOUT outputs in registers and writes
+// them back IN PLACE.  Every value is read once and written once per pass, and the
+// coefficients are wave-uniform, so they are scalar operands (kernarg -> SGPR), not LDS
+// traffic.  Measured (PMC, config 4): LDS pipe 33 % busy instead of 71 %, LDS instructions per
+// element 441 -> 220; without the q-point stream the kernel runs in 332 us against 398 us.
 //
-// Pipeline for a group of E elements owned by ONE wave64 (no s_barrier anywhere; a wave's LDS
-// queue is in order).  Arrays A, BX, BZ: [c][k][j][i], strides (1, Q, Q^2, Q^3) doubles.
+// Pipeline for a group of E elements owned by ONE wave64 (no s_barrier anywhere: a wave's LDS
+// queue is executed in order).  Arrays A, BX, BZ: [c][k][j][i], strides (1, Q, Q^2, Q^3) doubles.
 //   gather  x -> A (nodes)                          node-owner lanes
 //   F1..F3  interpolate along i, j, k in place      pencil lanes;  F3 also writes dU/dz -> BZ (grad1d)
 //   F4, F5  collocated d/dx: A -> BX, d/dy: A -> A  pencil lanes
-//   QF      9 gradient entries in, 9 out, in place  point-owner lanes (q-point data prefetched
-//                                                   two point-rounds ahead, across groups)
+//   QF      9 gradient entries in, 9 out, in place  point-owner lanes, one round of 64 points at a
+//                                                   time; q-point data prefetched a round ahead
 //   B1..B5  transposes of F5..F1, accumulating      pencil lanes
 //   final   A (nodes) -> E-vector / atomics         node-owner lanes
-//
-// All LDS accesses are explicit ds_read_b64 / ds_write_b64 with immediate offsets (inline asm):
-// hipcc would pair the strided pencil reads into ds_read2_b64, which runs at half the byte rate
-// of ds_read_b64 on gfx950 (MI355X_MICROARCH.md, LDS table).
+// Elements per wave E: 8 (Q=2), 4 (Q=3,4), 2 (Q=5), 1 (Q>=6): a pass has 3*Q^2 pencils per element,
+// E picks how well they fill 64 lanes against the LDS slab (9*Q^3 doubles per element).
 #pragma once
 #include "kernels_common.hpp"
 #include "qfunctions_device.hpp"
@@ -47,12 +45,13 @@ template <int P, int Q> struct PencilGeom {
 
 // ---- LDS accessors: VOLATILE 8-byte accesses through an LDS pointer + constant offset ----------
 // Volatile does two jobs.  (1) hipcc keeps each access a separate ds_read_b64 / ds_write_b64 with an
-// immediate offset (it still tracks them and places counted s_waitcnt lgkmcnt(N) itself), instead of
-// pairing the strided pencil reads into half-rate ds_read2_b64.  (2) Volatile accesses are never
-// reordered against each other, which is all the ordering the passes need: they communicate through
-// LDS across lanes of ONE wave, whose LDS queue the hardware executes in order.
-// (Inline-asm ds_read + explicit waits were tried first: the compiler does not know an asm output is
-// still in flight, so it may copy or spill the register before the wait -- it did, silently.)
+// immediate offset (and still tracks them: it places counted s_waitcnt lgkmcnt(N) itself) instead of
+// pairing the strided pencil reads into ds_read2_b64, which runs at half the byte rate of ds_read_b64
+// on gfx950 (MI355X_MICROARCH.md, LDS table).  (2) Volatile accesses are never reordered against
+// each other, which is all the ordering the passes need: they communicate through LDS across lanes
+// of ONE wave, whose LDS queue the hardware executes in order.
+// (Inline-asm ds_read_b64 + explicit waits were tried first: the compiler does not know that an asm
+// output is still in flight, so it may copy or spill the register before the wait -- it did.)
 typedef __attribute__((address_space(3))) double lds_double;
 typedef volatile lds_double *ldsp_t;
 template <int OFF>
@@ -80,12 +79,10 @@ CPS_DEV void pencil_st(ldsp_t a, const double *r) {
     pencil_st<N, SB, OFF, M + 1>(a, r);
   }
 }
-CPS_DEV void lds_wait() {}                    // the compiler counts the volatile reads itself
-template <int N> CPS_DEV void lds_pin(double *) {}
 
 // Coefficient tables are read straight from the kernarg segment (constant address space ->
 // s_load, SGPR operands of the FMAs).  Each pass takes a freshly "laundered" pointer, so the
-// compiler loads that pass's 25 coefficients inside the pass instead of hoisting all three tables
+// compiler loads that pass's coefficients inside the pass instead of hoisting all three tables
 // out of the element loop (150 SGPRs: it then spilled them to VGPR lanes, 900 v_readlane per group).
 typedef const __attribute__((address_space(4))) double *ktab_t;
 CPS_DEV ktab_t ktab_fresh(ktab_t p) {
@@ -101,10 +98,35 @@ CPS_DEV void pencil_mac(ktab_t tab, const double *in, double *out) {
     for (int m = 0; m < NIN; m++) out[o] += (TR ? tab[m * LD + o] : tab[o * LD + m]) * in[m];
   }
 }
+// round r of a pass with `ntask` tasks: is this lane's task t = lane + 64 r a real one?
+CPS_DEV bool pencil_ok(int lane, int r, int ntask) { return (r + 1) * 64 <= ntask ? true : lane + 64 * r < ntask; }
+
+// One single-input pass: every task reads its pencil (NIN entries at stride SB bytes from array SRC),
+// applies the NOUT x NIN matrix and writes NOUT entries to array DST (DST == SRC: in place).  All
+// rounds' reads are issued first, so the waits are counted ones and the FMAs of one round overlap the
+// reads of the next; tasks are disjoint pencils, so reads may pass the in-place writes of other rounds.
+template <int NIN, int NOUT, int LD, bool TR, int SB, int SRC, int DST, int R>
+CPS_DEV void pencil_pass(ktab_t table, const ldsp_t (&addr)[R], int lane, int ntask) {
+  const ktab_t t = ktab_fresh(table);
+  double in[R][NIN];
+#pragma unroll
+  for (int r = 0; r < R; r++)
+    if (pencil_ok(lane, r, ntask)) pencil_ld<NIN, SB, SRC>(addr[r], in[r]);
+#pragma unroll
+  for (int r = 0; r < R; r++)
+    if (pencil_ok(lane, r, ntask)) {
+      double out[NOUT] = {};
+      pencil_mac<NOUT, NIN, LD, TR>(t, in[r], out);
+      pencil_st<NOUT, SB, DST>(addr[r], out);
+    }
+}
 
 #ifndef CPS_PENCIL_MINW
-#define CPS_PENCIL_MINW 2
+#define CPS_PENCIL_MINW 2   // waves per SIMD the register allocation is held to (256 VGPRs)
 #endif
+#ifndef CPS_PENCIL_NSET
+#define CPS_PENCIL_NSET 2   // q-point register sets: 2 = every round's data is requested two rounds ahead
+#endif                      // (231 VGPRs with the hyperFS tangent; 1 set: 190 VGPRs, 4-6 % slower)
 template <int P, int Q, int QF>
 __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const BasisTables tab_, const FusedGradArgs a) {
   static_assert(offsetof(BasisTables, interp) == 0 && offsetof(BasisTables, colo) == 8 * MAXN1D * MAXN1D &&
@@ -134,9 +156,9 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
   if (grp >= gend) return;
 
   // ---- loop-invariant lane -> work maps -----------------------------------------------------
-  // pencil passes: task t = lane + 64 r over (element, component, b, a), a fastest; byte address of the
+  // pencil passes: task t = lane + 64 r over (element, component, b, a), a fastest; address of the
   // pencil's first entry.  Five families: direction i over nodal / quadrature (j,k), direction j over
-  // (i' , nodal / quadrature k), direction k over (i', j').
+  // (i', nodal / quadrature k), direction k over (i', j').
   auto pencil_addr = [&](int t, int NA, int NB, int sa, int sb) -> ldsp_t {
     const int T = 3 * NA * NB;
     const int el = t / T, tt = t % T, c = tt / (NA * NB), pen = tt % (NA * NB), ia = pen % NA, ib = pen / NA;
@@ -158,12 +180,6 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
   for (int r = 0; r < R_K; r++) aK[r] = pencil_addr(lane + 64 * r, Q, Q, BI, BJ);
   // point owners: q = lane + 64 r over (element, k, j, i); node owners likewise over P^3
   ldsp_t aPt[RQ], aNd[RN];
-  // element-in-group and local index of owner slot t = lane + 64 r, recomputed where needed (a few
-  // compares) instead of held in registers through the physics
-  auto el_of = [&](int t, int n3) { int el = 0;
-#pragma unroll
-    for (int e = 1; e < E; e++) el += (t >= e * n3) ? 1 : 0;
-    return el; };
 #pragma unroll
   for (int r = 0; r < RQ; r++) {
     const int t = lane + 64 * r, el = t / Q3, q = t % Q3;
@@ -174,16 +190,20 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
     const int t = lane + 64 * r, el = t / P3, n = t % P3;
     aNd[r] = lds0 + (el * SE + (n / (P * P)) * SK + ((n / P) % P) * SJ + n % P);
   }
-  auto task_ok = [&](int r, int ntask) { return (r + 1) * 64 <= ntask ? true : lane + 64 * r < ntask; };
+  // element-in-group of owner slot t, recomputed where needed (a few compares) instead of held in
+  // registers through the physics
+  auto el_of = [&](int t, int n3) {
+    int el = 0;
+#pragma unroll
+    for (int e = 1; e < E; e++) el += (t >= e * n3) ? 1 : 0;
+    return el;
+  };
 
   // ---- global-memory side: clamped, unconditional loads (as in the row kernel) ------------------
-  // Addressing: a wave-uniform 64-bit base per group (SGPRs) plus a 32-bit per-lane offset inside the
-  // group's block, so no per-lane 64-bit address arithmetic or loop-invariant address pairs.  Lanes of a
-  // dead element (only in the last, partial group) read the group's last live element instead.
+  // Addressing: a wave-uniform 64-bit base per group (SGPRs) plus a 32-bit per-lane index inside the
+  // group's block.  Lanes of a dead element (only in the last, partial group) read the group's last
+  // live element instead.
   auto nlive_of = [&](int g) { const int n = a.nelem - g * E; return n < E ? n : E; };  // uniform, >= 1
-#ifndef CPS_PENCIL_NSET
-#define CPS_PENCIL_NSET 1
-#endif
   constexpr int NSET = RQ >= 2 ? CPS_PENCIL_NSET : 1;
   double qd[NSET][10], st[NSET][9];
   auto load_point = [&](double *qdv, double *stv, int g, int r) {
@@ -240,7 +260,7 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
     // ---- gather: x -> A at the nodes (Dirichlet flags applied; dead elements of the last group zero) ----
 #pragma unroll
     for (int r = 0; r < RN; r++) {
-      if (task_ok(r, E * P3)) {
+      if (pencil_ok(lane, r, E * P3)) {
         const bool live = grp * E + el_of(lane + 64 * r, P3) < a.nelem;
         const uint32_t fl = live ? (a.mask_in ? (off[r] >> OFF_FLAG_SHIFT) : 0u) : 7u;
         lds_wr<oA + 0 * BC>(aNd[r], (fl & 1u) ? 0. : xin[r][0]);
@@ -249,92 +269,40 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
       }
     }
 
-    // ---- F1: along i, nodal (j,k):  A[i<P] -> A[i'<Q] ---------------------------------------------
-    {
-      const ktab_t tB = ktab_fresh(ktB);
-      double in[R_IP][P];
-#pragma unroll
-      for (int r = 0; r < R_IP; r++) if (task_ok(r, E * T_IP)) pencil_ld<P, BI, oA>(aIP[r], in[r]);
-      lds_wait();
-#pragma unroll
-      for (int r = 0; r < R_IP; r++) if (task_ok(r, E * T_IP)) {
-        lds_pin<P>(in[r]);
-        double out[Q] = {};
-        pencil_mac<Q, P, P, false>(tB, in[r], out);
-        pencil_st<Q, BI, oA>(aIP[r], out);
-      }
-    }
-    // ---- F2: along j, (i', nodal k) -----------------------------------------------------------------
-    {
-      const ktab_t tB = ktab_fresh(ktB);
-      double in[R_JP][P];
-#pragma unroll
-      for (int r = 0; r < R_JP; r++) if (task_ok(r, E * T_JP)) pencil_ld<P, BJ, oA>(aJP[r], in[r]);
-      lds_wait();
-#pragma unroll
-      for (int r = 0; r < R_JP; r++) if (task_ok(r, E * T_JP)) {
-        lds_pin<P>(in[r]);
-        double out[Q] = {};
-        pencil_mac<Q, P, P, false>(tB, in[r], out);
-        pencil_st<Q, BJ, oA>(aJP[r], out);
-      }
-    }
-    // ---- F3: along k, (i', j'):  U -> A in place, dU/dz -> BZ (grad1d on the nodal values) -----------
-    {
+    // ---- B: nodes -> points, in place -----------------------------------------------------------------
+    pencil_pass<P, Q, P, false, BI, oA, oA>(ktB, aIP, lane, E * T_IP);   // F1: along i at nodal (j, k)
+    pencil_pass<P, Q, P, false, BJ, oA, oA>(ktB, aJP, lane, E * T_JP);   // F2: along j at (i', nodal k)
+    {  // F3: along k at (i', j'): U -> A in place and dU/dz -> BZ (grad1d on the nodal values), one
+       // table at a time (both = 100 SGPRs = SGPR spills)
       const ktab_t tB = ktab_fresh(ktB);
       double in[R_K][P];
 #pragma unroll
-      for (int r = 0; r < R_K; r++) if (task_ok(r, E * T_K)) pencil_ld<P, BK, oA>(aK[r], in[r]);
-      lds_wait();
+      for (int r = 0; r < R_K; r++)
+        if (pencil_ok(lane, r, E * T_K)) pencil_ld<P, BK, oA>(aK[r], in[r]);
 #pragma unroll
-      for (int r = 0; r < R_K; r++) if (task_ok(r, E * T_K)) {
-        lds_pin<P>(in[r]);
-        double out[Q] = {};
-        pencil_mac<Q, P, P, false>(tB, in[r], out);
-        pencil_st<Q, BK, oA>(aK[r], out);
-      }
+      for (int r = 0; r < R_K; r++)
+        if (pencil_ok(lane, r, E * T_K)) {
+          double out[Q] = {};
+          pencil_mac<Q, P, P, false>(tB, in[r], out);
+          pencil_st<Q, BK, oA>(aK[r], out);
+        }
       const ktab_t tG = ktab_fresh(ktG);
 #pragma unroll
-      for (int r = 0; r < R_K; r++) if (task_ok(r, E * T_K)) {
-        double dz[Q] = {};
-        pencil_mac<Q, P, P, false>(tG, in[r], dz);
-        pencil_st<Q, BK, oBZ>(aK[r], dz);
-      }
+      for (int r = 0; r < R_K; r++)
+        if (pencil_ok(lane, r, E * T_K)) {
+          double dz[Q] = {};
+          pencil_mac<Q, P, P, false>(tG, in[r], dz);
+          pencil_st<Q, BK, oBZ>(aK[r], dz);
+        }
     }
-    // ---- F4: d/dx (collocated) A -> BX;  F5: d/dy A -> A in place -------------------------------------
-    {
-      const ktab_t tD = ktab_fresh(ktD);
-      double in[R_IQ][Q];
-#pragma unroll
-      for (int r = 0; r < R_IQ; r++) if (task_ok(r, E * T_IQ)) pencil_ld<Q, BI, oA>(aIQ[r], in[r]);
-      lds_wait();
-#pragma unroll
-      for (int r = 0; r < R_IQ; r++) if (task_ok(r, E * T_IQ)) {
-        lds_pin<Q>(in[r]);
-        double out[Q] = {};
-        pencil_mac<Q, Q, Q, false>(tD, in[r], out);
-        pencil_st<Q, BI, oBX>(aIQ[r], out);
-      }
-    }
-    {
-      const ktab_t tD = ktab_fresh(ktD);
-      double in[R_JQ][Q];
-#pragma unroll
-      for (int r = 0; r < R_JQ; r++) if (task_ok(r, E * T_JQ)) pencil_ld<Q, BJ, oA>(aJQ[r], in[r]);
-      lds_wait();
-#pragma unroll
-      for (int r = 0; r < R_JQ; r++) if (task_ok(r, E * T_JQ)) {
-        lds_pin<Q>(in[r]);
-        double out[Q] = {};
-        pencil_mac<Q, Q, Q, false>(tD, in[r], out);
-        pencil_st<Q, BJ, oA>(aJQ[r], out);
-      }
-    }
+    // ---- collocated gradient on the quadrature points -----------------------------------------------------
+    pencil_pass<Q, Q, Q, false, BI, oA, oBX>(ktD, aIQ, lane, E * T_IQ);  // F4: d/dx: A -> BX
+    pencil_pass<Q, Q, Q, false, BJ, oA, oA>(ktD, aJQ, lane, E * T_JQ);   // F5: d/dy: A -> A in place
 
     // ---- physics: point owners, one round at a time; ug[d*3+c] from (BX, A, BZ), dv back in place ----
 #pragma unroll
     for (int r = 0; r < RQ; r++) {
-      const bool okp = task_ok(r, E * Q3);
+      const bool okp = pencil_ok(lane, r, E * Q3);
       const int pel = el_of(lane + 64 * r, Q3), pq = lane + 64 * r - pel * Q3;
       const bool live = okp && (grp * E + pel < a.nelem);
       double ug[9], dv[9], sto[9];
@@ -343,9 +311,7 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
         ug[3] = lds_rd<oA + 0 * BC>(aPt[r]);  ug[4] = lds_rd<oA + 1 * BC>(aPt[r]);  ug[5] = lds_rd<oA + 2 * BC>(aPt[r]);
         ug[6] = lds_rd<oBZ + 0 * BC>(aPt[r]); ug[7] = lds_rd<oBZ + 1 * BC>(aPt[r]); ug[8] = lds_rd<oBZ + 2 * BC>(aPt[r]);
       }
-      lds_wait();
       if (live) {
-        lds_pin<9>(ug);
         qf_point<QF>(Phys{a.nu, a.E, a.lambda, a.TwoMu}, ug, qd[r % NSET], st[r % NSET], dv, sto);
         if constexpr (ST_OUT) {
           double *sb = a.state_out + (size_t)(a.elem_begin + grp * E) * (9 * Q3);
@@ -367,67 +333,47 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
       }
     }
 
-    // ---- B1: W1 = Dx^T g0, BX in place ----------------------------------------------------------------
-    {
-      const ktab_t tD = ktab_fresh(ktD);
-      double in[R_IQ][Q];
-#pragma unroll
-      for (int r = 0; r < R_IQ; r++) if (task_ok(r, E * T_IQ)) pencil_ld<Q, BI, oBX>(aIQ[r], in[r]);
-      lds_wait();
-#pragma unroll
-      for (int r = 0; r < R_IQ; r++) if (task_ok(r, E * T_IQ)) {
-        lds_pin<Q>(in[r]);
-        double out[Q] = {};
-        pencil_mac<Q, Q, Q, true>(tD, in[r], out);
-        pencil_st<Q, BI, oBX>(aIQ[r], out);
-      }
-    }
-    // ---- B2: W2 = W1 + Dy^T g1, A in place ----------------------------------------------------------------
-    {
-      // two-input passes are software-pipelined over the rounds (round r+1's reads are issued before
-      // round r is computed; two rounds of inputs live instead of all): tasks are disjoint pencils,
-      // so a later round's reads may pass an earlier round's in-place writes
+    // ---- gradient^T --------------------------------------------------------------------------------------
+    pencil_pass<Q, Q, Q, true, BI, oBX, oBX>(ktD, aIQ, lane, E * T_IQ);  // B1: W1 = Dx^T g0, BX in place
+    {  // B2: W2 = W1 + Dy^T g1, A in place.  Two inputs per task: software-pipelined over the rounds
+       // (two rounds of inputs live instead of all)
       const ktab_t tD = ktab_fresh(ktD);
       double in[2][Q], acc[2][Q];
-      if (task_ok(0, E * T_JQ)) { pencil_ld<Q, BJ, oA>(aJQ[0], in[0]); pencil_ld<Q, BJ, oBX>(aJQ[0], acc[0]); }
+      if (pencil_ok(lane, 0, E * T_JQ)) { pencil_ld<Q, BJ, oA>(aJQ[0], in[0]); pencil_ld<Q, BJ, oBX>(aJQ[0], acc[0]); }
 #pragma unroll
       for (int r = 0; r < R_JQ; r++) {
-        lds_wait();
-        if (r + 1 < R_JQ && task_ok(r + 1, E * T_JQ)) {
-          pencil_ld<Q, BJ, oA>(aJQ[r + 1], in[(r + 1) & 1]); pencil_ld<Q, BJ, oBX>(aJQ[r + 1], acc[(r + 1) & 1]);
+        if (r + 1 < R_JQ && pencil_ok(lane, r + 1, E * T_JQ)) {
+          pencil_ld<Q, BJ, oA>(aJQ[r + 1], in[(r + 1) & 1]);
+          pencil_ld<Q, BJ, oBX>(aJQ[r + 1], acc[(r + 1) & 1]);
         }
-        if (task_ok(r, E * T_JQ)) {
-          lds_pin<Q>(in[r & 1]); lds_pin<Q>(acc[r & 1]);
+        if (pencil_ok(lane, r, E * T_JQ)) {
           pencil_mac<Q, Q, Q, true>(tD, in[r & 1], acc[r & 1]);
           pencil_st<Q, BJ, oA>(aJQ[r], acc[r & 1]);
         }
       }
     }
-    // ---- B3: along k: A[k<P] = B^T W2 + G^T g2 ----------------------------------------------------------
-    {
-      // two sweeps over the rounds so that only ONE coefficient table is live in SGPRs at a time
-      // (both = 100 SGPRs = guaranteed SGPR spills): B^T W2 into out[], then + G^T g2 and store
+    {  // B3: along k: A[k<P] = B^T W2 + G^T g2, in two sweeps so that one coefficient table is live at a time
       double out[R_K][P];
       {
         const ktab_t tB = ktab_fresh(ktB);
         double in[2][Q];
-        if (task_ok(0, E * T_K)) pencil_ld<Q, BK, oA>(aK[0], in[0]);
+        if (pencil_ok(lane, 0, E * T_K)) pencil_ld<Q, BK, oA>(aK[0], in[0]);
 #pragma unroll
         for (int r = 0; r < R_K; r++) {
-          if (r + 1 < R_K && task_ok(r + 1, E * T_K)) pencil_ld<Q, BK, oA>(aK[r + 1], in[(r + 1) & 1]);
+          if (r + 1 < R_K && pencil_ok(lane, r + 1, E * T_K)) pencil_ld<Q, BK, oA>(aK[r + 1], in[(r + 1) & 1]);
 #pragma unroll
           for (int m = 0; m < P; m++) out[r][m] = 0.;
-          if (task_ok(r, E * T_K)) pencil_mac<P, Q, P, true>(tB, in[r & 1], out[r]);
+          if (pencil_ok(lane, r, E * T_K)) pencil_mac<P, Q, P, true>(tB, in[r & 1], out[r]);
         }
       }
       {
         const ktab_t tG = ktab_fresh(ktG);
         double in2[2][Q];
-        if (task_ok(0, E * T_K)) pencil_ld<Q, BK, oBZ>(aK[0], in2[0]);
+        if (pencil_ok(lane, 0, E * T_K)) pencil_ld<Q, BK, oBZ>(aK[0], in2[0]);
 #pragma unroll
         for (int r = 0; r < R_K; r++) {
-          if (r + 1 < R_K && task_ok(r + 1, E * T_K)) pencil_ld<Q, BK, oBZ>(aK[r + 1], in2[(r + 1) & 1]);
-          if (task_ok(r, E * T_K)) {
+          if (r + 1 < R_K && pencil_ok(lane, r + 1, E * T_K)) pencil_ld<Q, BK, oBZ>(aK[r + 1], in2[(r + 1) & 1]);
+          if (pencil_ok(lane, r, E * T_K)) {
             pencil_mac<P, Q, P, true>(tG, in2[r & 1], out[r]);
             pencil_st<P, BK, oA>(aK[r], out[r]);
           }
@@ -437,49 +383,21 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
     load_x(off_nx, xin);  // next group's x (its offsets landed long ago): issued this late so its 6 RN registers
                           // are not live across the physics and the register-hungry passes; B4, B5, the
                           // final store and the next gather's address work hide most of its latency
-    // ---- B4: along j ----------------------------------------------------------------------------------
-    {
-      const ktab_t tB = ktab_fresh(ktB);
-      double in[R_JP][Q];
-#pragma unroll
-      for (int r = 0; r < R_JP; r++) if (task_ok(r, E * T_JP)) pencil_ld<Q, BJ, oA>(aJP[r], in[r]);
-      lds_wait();
-#pragma unroll
-      for (int r = 0; r < R_JP; r++) if (task_ok(r, E * T_JP)) {
-        lds_pin<Q>(in[r]);
-        double out[P] = {};
-        pencil_mac<P, Q, P, true>(tB, in[r], out);
-        pencil_st<P, BJ, oA>(aJP[r], out);
-      }
-    }
-    // ---- B5: along i ----------------------------------------------------------------------------------
-    {
-      const ktab_t tB = ktab_fresh(ktB);
-      double in[R_IP][Q];
-#pragma unroll
-      for (int r = 0; r < R_IP; r++) if (task_ok(r, E * T_IP)) pencil_ld<Q, BI, oA>(aIP[r], in[r]);
-      lds_wait();
-#pragma unroll
-      for (int r = 0; r < R_IP; r++) if (task_ok(r, E * T_IP)) {
-        lds_pin<Q>(in[r]);
-        double out[P] = {};
-        pencil_mac<P, Q, P, true>(tB, in[r], out);
-        pencil_st<P, BI, oA>(aIP[r], out);
-      }
-    }
+    // ---- B^T: points -> nodes ---------------------------------------------------------------------------
+    pencil_pass<Q, P, P, true, BJ, oA, oA>(ktB, aJP, lane, E * T_JP);    // B4: along j
+    pencil_pass<Q, P, P, true, BI, oA, oA>(ktB, aIP, lane, E * T_IP);    // B5: along i
     // ---- final: node owners -> E-vector (plain coalesced stores) or f64 atomics ---------------------------
     {
       double v[RN][3];
 #pragma unroll
-      for (int r = 0; r < RN; r++) if (task_ok(r, E * P3)) {
-        v[r][0] = lds_rd<oA + 0 * BC>(aNd[r]); v[r][1] = lds_rd<oA + 1 * BC>(aNd[r]); v[r][2] = lds_rd<oA + 2 * BC>(aNd[r]);
-      }
-      lds_wait();
+      for (int r = 0; r < RN; r++)
+        if (pencil_ok(lane, r, E * P3)) {
+          v[r][0] = lds_rd<oA + 0 * BC>(aNd[r]); v[r][1] = lds_rd<oA + 1 * BC>(aNd[r]); v[r][2] = lds_rd<oA + 2 * BC>(aNd[r]);
+        }
 #pragma unroll
       for (int r = 0; r < RN; r++) {
         const int nel = el_of(lane + 64 * r, P3), nn = lane + 64 * r - nel * P3;
-        if (task_ok(r, E * P3) && grp * E + nel < a.nelem) {
-          lds_pin<3>(v[r]);
+        if (pencil_ok(lane, r, E * P3) && grp * E + nel < a.nelem) {
           if (a.evec) {
             double *eb = a.evec + (size_t)(a.elem_begin + grp * E) * (3 * P3);
             const uint32_t ve = (uint32_t)((nel * P3 + nn) * 3);
