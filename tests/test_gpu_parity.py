@@ -287,3 +287,38 @@ def test_apply_add_and_empty_vectors(gpu):
     assert rel_err(Y.to_numpy(), y0 + jx) < 1e-14
     e = gpu.vector(0)
     assert e.to_numpy().size == 0
+
+
+@pytest.mark.gpu
+def test_row_kernel_variant_matches_pencil_kernel(gpu, product_lib):
+    """Both generations of the fused kernel ship (CEED_MI355X_FUSED=rows selects the first); they must agree
+    to rounding on every level of a multigrid hierarchy (P < Q on the coarse levels) and both be reproducible."""
+    old = os.environ.get("CEED_MI355X_FUSED")
+    os.environ["CEED_MI355X_FUSED"] = "rows"
+    try:
+        rows = cd.Ceed(product_lib, "/gpu/hip/mi355x")      # the variant is read at CeedInit
+    finally:
+        if old is None:
+            os.environ.pop("CEED_MI355X_FUSED", None)
+        else:
+            os.environ["CEED_MI355X_FUSED"] = old
+    mesh = hollow_cylinder_mesh(2, 8, 3)
+    for problem in ("linElas", "hyperFS"):
+        ys = []
+        for c in (gpu, rows):
+            p = SolidProblem(c, mesh, 4, problem, nu=0.3, E=1e3, bc_sides=[998])
+            n = p.lsize()
+            X, R = c.vector(n), c.vector(n)
+            X.set_array(p.smooth_state(0.05)); p.form_residual(X, R)
+            out = [R.to_numpy()]
+            for lv in range(len(p.levels)):
+                nl = p.lsize(lv)
+                x = c.vector(nl).set_array(np.random.default_rng(lv).uniform(-1, 1, nl))
+                y1, y2 = c.vector(nl), c.vector(nl)
+                p.apply_jacobian(lv, x, y1); p.apply_jacobian(lv, x, y2)
+                assert np.array_equal(y1.to_numpy(), y2.to_numpy())
+                out.append(y1.to_numpy())
+            ys.append((out, p.levels[p.fine].opJacob.kernel_name))
+        assert ys[0][1].endswith("/pencil") and not ys[1][1].endswith("/pencil")
+        for a, b in zip(ys[0][0], ys[1][0]):
+            assert rel_err(a, b) < 1e-13
