@@ -308,9 +308,22 @@ __global__ void k_assemble(const uint32_t *rowptr, const uint32_t *cols, const u
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nnodes; r += gridDim.x * blockDim.x) {
     const uint32_t k0 = rowptr[r], k1 = rowptr[r + 1];
     double a0 = 0., a1 = 0., a2 = 0.;
-    for (uint32_t k = k0; k < k1; k++) {
-      const double *p = evec + (size_t)cols[k] * 3;
-      a0 += p[0]; a1 += p[1]; a2 += p[2];
+    // four contributors per trip: the index loads, then the twelve value loads, are issued together (the
+    // chain rowptr -> cols -> E-vector is latency bound otherwise); lanes with fewer contributors re-read
+    // their last one and discard it.  Sums are still formed in contributor (= element) order.
+    for (uint32_t k = k0; k < k1; k += 4) {
+      uint32_t c[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) c[j] = cols[k + j < k1 ? k + j : k1 - 1];
+      double v[4][3];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const double *p = evec + (size_t)c[j] * 3;
+        v[j][0] = p[0]; v[j][1] = p[1]; v[j][2] = p[2];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (k + j < k1) { a0 += v[j][0]; a1 += v[j][1]; a2 += v[j][2]; }
     }
     const unsigned fl = flags ? flags[r] : 0u;
     double *dst = y + (node_off[r] & OFF_MASK);
