@@ -67,6 +67,7 @@ class CeedLib:
         "CeedXOperatorSetFineScale", "CeedXOperatorSetOverlapSplit", "CeedXOperatorApplyPhase",
         "CeedXVectorPointwiseMult", "CeedXVectorAXPBY", "CeedXVectorDot", "CeedXVectorChebyshevUpdate",
         "CeedXGraphBeginCapture", "CeedXGraphEndCapture", "CeedXGraphLaunch", "CeedXGraphDestroy",
+        "CeedXCsrCreate", "CeedXCsrAssemble", "CeedXCsrApply", "CeedXCsrGetDiagonal", "CeedXCsrDestroy",
     ]
     DATA = [
         "CeedMemTypes", "CEED_VECTOR_ACTIVE", "CEED_VECTOR_NONE", "CEED_ELEMRESTRICTION_NONE",
@@ -113,6 +114,34 @@ class CeedLib:
 
 def _np_f64(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Csr:
+    """Assembled sparse operator on L-vectors (CeedXCsr*): the coarse multigrid level."""
+
+    def __init__(self, ceed: "Ceed", rowptr, cols, coo_slot, unit_rows=()):
+        self.L = ceed.L
+        self.h = C.c_void_p()
+        rp = np.ascontiguousarray(rowptr, dtype=np.int32); cl = np.ascontiguousarray(cols, dtype=np.int32)
+        sl = np.ascontiguousarray(coo_slot, dtype=np.int32); ur = np.ascontiguousarray(unit_rows, dtype=np.int32)
+        self.nrows, self.nnz, self.ncoo = rp.size - 1, int(rp[-1]), sl.size
+        self.L.chk(self.L.lib.CeedXCsrCreate(ceed.h, c_int(self.nrows), rp.ctypes.data_as(c_int_p), cl.ctypes.data_as(c_int_p),
+                                             c_int(sl.size), sl.ctypes.data_as(c_int_p), c_int(ur.size),
+                                             ur.ctypes.data_as(c_int_p), C.byref(self.h)))
+
+    def assemble(self, coo_values: "Vector"):
+        self.L.chk(self.L.lib.CeedXCsrAssemble(self.h, coo_values.h))
+
+    def apply(self, x: "Vector", y: "Vector"):
+        self.L.chk(self.L.lib.CeedXCsrApply(self.h, x.h, y.h))
+
+    def diagonal(self, d: "Vector"):
+        self.L.chk(self.L.lib.CeedXCsrGetDiagonal(self.h, d.h))
+
+    def destroy(self):
+        if self.h:
+            self.L.lib.CeedXCsrDestroy(C.byref(self.h))
+            self.h = None
 
 
 class Graph:

@@ -1207,3 +1207,94 @@ extern "C" int CeedXVectorDot(CeedVector x, CeedVector y, CeedVector weight, dou
   *result = *x->ceed->h_scalar;
   return 0;
 }
+
+// ---------------------------------------------------------------------------
+// Assembled sparse operator (coarse multigrid level; misc.c:151-183, elasticity.c:457-483)
+// ---------------------------------------------------------------------------
+struct CeedXCsr_private {
+  Ceed ceed = nullptr;
+  int nrows = 0, nnz = 0, ncoo = 0, n_unit = 0;
+  uint32_t *d_rowptr = nullptr, *d_cols = nullptr, *d_slotptr = nullptr, *d_perm = nullptr, *d_unit_slot = nullptr,
+           *d_diag_slot = nullptr;
+  double *d_vals = nullptr;
+};
+template <class T>
+static int csr_upload(uint32_t **dst, const std::vector<T> &v) {
+  HIPCHK(hipMalloc((void **)dst, sizeof(uint32_t) * (v.size() ? v.size() : 1)));
+  if (!v.empty()) HIPCHK(hipMemcpy(*dst, v.data(), sizeof(uint32_t) * v.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+extern "C" int CeedXCsrCreate(Ceed ceed, CeedInt nrows, const CeedInt *rowptr, const CeedInt *cols, CeedInt ncoo,
+                              const CeedInt *coo_slot, CeedInt n_unit, const CeedInt *unit_rows, CeedXCsr *csr) {
+  if (nrows < 0 || ncoo < 0 || !rowptr || (rowptr[nrows] > 0 && !cols)) return ceed_error("CeedXCsrCreate: bad pattern");
+  const int nnz = rowptr[nrows];
+  std::vector<uint32_t> rp(rowptr, rowptr + nrows + 1), cl(cols, cols + nnz), diag((size_t)nrows, 0xFFFFFFFFu);
+  for (int r = 0; r < nrows; r++) {
+    if (rowptr[r + 1] < rowptr[r]) return ceed_error("CeedXCsrCreate: rowptr not monotone");
+    for (int k = rowptr[r]; k < rowptr[r + 1]; k++) {
+      if (cols[k] < 0 || cols[k] >= nrows) return ceed_error("CeedXCsrCreate: column %d out of range in row %d", cols[k], r);
+      if (cols[k] == r) diag[r] = (uint32_t)k;
+    }
+  }
+  // transpose of coo_slot: for every CSR slot the COO entries it sums, ascending (counting sort keeps the order)
+  std::vector<uint32_t> slotptr((size_t)nnz + 1, 0u), perm;
+  size_t kept = 0;
+  for (int k = 0; k < ncoo; k++) {
+    if (coo_slot[k] >= nnz) return ceed_error("CeedXCsrCreate: COO entry %d maps to slot %d of %d", k, coo_slot[k], nnz);
+    if (coo_slot[k] >= 0) { slotptr[(size_t)coo_slot[k] + 1]++; kept++; }
+  }
+  for (int s = 0; s < nnz; s++) slotptr[s + 1] += slotptr[s];
+  perm.resize(kept ? kept : 1);
+  {
+    std::vector<uint32_t> cur(slotptr.begin(), slotptr.end() - 1);
+    for (int k = 0; k < ncoo; k++) if (coo_slot[k] >= 0) perm[cur[coo_slot[k]]++] = (uint32_t)k;
+  }
+  std::vector<uint32_t> unit;
+  for (int i = 0; i < n_unit; i++) {
+    if (unit_rows[i] < 0 || unit_rows[i] >= nrows || diag[unit_rows[i]] == 0xFFFFFFFFu)
+      return ceed_error("CeedXCsrCreate: unit row %d has no diagonal entry in the pattern", unit_rows[i]);
+    unit.push_back(diag[unit_rows[i]]);
+  }
+  CeedXCsr A = new CeedXCsr_private;
+  A->ceed = ceed; ceed_ref(ceed);
+  A->nrows = nrows; A->nnz = nnz; A->ncoo = ncoo; A->n_unit = n_unit;
+  CHK(csr_upload(&A->d_rowptr, rp)); CHK(csr_upload(&A->d_cols, cl)); CHK(csr_upload(&A->d_slotptr, slotptr));
+  CHK(csr_upload(&A->d_perm, perm)); CHK(csr_upload(&A->d_unit_slot, unit)); CHK(csr_upload(&A->d_diag_slot, diag));
+  HIPCHK(hipMalloc((void **)&A->d_vals, sizeof(double) * (nnz ? nnz : 1)));
+  HIPCHK(hipMemset(A->d_vals, 0, sizeof(double) * (nnz ? nnz : 1)));
+  *csr = A;
+  return 0;
+}
+extern "C" int CeedXCsrAssemble(CeedXCsr A, CeedVector coo_values) {
+  if (coo_values->length < A->ncoo) return ceed_error("CeedXCsrAssemble: %d COO values, %d expected", coo_values->length, A->ncoo);
+  double *pc;
+  CHK(vec_dev(coo_values, false, &pc));
+  HIPCHK(launch_csr_sum(A->d_slotptr, A->d_perm, pc, A->d_vals, A->nnz, A->d_unit_slot, A->n_unit, A->ceed->stream));
+  return 0;
+}
+extern "C" int CeedXCsrApply(CeedXCsr A, CeedVector x, CeedVector y) {
+  if (x == y) return ceed_error("CeedXCsrApply: in-place apply is not supported");
+  if (x->length < A->nrows || y->length < A->nrows) return ceed_error("CeedXCsrApply: vector shorter than the matrix");
+  double *px, *py;
+  CHK(vec_dev(x, false, &px)); CHK(vec_dev(y, true, &py));
+  HIPCHK(launch_csr_spmv(A->d_rowptr, A->d_cols, A->d_vals, px, py, A->nrows, A->ceed->stream));
+  return 0;
+}
+extern "C" int CeedXCsrGetDiagonal(CeedXCsr A, CeedVector d) {
+  if (d->length < A->nrows) return ceed_error("CeedXCsrGetDiagonal: vector shorter than the matrix");
+  double *pd;
+  CHK(vec_dev(d, true, &pd));
+  HIPCHK(launch_csr_diag(A->d_diag_slot, A->d_vals, pd, A->nrows, A->ceed->stream));
+  return 0;
+}
+extern "C" int CeedXCsrDestroy(CeedXCsr *csr) {
+  if (!csr || !*csr) return 0;
+  CeedXCsr A = *csr;
+  (void)hipStreamSynchronize(A->ceed->stream);
+  for (uint32_t *p : {A->d_rowptr, A->d_cols, A->d_slotptr, A->d_perm, A->d_unit_slot, A->d_diag_slot}) if (p) (void)hipFree(p);
+  if (A->d_vals) (void)hipFree(A->d_vals);
+  ceed_unref(A->ceed);
+  delete A;
+  *csr = nullptr;
+  return 0;
+}

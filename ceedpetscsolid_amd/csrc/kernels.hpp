@@ -96,6 +96,13 @@ hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const u
                            const unsigned char *flags, const double *evec, double *y, int nnodes, int P3,
                            int add, hipStream_t s);
 
+// Assembled coarse-level operator (kernels_csr.hip).
+hipError_t launch_csr_sum(const uint32_t *slotptr, const uint32_t *perm, const double *coo, double *vals, int nnz,
+                          const uint32_t *unit_diag_slot, int n_unit, hipStream_t s);
+hipError_t launch_csr_spmv(const uint32_t *rowptr, const uint32_t *cols, const double *vals, const double *x, double *y,
+                           int nrows, hipStream_t s);
+hipError_t launch_csr_diag(const uint32_t *diag_slot_of_row, const double *vals, double *d, int nrows, hipStream_t s);
+
 // Vector / restriction utilities.
 hipError_t launch_set_value(double *v, size_t n, double val, hipStream_t s);
 hipError_t launch_cheb_update(double *x, double *d, double *r, const double *t, const double *dinv, double c1, double c2,

@@ -58,6 +58,7 @@ class SolveStats:
     ksp_its: int = 0
     coarse_its: int = 0
     jacobian_applies: int = 0
+    coarse_spmv: int = 0
     residual_evals: int = 0
     seconds: float = 0.0
     increments: int = 0
@@ -92,8 +93,14 @@ class NewtonPMG:
         # estimates are known) into a hipGraph per Newton step and replay it per Krylov iteration;
         # needs the reduction-free Chebyshev coarse solver
         self.graph = bool(graph)
-        if self.graph and coarse != "chebyshev":
-            raise ValueError("graph=True needs coarse='chebyshev' (the CG coarse solve reads dot products on the host)")
+        if self.graph and coarse not in ("chebyshev", "assembled"):
+            raise ValueError("graph=True needs coarse='chebyshev' or 'assembled' (the CG coarse solve reads dot products on the host)")
+        # coarse="assembled": the same Chebyshev polynomial, but on the ASSEMBLED p=1 matrix (assembly.py): a
+        # coarse iteration is one SpMV on 81 entries per row instead of a matrix-free apply on the fine quadrature
+        self.asm = None
+        if coarse == "assembled" and len(prob.levels) > 1:
+            from .assembly import AssembledLevel
+            self.asm = AssembledLevel(prob, 0)
         self._pc_graph, self._pc_graph_io, self._pc_graph_counts, self._pc_warm = None, None, (0, 0), False
         self.ksp_rtol, self.snes_rtol, self.snes_maxit, self.verbose = ksp_rtol, snes_rtol, snes_maxit, verbose
         self.nlev = len(prob.levels)
@@ -141,6 +148,10 @@ class NewtonPMG:
 
     # ---- operators ---------------------------------------------------------------------------
     def A(self, lv, x, y):
+        if lv == 0 and self.asm is not None:
+            self.asm.apply(x, y)
+            self.stats.coarse_spmv += 1
+            return
         self.p.apply_jacobian(lv, x, y)
         self.stats.jacobian_applies += 1
 
@@ -174,6 +185,9 @@ class NewtonPMG:
     # ---- multigrid preconditioner ---------------------------------------------------------------
     def setup_preconditioner(self):
         """Per Newton step: diagonals (GetDiag_Ceed), Chebyshev eigenvalue estimates."""
+        if self.asm is not None:
+            self.asm.assemble()
+            self.stats.jacobian_applies += self.asm.nd
         for lv in range(self.nlev):
             w = self.w[lv]
             self.p.get_diag(lv, w["dinv"])
@@ -248,7 +262,7 @@ class NewtonPMG:
         if lv == 0:
             if self.nlev == 1:
                 self.chebyshev(0, b, x, self.smooth_its, True)
-            elif self.coarse == "chebyshev":
+            elif self.coarse in ("chebyshev", "assembled"):
                 self.chebyshev(0, b, x, self.coarse_cheb_its, True, 1.0 / self.coarse_cheb_ratio)
                 self.stats.coarse_its += self.coarse_cheb_its
             else:

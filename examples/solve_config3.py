@@ -27,7 +27,7 @@ ap.add_argument("--E", type=float, default=1e3)
 ap.add_argument("--nu", type=float, default=0.3)
 ap.add_argument("--oracle", action="store_true", help="TESTS ONLY: run the same solve on the CPU oracle")
 ap.add_argument("--verbose", action="store_true")
-ap.add_argument("--coarse", default="cg", choices=["cg", "chebyshev"])
+ap.add_argument("--coarse", default="cg", choices=["cg", "chebyshev", "assembled"])
 ap.add_argument("--graph", action="store_true", help="replay the V-cycle as a hipGraph")
 ap.add_argument("--coarse-cheb-its", type=int, default=40)
 ap.add_argument("--coarse-cheb-ratio", type=float, default=100.0)
@@ -52,7 +52,7 @@ u = solver.U.to_numpy().reshape(-1, 3)
 out = {"resource": ceed.resource, "problem": args.problem, "mesh": os.path.basename(args.mesh), "elements": mesh.nelem,
        "level_degrees": prob.degrees, "global_dofs_per_level": [prob.n_free(l) for l in range(len(prob.levels))],
        "translate_998": list(tr), "coarse_solver": args.coarse, "vcycle_graph": args.graph, "load_increments": st.increments, "converged": st.converged, "snes_its": st.newton_its, "ksp_its": st.ksp_its,
-       "coarse_cg_its": st.coarse_its, "jacobian_applies": st.jacobian_applies, "residual_evals": st.residual_evals,
+       "coarse_cg_its": st.coarse_its, "jacobian_applies": st.jacobian_applies, "residual_evals": st.residual_evals, "coarse_spmv": st.coarse_spmv,
        "setup_s": t_setup, "snes_solve_s": st.seconds,
        "MDoFs_per_s_in_SNES": 1e-6 * prob.n_free() * st.ksp_its / st.seconds,   # elasticity.c:755-764
        "max_abs_displacement": np.abs(u).max(axis=0).tolist(), "final_residual_norm": st.history[-1][4] if st.history else None}

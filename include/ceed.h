@@ -284,6 +284,26 @@ CEED_EXTERN int CeedXVectorDot(CeedVector x, CeedVector y,
 CEED_EXTERN int CeedXVectorChebyshevUpdate(CeedVector x, CeedVector d, CeedVector r,
                                            CeedVector t /* or NULL */, CeedVector dinv,
                                            double c1, double c2, int assign_x);
+/* Assembled sparse operator on L-vectors: the coarse level of the multigrid. */
+/* The reference builds it by finite-difference colouring of the p=1 operator */
+/* (misc.c:151-183, elasticity.c:457-483) and hands it to GAMG; here the      */
+/* caller supplies the sparsity pattern and, per Newton step, element-matrix  */
+/* entries in COO form (e.g. the outputs of the Jacobian operator on an       */
+/* element-discontinuous restriction applied to unit vectors).                */
+/*   rowptr[nrows+1], cols[nnz]: CSR pattern (host, copied).                  */
+/*   coo_slot[ncoo]: CSR slot that COO entry k is summed into, or -1 to drop  */
+/*     it (host, copied); each slot sums its entries in ascending k, so the   */
+/*     assembly is deterministic.                                            */
+/*   unit_rows[n_unit]: rows whose diagonal entry is set to 1 after assembly  */
+/*     (constrained dofs whose other entries were dropped).                   */
+typedef struct CeedXCsr_private *CeedXCsr;
+CEED_EXTERN int CeedXCsrCreate(Ceed ceed, CeedInt nrows, const CeedInt *rowptr, const CeedInt *cols,
+                               CeedInt ncoo, const CeedInt *coo_slot, CeedInt n_unit,
+                               const CeedInt *unit_rows, CeedXCsr *csr);
+CEED_EXTERN int CeedXCsrAssemble(CeedXCsr csr, CeedVector coo_values);
+CEED_EXTERN int CeedXCsrApply(CeedXCsr csr, CeedVector x, CeedVector y);       /* y = A x */
+CEED_EXTERN int CeedXCsrGetDiagonal(CeedXCsr csr, CeedVector d);
+CEED_EXTERN int CeedXCsrDestroy(CeedXCsr *csr);
 /* Accumulated device time (ms) and launch count of the operator's dominant   */
 /* kernel since the last reset; measured with hipEvents on the Ceed's stream  */
 /* when timing is enabled.                                                    */

@@ -1111,3 +1111,65 @@ int CeedXVectorDot(CeedVector x, CeedVector y, CeedVector weight, double *result
 }
 int CeedXOperatorSetTiming(CeedOperator op, int enable) { (void)op; (void)enable; return 0; }
 int CeedXOperatorGetTiming(CeedOperator op, double *ms, int64_t *launches) { (void)op; *ms = 0; *launches = 0; return 0; }
+
+/* ---- assembled sparse operator (include/ceed.h, CeedXCsr*): plain CSR on the host ------------ */
+struct CeedXCsr_private {
+  CeedInt nrows, nnz, ncoo, n_unit;
+  CeedInt *rowptr, *cols, *coo_slot, *unit_rows;
+  double  *vals;
+};
+int CeedXCsrCreate(Ceed ceed, CeedInt nrows, const CeedInt *rowptr, const CeedInt *cols, CeedInt ncoo,
+                   const CeedInt *coo_slot, CeedInt n_unit, const CeedInt *unit_rows, CeedXCsr *csr) {
+  (void)ceed;
+  if (nrows < 0 || ncoo < 0 || !rowptr) return oracle_error("CeedXCsrCreate: bad pattern");
+  CeedXCsr A = calloc(1, sizeof *A);
+  A->nrows = nrows; A->nnz = rowptr[nrows]; A->ncoo = ncoo; A->n_unit = n_unit;
+  A->rowptr = malloc(sizeof(CeedInt) * (size_t)(nrows + 1)); memcpy(A->rowptr, rowptr, sizeof(CeedInt) * (size_t)(nrows + 1));
+  A->cols = malloc(sizeof(CeedInt) * (size_t)(A->nnz + 1)); memcpy(A->cols, cols, sizeof(CeedInt) * (size_t)A->nnz);
+  A->coo_slot = malloc(sizeof(CeedInt) * (size_t)(ncoo + 1)); memcpy(A->coo_slot, coo_slot, sizeof(CeedInt) * (size_t)ncoo);
+  A->unit_rows = malloc(sizeof(CeedInt) * (size_t)(n_unit + 1)); if (n_unit) memcpy(A->unit_rows, unit_rows, sizeof(CeedInt) * (size_t)n_unit);
+  A->vals = calloc((size_t)(A->nnz + 1), sizeof(double));
+  for (CeedInt k = 0; k < ncoo; k++)
+    if (coo_slot[k] >= A->nnz) { free(A); return oracle_error("CeedXCsrCreate: COO entry maps outside the pattern"); }
+  *csr = A;
+  return 0;
+}
+int CeedXCsrAssemble(CeedXCsr A, CeedVector coo_values) {
+  vec_ensure(coo_values);
+  if (coo_values->length < A->ncoo) return oracle_error("CeedXCsrAssemble: too few COO values");
+  memset(A->vals, 0, sizeof(double) * (size_t)A->nnz);
+  for (CeedInt k = 0; k < A->ncoo; k++)   /* ascending entry order per slot, as the device path */
+    if (A->coo_slot[k] >= 0) A->vals[A->coo_slot[k]] += coo_values->array[k];
+  for (CeedInt i = 0; i < A->n_unit; i++) {
+    const CeedInt r = A->unit_rows[i];
+    int found = 0;
+    for (CeedInt k = A->rowptr[r]; k < A->rowptr[r + 1]; k++) if (A->cols[k] == r) { A->vals[k] = 1.; found = 1; }
+    if (!found) return oracle_error("CeedXCsrAssemble: unit row %d has no diagonal entry", r);
+  }
+  return 0;
+}
+int CeedXCsrApply(CeedXCsr A, CeedVector x, CeedVector y) {
+  vec_ensure(x); vec_ensure(y);
+  if (x == y || x->length < A->nrows || y->length < A->nrows) return oracle_error("CeedXCsrApply: bad vectors");
+  for (CeedInt r = 0; r < A->nrows; r++) {
+    double a = 0.;
+    for (CeedInt k = A->rowptr[r]; k < A->rowptr[r + 1]; k++) a += A->vals[k] * x->array[A->cols[k]];
+    y->array[r] = a;
+  }
+  return 0;
+}
+int CeedXCsrGetDiagonal(CeedXCsr A, CeedVector d) {
+  vec_ensure(d);
+  for (CeedInt r = 0; r < A->nrows; r++) {
+    d->array[r] = 0.;
+    for (CeedInt k = A->rowptr[r]; k < A->rowptr[r + 1]; k++) if (A->cols[k] == r) d->array[r] = A->vals[k];
+  }
+  return 0;
+}
+int CeedXCsrDestroy(CeedXCsr *csr) {
+  if (!csr || !*csr) return 0;
+  CeedXCsr A = *csr;
+  free(A->rowptr); free(A->cols); free(A->coo_slot); free(A->unit_rows); free(A->vals); free(A);
+  *csr = NULL;
+  return 0;
+}

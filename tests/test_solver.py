@@ -89,3 +89,69 @@ def test_graph_replayed_vcycle_matches_eager_vcycle(gpu):
         gpu.capture(bad)
     x.set_value(3.0)                       # the Ceed is usable again after the refused recording
     assert np.all(x.to_numpy() == 3.0)
+
+
+@pytest.mark.parametrize("problem", ["linElas", "hyperFS"])
+def test_assembled_coarse_matrix_equals_matrix_free_operator(oracle, problem):
+    """the p=1 matrix assembled from element matrices (assembly.py, CeedXCsr*) acts like the
+    matrix-free coarse Jacobian on the free dofs and like the identity on the constrained ones."""
+    from ceedpetscsolid_amd.assembly import AssembledLevel
+    mesh = hollow_cylinder_mesh(1, 6, 2, z0=-1.0, z1=1.0)
+    p = SolidProblem(oracle, mesh, 2, problem, nu=0.3, E=10.0, bc_sides=[998])
+    n = p.lsize()
+    X, R = oracle.vector(n), oracle.vector(n)
+    X.set_array(p.smooth_state(0.05) * (p.levels[p.fine].mask == 0)); p.form_residual(X, R)
+    A = AssembledLevel(p, 0); A.assemble()
+    n0 = p.lsize(0)
+    free = p.levels[0].mask == 0
+    x = np.random.default_rng(1).uniform(-1, 1, n0)
+    xv, y1, y2, d1, d2 = (oracle.vector(n0) for _ in range(5))
+    xv.set_array(x)
+    p.apply_jacobian(0, xv, y1); A.apply(xv, y2)
+    a, b = y1.to_numpy(), y2.to_numpy()
+    assert rel_err(b[free], a[free]) < 1e-13 and np.array_equal(b[~free], x[~free])
+    p.get_diag(0, d1); A.diagonal(d2)
+    assert rel_err(d2.to_numpy()[free], d1.to_numpy()[free]) < 1e-13 and np.all(d2.to_numpy()[~free] == 1.0)
+    # symmetric (the tangent of a hyperelastic energy), 81-point stencil at most
+    assert A.nnz <= 81 * n0
+
+
+def test_solver_with_assembled_coarse_level_converges_on_oracle(oracle):
+    mesh = hollow_cylinder_mesh(1, 6, 2, z0=-1.0, z1=1.0)
+    p = SolidProblem(oracle, mesh, 2, "hyperSS", nu=0.3, E=10.0, bc_sides=[998, 999])
+    ref = NewtonPMG(p, clamp=CLAMP, coarse="chebyshev", coarse_cheb_its=20, coarse_cheb_ratio=50.0)
+    assert ref.solve(1).converged
+    s = NewtonPMG(p, clamp=CLAMP, coarse="assembled", coarse_cheb_its=20, coarse_cheb_ratio=50.0)
+    st = s.solve(1)
+    assert st.converged and st.coarse_spmv > 0
+    assert st.ksp_its == ref.stats.ksp_its            # the same polynomial of the same operator
+    assert rel_err(s.U.to_numpy(), ref.U.to_numpy()) < 1e-8
+
+
+@pytest.mark.gpu
+def test_assembled_coarse_level_on_device(oracle, gpu):
+    """Device assembly == oracle assembly (same element-matrix entries, same summation order), and the
+    graph-replayed solve with the assembled coarse level converges to the eager matrix-free answer."""
+    from ceedpetscsolid_amd.assembly import AssembledLevel
+    mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_672e_4ss_us.npz"))
+    ys = []
+    for c in (oracle, gpu):
+        p = SolidProblem(c, mesh, 4, "hyperFS", nu=0.3, E=1e3, bc_sides=[998, 999])
+        n = p.lsize()
+        X, R = c.vector(n), c.vector(n)
+        X.set_array(p.smooth_state(0.02) * (p.levels[p.fine].mask == 0)); p.form_residual(X, R)
+        A = AssembledLevel(p, 0); A.assemble()
+        n0 = p.lsize(0)
+        x = c.vector(n0).set_array(np.random.default_rng(3).uniform(-1, 1, n0))
+        y, ymf = c.vector(n0), c.vector(n0)
+        A.apply(x, y); p.apply_jacobian(0, x, ymf)
+        free = p.levels[0].mask == 0
+        assert rel_err(y.to_numpy()[free], ymf.to_numpy()[free]) < 1e-12
+        ys.append(y.to_numpy())
+    assert rel_err(ys[1], ys[0]) < 1e-12
+    p = SolidProblem(gpu, mesh, 2, "hyperSS", nu=0.3, E=1e3, bc_sides=[998, 999])
+    ref = NewtonPMG(p, clamp=CLAMP, coarse="chebyshev", coarse_cheb_its=20, coarse_cheb_ratio=50.0)
+    assert ref.solve(2).converged
+    s = NewtonPMG(p, clamp=CLAMP, coarse="assembled", coarse_cheb_its=20, coarse_cheb_ratio=50.0, graph=True)
+    assert s.solve(2).converged
+    assert rel_err(s.U.to_numpy(), ref.U.to_numpy()) < 1e-8
