@@ -142,7 +142,7 @@ struct CeedQFunction_private {
 
 struct OpField { bool set = false; CeedElemRestriction rstr = nullptr; CeedBasis basis = nullptr; CeedVector vec = nullptr; };
 
-enum PlanKind { PLAN_NONE = 0, PLAN_FUSED_GRAD, PLAN_SETUP_GEO, PLAN_PROLONG, PLAN_RESTRICT };
+enum PlanKind { PLAN_NONE = 0, PLAN_FUSED_GRAD, PLAN_SETUP_GEO, PLAN_PROLONG, PLAN_RESTRICT, PLAN_COORD };
 
 struct CeedOperator_private {
   Ceed ceed = nullptr;
@@ -607,7 +607,8 @@ static int resolve_qf(const std::string &name) {
   static const struct { const char *n; int k; } tab[] = {
       {"SetupGeo", QF_SETUP_GEO},    {"LinElasF", QF_LINELAS},       {"LinElasdF", QF_LINELAS},
       {"HyperSSF", QF_HYPERSS_F},    {"HyperSSdF", QF_HYPERSS_DF},   {"HyperFSF", QF_HYPERFS_F},
-      {"HyperFSdF", QF_HYPERFS_DF},
+      {"HyperFSdF", QF_HYPERFS_DF},  {"SetupConstantForce", QF_CONST_FORCE}, {"SetupMMSForce", QF_MMS_FORCE},
+      {"MMSTrueSoln", QF_MMS_TRUE},
   };
   for (auto &t : tab) if (name == t.n) return t.k;
   return QF_NONE;
@@ -867,6 +868,29 @@ static int op_plan(CeedOperator op) {
     op->i_active = 0; op->o_active = 0;
     return 0;
   }
+  if (k == QF_CONST_FORCE || k == QF_MMS_FORCE || k == QF_MMS_TRUE) {
+    // opSetupForce: (x INTERP, qdata NONE) -> force INTERP (setuplibceed.c:555-583); opTrue: x INTERP -> true_soln NONE (:608-623)
+    const bool force = k != QF_MMS_TRUE;
+    if (qf->in.size() != (force ? 2u : 1u) || qf->out.size() != 1) return unsupported("expected (x[, qdata]) -> one output");
+    if (qf->in[0].emode != CEED_EVAL_INTERP || qf->in[0].size != 3 || qf->out[0].size != 3) return unsupported("x must be 3 components, INTERP");
+    OpField &x = op->in[0], &o = op->out[0];
+    if (!is_offsets(x.rstr) || x.rstr->elemsize != 8 || x.rstr->ncomp != 3 || x.rstr->compstride != 1 || x.basis == CEED_BASIS_COLLOCATED || x.basis->P1d != 2)
+      return unsupported("coordinates must be trilinear (P=2), 3 interlaced components");
+    if (!is_offsets(o.rstr) || o.rstr->ncomp != 3 || o.rstr->compstride != 1 || o.rstr->nelem != x.rstr->nelem) return unsupported("output must be an offsets restriction with 3 interlaced components");
+    const int Q = x.basis->Q1d;
+    if (force) {
+      if (qf->in[1].emode != CEED_EVAL_NONE || qf->in[1].size != 10 || qf->out[0].emode != CEED_EVAL_INTERP) return unsupported("forcing takes qdata NONE and gives force INTERP");
+      OpField &qd = op->in[1];
+      if (!is_strided(qd.rstr) || qd.rstr->ncomp != 10 || qd.rstr->elemsize != Q * Q * Q) return unsupported("qdata must be strided 10 x Q^3");
+      if (o.basis == CEED_BASIS_COLLOCATED || o.basis->Q1d != Q || o.rstr->elemsize != o.basis->P1d * o.basis->P1d * o.basis->P1d) return unsupported("force basis must share the quadrature of the coordinate basis");
+      op->i_qdata = 1;
+    } else {
+      if (qf->out[0].emode != CEED_EVAL_NONE || o.basis != CEED_BASIS_COLLOCATED || o.rstr->elemsize != Q * Q * Q) return unsupported("true solution is collocated on the points of the coordinate basis");
+    }
+    op->i_active = 0; op->o_active = 0;
+    op->plan = PLAN_COORD;
+    return 0;
+  }
   return unsupported("no kernel family");
 }
 
@@ -1017,6 +1041,34 @@ static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool 
     hipError_t e = launch_transfer(b->P1d, b->Q1d, pro, op->tables, a, s, &kname);
     if (e == hipErrorInvalidValue && !*kname) return ceed_error("no transfer kernel for Pc=%d Pf=%d", b->P1d, b->Q1d);
     HIPCHK(e);
+    op->launches++;
+    break;
+  }
+  case PLAN_COORD: {
+    OpField &x = op->in[0], &o = op->out[0];
+    if (!in || in->length < x.rstr->lsize || !out || out->length < o.rstr->lsize) return ceed_error("coordinate / output vector too short");
+    CoordOpArgs a{};
+    double *px, *py, *pq = nullptr;
+    CHK(vec_dev(in, false, &px)); CHK(vec_dev(out, true, &py));
+    a.off_x = x.rstr->d_offsets; a.xcoord = px; a.off_u = o.rstr->d_offsets; a.y = py;
+    a.nelem = x.rstr->nelem; a.Q = x.basis->Q1d;
+    a.mode = qf->kind == QF_CONST_FORCE ? 0 : (qf->kind == QF_MMS_FORCE ? 1 : 2);
+    if (a.mode != 2) {
+      CHK(vec_dev(op->in[1].vec, false, &pq)); a.qdata = pq;
+      a.Pout = o.basis->P1d;
+      memcpy(a.bu, o.basis->interp1d.data(), sizeof(double) * o.basis->interp1d.size());
+      if (!qf->ctx) return ceed_error("QFunction '%s' needs its context", qf->name.c_str());
+      const double *cx = (const double *)qf->ctx;   // pointer pass-through: forcing vector (3) or Physics {nu, E} (setuplibceed.c:563-566)
+      for (int i = 0; i < (a.mode == 0 ? 3 : 2); i++) a.ctx[i] = cx[i];
+    } else {
+      a.Pout = a.Q;
+    }
+    memcpy(a.bx, x.basis->interp1d.data(), sizeof(double) * x.basis->interp1d.size());
+    if (!add) CHK(dev_zero(op->ceed, py, (size_t)out->length));
+    hipError_t e = launch_coord_op(a, s);
+    if (e == hipErrorInvalidValue) return ceed_error("coordinate operator: Q=%d / P=%d outside the supported range", a.Q, a.Pout);
+    HIPCHK(e);
+    kname = a.mode == 2 ? "coord_op<MMSTrueSoln>" : (a.mode == 1 ? "coord_op<SetupMMSForce>" : "coord_op<SetupConstantForce>");
     op->launches++;
     break;
   }

@@ -96,6 +96,20 @@ hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const u
                            const unsigned char *flags, const double *evec, double *y, int nnodes, int P3,
                            int add, hipStream_t s);
 
+// Coordinate-driven set-up operators (kernels_coord.hip): opSetupForce and opTrue of setuplibceed.c:555-623.
+struct CoordOpArgs {
+  const uint32_t *off_x;   // [nelem][8] coordinate restriction
+  const double *xcoord;    // interlaced [vertex][3]
+  const uint32_t *off_u;   // [nelem][Pout^3] displacement restriction
+  double *y;               // output L-vector, pre-zeroed, accumulated over the elements
+  const double *qdata;     // [nelem][10][Q^3] (forcing) or null (true solution)
+  int nelem, Q, Pout, mode;  // mode 0: SetupConstantForce, 1: SetupMMSForce, 2: MMSTrueSoln
+  double ctx[3];           // direction | (nu, E)
+  double bx[MAXN1D * 2];   // coordinate basis interp1d, Q x 2
+  double bu[MAXN1D * MAXN1D];  // displacement basis interp1d, Q x Pout (forcing only)
+};
+hipError_t launch_coord_op(const CoordOpArgs &a, hipStream_t s);
+
 // Assembled coarse-level operator (kernels_csr.hip).
 hipError_t launch_csr_sum(const uint32_t *slotptr, const uint32_t *perm, const double *coo, double *vals, int nnz,
                           const uint32_t *unit_diag_slot, int n_unit, hipStream_t s);

@@ -75,7 +75,7 @@ class Vec:
 
 
 class NewtonPMG:
-    def __init__(self, prob: SolidProblem, clamp: Optional[Dict[int, dict]] = None, mms: bool = False,
+    def __init__(self, prob: SolidProblem, clamp: Optional[Dict[int, dict]] = None, mms: bool = False, forcing=None,
                  halo=None, smooth_its: int = 3, coarse_rtol: float = 1e-3, coarse_maxit: int = 200,
                  coarse: str = "cg", coarse_cheb_its: int = 40, coarse_cheb_ratio: float = 100.0, graph: bool = False,
                  ksp_rtol: float = 1e-10, snes_rtol: float = 1e-8, snes_maxit: int = 50, verbose: bool = False):
@@ -117,6 +117,12 @@ class NewtonPMG:
         self.weight = None
         if halo is not None and halo.world > 1:
             self.weight = c.vector(n).set_array(halo.owner_weight * self.free)
+        # body force vector (opSetupForce output, setuplibceed.c:555-583): SNESSolve(snes, F, U) solves
+        # residual(U) = load * F on the unconstrained dofs (elasticity.c:645-654)
+        self.fv = None
+        if forcing is not None:
+            self.fv = c.vector(n).set_array(np.asarray(forcing, dtype=np.float64) * self.free)
+        self.load = 1.0
         self.stats = SolveStats()
         self._bc_nodes = self._collect_bc_nodes()
 
@@ -180,6 +186,8 @@ class NewtonPMG:
         self.copy(self.Xloc, U)
         self.axpby(self.Xloc, 1.0, self.bcv, 1.0)
         self.p.form_residual(self.Xloc, R)
+        if self.fv is not None:
+            self.axpby(R, -self.load, self.fv, 1.0)
         self.stats.residual_evals += 1
 
     # ---- multigrid preconditioner ---------------------------------------------------------------
@@ -343,6 +351,7 @@ class NewtonPMG:
         self.U.set_value(0.0)
         for inc in range(1, num_increments + 1):
             load = inc / num_increments
+            self.load = load
             self.bcv.set_array(self.bc_values(load))
             self.residual(self.U, self.R)
             rnorm0 = np.sqrt(self.dot(self.R, self.R, True))

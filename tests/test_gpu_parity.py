@@ -322,3 +322,63 @@ def test_row_kernel_variant_matches_pencil_kernel(gpu, product_lib):
         assert ys[0][1].endswith("/pencil") and not ys[1][1].endswith("/pencil")
         for a, b in zip(ys[0][0], ys[1][0]):
             assert rel_err(a, b) < 1e-13
+
+
+def _forcing_and_true(c, p, kind):
+    """opSetupForce / opTrue as the reference wires them (setuplibceed.c:555-583, 608-636)."""
+    lv = p.levels[p.fine]
+    n = p.lsize()
+    if kind == "true":
+        qf = c.qfunction("MMSTrueSoln", source="qfunctions/manufacturedTrue.h:MMSTrueSoln")
+        qf.add_input("x", 3, cd.EVAL_INTERP).add_output("true_soln", 3, cd.EVAL_NONE)
+        bxt = c.basis_lagrange(3, 3, 2, lv.degree + 1, cd.GAUSS_LOBATTO)      # basisxtrue, :600-603
+        op = c.operator(qf)
+        op.set_field("x", p.Erestrictx, bxt, "active")
+        op.set_field("true_soln", lv.Erestrictu, None, "active")
+    else:
+        name = "SetupMMSForce" if kind == "mms" else "SetupConstantForce"
+        src = "manufacturedForce.h" if kind == "mms" else "constantForce.h"
+        qf = c.qfunction(name, source=f"qfunctions/{src}:{name}")
+        qf.add_input("x", 3, cd.EVAL_INTERP).add_input("qdata", 10, cd.EVAL_NONE).add_output("force", 3, cd.EVAL_INTERP)
+        if kind == "mms":
+            qf.set_context(p.phys)
+        else:
+            _forcing_and_true.vec = np.array([0.3, -1.0, 2.0])
+            qf.set_context(_forcing_and_true.vec, reported_size=8)             # sizeof(*forcingVector) quirk, :565-566
+        op = c.operator(qf)
+        op.set_field("x", p.Erestrictx, p.basisx, "active")
+        op.set_field("qdata", p.Erestrictqdi, None, p.qdata)
+        op.set_field("force", lv.Erestrictu, lv.basisu, "active")
+    F = c.vector(n)
+    op.apply(p.xcoord, F)
+    return F.to_numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["const", "mms", "true"])
+def test_forcing_and_true_solution_operators_match_oracle(oracle, gpu, kind):
+    mesh = hollow_cylinder_mesh(2, 8, 3)
+    fo, fg = (_forcing_and_true(c, SolidProblem(c, mesh, 3, "linElas", nu=0.3, E=1e6, bc_sides=[998], multigrid="none"), kind)
+              for c in (oracle, gpu))
+    assert np.linalg.norm(fo) > 0 and rel_err(fg, fo) < TOL
+
+
+@pytest.mark.gpu
+def test_config1_mms_on_the_device(gpu):
+    """BASELINE config 1 end to end on the MI355X path: linElas, box 4x4x4, degree 2, SetupMMSForce forcing,
+    BCMMS boundary values, one Newton step of the PCG-pMG solver; the reference's own acceptance gate is a
+    relative L2 error <= 0.05 against MMSTrueSoln (elasticity.c:790-810)."""
+    from ceedpetscsolid_amd.solver import NewtonPMG
+    mesh = box_mesh(4, 4, 4)
+    p = SolidProblem(gpu, mesh, 2, "linElas", nu=0.3, E=1e6, bc_all_boundary=True)
+    lv = p.levels[p.fine]
+    f = _forcing_and_true(gpu, p, "mms")
+    ut = _forcing_and_true(gpu, p, "true")
+    mult = gpu.vector(p.lsize()); lv.Erestrictu.multiplicity(mult)
+    ut = ut / mult.to_numpy()                                                   # setuplibceed.c:626-636
+    s = NewtonPMG(p, mms=True, forcing=f)
+    st = s.solve(1)
+    assert st.converged and st.newton_its == 1
+    u = s.U.to_numpy() + s.bc_values(1.0)
+    err = np.linalg.norm(u - ut) / np.linalg.norm(ut)
+    assert err < 0.05 and err < 5e-3, err
