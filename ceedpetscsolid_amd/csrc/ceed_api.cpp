@@ -142,7 +142,7 @@ struct CeedQFunction_private {
 
 struct OpField { bool set = false; CeedElemRestriction rstr = nullptr; CeedBasis basis = nullptr; CeedVector vec = nullptr; };
 
-enum PlanKind { PLAN_NONE = 0, PLAN_FUSED_GRAD, PLAN_SETUP_GEO, PLAN_PROLONG, PLAN_RESTRICT, PLAN_COORD };
+enum PlanKind { PLAN_NONE = 0, PLAN_FUSED_GRAD, PLAN_SETUP_GEO, PLAN_PROLONG, PLAN_RESTRICT, PLAN_COORD, PLAN_ENERGY };
 
 struct CeedOperator_private {
   Ceed ceed = nullptr;
@@ -608,7 +608,8 @@ static int resolve_qf(const std::string &name) {
       {"SetupGeo", QF_SETUP_GEO},    {"LinElasF", QF_LINELAS},       {"LinElasdF", QF_LINELAS},
       {"HyperSSF", QF_HYPERSS_F},    {"HyperSSdF", QF_HYPERSS_DF},   {"HyperFSF", QF_HYPERFS_F},
       {"HyperFSdF", QF_HYPERFS_DF},  {"SetupConstantForce", QF_CONST_FORCE}, {"SetupMMSForce", QF_MMS_FORCE},
-      {"MMSTrueSoln", QF_MMS_TRUE},
+      {"MMSTrueSoln", QF_MMS_TRUE},  {"LinElasEnergy", QF_ENERGY_LINELAS}, {"HyperSSEnergy", QF_ENERGY_HYPERSS},
+      {"HyperFSEnergy", QF_ENERGY_HYPERFS},
   };
   for (auto &t : tab) if (name == t.n) return t.k;
   return QF_NONE;
@@ -868,6 +869,24 @@ static int op_plan(CeedOperator op) {
     op->i_active = 0; op->o_active = 0;
     return 0;
   }
+  if (k == QF_ENERGY_LINELAS || k == QF_ENERGY_HYPERSS || k == QF_ENERGY_HYPERFS) {
+    // opEnergy (setuplibceed.c:651-670): (du GRAD active, qdata NONE) -> energy INTERP, 1 component
+    if (qf->in.size() != 2 || qf->out.size() != 1) return unsupported("energy takes (du, qdata) -> energy");
+    if (qf->in[0].emode != CEED_EVAL_GRAD || qf->in[0].size != 9 || qf->in[1].emode != CEED_EVAL_NONE || qf->in[1].size != 10 ||
+        qf->out[0].emode != CEED_EVAL_INTERP || qf->out[0].size != 1)
+      return unsupported("energy eval modes must be GRAD(9), NONE(10) -> INTERP(1)");
+    OpField &u = op->in[0], &qd = op->in[1], &en = op->out[0];
+    if (!is_offsets(u.rstr) || u.rstr->ncomp != 3 || u.rstr->compstride != 1 || u.basis == CEED_BASIS_COLLOCATED) return unsupported("displacement field");
+    const int P = u.basis->P1d, Q = u.basis->Q1d;
+    if (u.rstr->elemsize != P * P * P) return unsupported("restriction element size is not P^3");
+    if (!is_strided(qd.rstr) || qd.rstr->ncomp != 10 || qd.rstr->elemsize != Q * Q * Q) return unsupported("qdata must be strided 10 x Q^3");
+    if (!is_offsets(en.rstr) || en.rstr->ncomp != 1 || en.rstr->nelem != u.rstr->nelem || en.basis == CEED_BASIS_COLLOCATED ||
+        en.basis->P1d * en.basis->P1d * en.basis->P1d != en.rstr->elemsize || en.basis->Q1d != Q || en.basis->P1d != P)
+      return unsupported("energy field must be a 1-component field on the displacement's nodes and points");
+    op->i_active = 0; op->i_qdata = 1; op->o_active = 0;
+    op->plan = PLAN_ENERGY;
+    return 0;
+  }
   if (k == QF_CONST_FORCE || k == QF_MMS_FORCE || k == QF_MMS_TRUE) {
     // opSetupForce: (x INTERP, qdata NONE) -> force INTERP (setuplibceed.c:555-583); opTrue: x INTERP -> true_soln NONE (:608-623)
     const bool force = k != QF_MMS_TRUE;
@@ -1041,6 +1060,27 @@ static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool 
     hipError_t e = launch_transfer(b->P1d, b->Q1d, pro, op->tables, a, s, &kname);
     if (e == hipErrorInvalidValue && !*kname) return ceed_error("no transfer kernel for Pc=%d Pf=%d", b->P1d, b->Q1d);
     HIPCHK(e);
+    op->launches++;
+    break;
+  }
+  case PLAN_ENERGY: {
+    OpField &u = op->in[0], &en = op->out[0];
+    if (!in || in->length < u.rstr->lsize || !out || out->length < en.rstr->lsize) return ceed_error("displacement / energy vector too short");
+    EnergyOpArgs a{};
+    double *pu, *py, *pq;
+    CHK(vec_dev(in, false, &pu)); CHK(vec_dev(out, true, &py)); CHK(vec_dev(op->in[1].vec, false, &pq));
+    a.off_u = u.rstr->d_offsets; a.u = pu; a.off_e = en.rstr->d_offsets; a.y = py; a.qdata = pq;
+    a.nelem = u.rstr->nelem; a.Q = u.basis->Q1d; a.P = u.basis->P1d;
+    a.model = qf->kind == QF_ENERGY_LINELAS ? 0 : (qf->kind == QF_ENERGY_HYPERSS ? 1 : 2);
+    CHK(read_phys(qf, &a.nu, &a.E));
+    memcpy(a.interp, u.basis->interp1d.data(), sizeof(double) * u.basis->interp1d.size());
+    memcpy(a.grad, u.basis->grad1d.data(), sizeof(double) * u.basis->grad1d.size());
+    memcpy(a.interp_e, en.basis->interp1d.data(), sizeof(double) * en.basis->interp1d.size());
+    if (!add) CHK(dev_zero(op->ceed, py, (size_t)out->length));
+    hipError_t e = launch_energy_op(a, s);
+    if (e == hipErrorInvalidValue) return ceed_error("energy operator: Q=%d / P=%d outside the supported range", a.Q, a.P);
+    HIPCHK(e);
+    kname = a.model == 0 ? "energy_op<LinElasEnergy>" : (a.model == 1 ? "energy_op<HyperSSEnergy>" : "energy_op<HyperFSEnergy>");
     op->launches++;
     break;
   }

@@ -17,6 +17,9 @@ enum QFKind : int {
   QF_CONST_FORCE,
   QF_MMS_FORCE,
   QF_MMS_TRUE,
+  QF_ENERGY_LINELAS,
+  QF_ENERGY_HYPERSS,
+  QF_ENERGY_HYPERFS,
 };
 
 constexpr int MAXN1D = 8;  // largest P or Q supported by the kernel tables
@@ -109,6 +112,19 @@ struct CoordOpArgs {
   double bu[MAXN1D * MAXN1D];  // displacement basis interp1d, Q x Pout (forcing only)
 };
 hipError_t launch_coord_op(const CoordOpArgs &a, hipStream_t s);
+// Strain-energy operator (kernels_coord.hip): opEnergy of setuplibceed.c:651-670.
+struct EnergyOpArgs {
+  const uint32_t *off_u;   // [nelem][P^3] displacement restriction (3 interlaced components)
+  const double *u;         // displacement L-vector
+  const uint32_t *off_e;   // [nelem][P^3] energy restriction (1 component)
+  double *y;               // energy L-vector, pre-zeroed
+  const double *qdata;     // [nelem][10][Q^3]
+  int nelem, Q, P, model;  // model 0: LinElasEnergy, 1: HyperSSEnergy, 2: HyperFSEnergy
+  double nu, E;
+  double interp[MAXN1D * MAXN1D], grad[MAXN1D * MAXN1D];  // displacement basis, Q x P
+  double interp_e[MAXN1D * MAXN1D];                        // energy basis, Q x P
+};
+hipError_t launch_energy_op(const EnergyOpArgs &a, hipStream_t s);
 
 // Assembled coarse-level operator (kernels_csr.hip).
 hipError_t launch_csr_sum(const uint32_t *slotptr, const uint32_t *perm, const double *coo, double *vals, int nnz,

@@ -97,3 +97,112 @@ hipError_t launch_coord_op(const CoordOpArgs &a, hipStream_t s) {
 }
 
 }  // namespace cps
+
+// ===========================================================================
+// opEnergy (setuplibceed.c:651-670, matops.c:247-296): u --GRAD(basisu)--> *Energy with qdata
+// --INTERP^T(basisEnergy, 1 component)--> energy L-vector; its sum is the strain energy.  Post-processing,
+// run once per solve: one workgroup per element, direct (not sum-factorised) tensor evaluation.
+// ===========================================================================
+namespace cps {
+
+CPS_DEV double log1p_series4_e(double x) {  // hyperSS.h:43-55
+  const double y = x / (2. + x), y2 = y * y;
+  return 2. * (y + y2 * y / 3. + y2 * y2 * y / 5. + y2 * y2 * y2 * y / 7.);
+}
+CPS_DEV double log1p_series4_shifted_e(double x) {  // hyperFS.h:45-67
+  const double left = sqrt(2.) / 2 - 1, right = sqrt(2.) - 1;
+  double sum = 0;
+  if (x < left) { sum -= log(2.) / 2; x = 1 + 2 * x; }
+  else if (right < x) { sum += log(2.) / 2; x = (x - 1) / 2; }
+  const double y = x / (2. + x), y2 = y * y;
+  return sum + 2. * (y + y2 * y / 3. + y2 * y2 * y / 5. + y2 * y2 * y2 * y / 7.);
+}
+// model 0: LinElasEnergy (linElas.h:285-370), 1: HyperSSEnergy (hyperSS.h:326-412), 2: HyperFSEnergy
+// (hyperFS.h:469-553), restated as written (including the `strain_vol * mu` term of the first two)
+CPS_DEV double qf_energy(int model, double nu, double E, const double *ug, const double *qd) {
+  const double TwoMu = E / (1 + nu), mu = TwoMu / 2, Kbulk = E / (3 * (1 - 2 * nu)), lambda = (3 * Kbulk - TwoMu) / 3;
+  double g[3][3];  // grad u [component][derivative] = sum_m du[c][m] dXdx[m][k], ug[(d*3+c)] = du[c][d]
+  for (int c = 0; c < 3; c++)
+    for (int k = 0; k < 3; k++) {
+      double s = 0;
+      for (int m = 0; m < 3; m++) s += qd[1 + 3 * m + k] * ug[m * 3 + c];
+      g[c][k] = s;
+    }
+  double en;
+  if (model == 2) {
+    const int J[6] = {0, 1, 2, 1, 0, 0}, K[6] = {0, 1, 2, 2, 2, 1};
+    double w[6];
+    for (int m = 0; m < 6; m++) {
+      double s = g[J[m]][K[m]] + g[K[m]][J[m]];
+      for (int n = 0; n < 3; n++) s += g[n][J[m]] * g[n][K[m]];
+      w[m] = s;
+    }
+    const double detCm1 = w[0] * (w[1] * w[2] - w[3] * w[3]) + w[5] * (w[4] * w[3] - w[5] * w[2]) +
+                          w[4] * (w[5] * w[3] - w[4] * w[1]) + w[0] + w[1] + w[2] + w[0] * w[1] + w[0] * w[2] +
+                          w[1] * w[2] - w[5] * w[5] - w[4] * w[4] - w[3] * w[3];
+    const double logj = log1p_series4_shifted_e(detCm1) / 2.;
+    en = lambda * logj * logj / 2. - mu * logj + mu * (w[0] + w[1] + w[2]) / 2.;
+  } else {
+    const double e01 = (g[0][1] + g[1][0]) / 2., e02 = (g[0][2] + g[2][0]) / 2., e12 = (g[1][2] + g[2][1]) / 2.;
+    const double sv = (g[0][0] + g[0][0]) / 2. + (g[1][1] + g[1][1]) / 2. + (g[2][2] + g[2][2]) / 2.;
+    const double shear = (e01 * e01 + e02 * e02 + e12 * e12) * 2 * mu;
+    en = model == 0 ? lambda * sv * sv / 2. + sv * mu + shear
+                    : lambda * (1 + sv) * (log1p_series4_e(sv) - 1) + sv * mu + shear;
+  }
+  return en * qd[0];
+}
+
+__global__ __launch_bounds__(512) void k_energy_op(const EnergyOpArgs a) {
+  extern __shared__ double sh[];
+  const int Q = a.Q, Q3 = Q * Q * Q, P = a.P, P3 = P * P * P;
+  double *su = sh, *se = sh + 3 * P3;  // u[c][n]; energy[q]
+  const int e = blockIdx.x, t = threadIdx.x;
+  if (t < P3) {
+    const uint32_t base = a.off_u[(size_t)e * P3 + t] & OFF_MASK;
+    for (int c = 0; c < 3; c++) su[c * P3 + t] = a.u[base + c];
+  }
+  __syncthreads();
+  if (t < Q3) {
+    const int i = t % Q, j = (t / Q) % Q, k = t / (Q * Q);
+    double ug[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
+    for (int cc = 0; cc < P; cc++)
+      for (int b = 0; b < P; b++) {
+        const double bk = a.interp[k * P + cc], gk = a.grad[k * P + cc], bj = a.interp[j * P + b], gj = a.grad[j * P + b];
+        for (int aa = 0; aa < P; aa++) {
+          const double bi = a.interp[i * P + aa], gi = a.grad[i * P + aa];
+          const double w0 = gi * bj * bk, w1 = bi * gj * bk, w2 = bi * bj * gk;
+          const int n = (cc * P + b) * P + aa;
+          for (int c = 0; c < 3; c++) {
+            const double v = su[c * P3 + n];
+            ug[0 * 3 + c] += w0 * v; ug[1 * 3 + c] += w1 * v; ug[2 * 3 + c] += w2 * v;
+          }
+        }
+      }
+    double qd[10];
+    for (int c = 0; c < 10; c++) qd[c] = a.qdata[(size_t)e * 10 * Q3 + (size_t)c * Q3 + t];
+    se[t] = qf_energy(a.model, a.nu, a.E, ug, qd);
+  }
+  __syncthreads();
+  if (t < P3) {
+    const int i = t % P, j = (t / P) % P, k = t / (P * P);
+    double v = 0.;
+    for (int qk = 0; qk < Q; qk++)
+      for (int qj = 0; qj < Q; qj++) {
+        const double wjk = a.interp_e[qk * P + k] * a.interp_e[qj * P + j];
+        for (int qi = 0; qi < Q; qi++) v += wjk * a.interp_e[qi * P + i] * se[(qk * Q + qj) * Q + qi];
+      }
+    atomic_add_f64(a.y + (a.off_e[(size_t)e * P3 + t] & OFF_MASK), v);
+  }
+}
+
+hipError_t launch_energy_op(const EnergyOpArgs &a, hipStream_t s) {
+  if (a.nelem <= 0) return hipSuccess;
+  const int Q3 = a.Q * a.Q * a.Q, P3 = a.P * a.P * a.P;
+  int nt = Q3 > P3 ? Q3 : P3;
+  nt = ((nt + 63) / 64) * 64;
+  if (nt > 512 || a.Q > MAXN1D || a.P > MAXN1D) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_energy_op, dim3(a.nelem), dim3(nt), sizeof(double) * (3 * P3 + Q3), s, a);
+  return hipGetLastError();
+}
+
+}  // namespace cps

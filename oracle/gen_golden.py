@@ -89,6 +89,9 @@ def main():
         out[f"{fam}F.dv"], out[f"{fam}F.gradu"] = dv, gradu
         (ddv,) = call_qf(ref(fam + "dF"), phys, Q, [d["dug"], qdata, gradu], [9])
         out[f"{fam}dF.dv"] = ddv
+    for fam in ("LinElas", "HyperSS", "HyperFS"):   # strain energy density x w detJ (post-processing operator opEnergy)
+        (en,) = call_qf(ref(fam + "Energy"), phys, Q, [ug, qdata], [1])
+        out[f"{fam}Energy.energy"] = en
     (f1,) = call_qf(ref("SetupConstantForce"), force_dir, Q, [d["x"], qdata], [3])
     out["SetupConstantForce.force"] = f1
     (f2,) = call_qf(ref("SetupMMSForce"), phys, Q, [d["x"], qdata], [3])

@@ -370,6 +370,49 @@ static int Oracle_SetupMMSForce(void *ctx, CeedInt Q, const CeedScalar *const *i
   return 0;
 }
 
+/* ---- strain energy (opEnergy, setuplibceed.c:651-670): energy density x w detJ ------------------
+ * LinElasEnergy linElas.h:285-370, HyperSSEnergy hyperSS.h:326-412, HyperFSEnergy hyperFS.h:469-553;
+ * restated AS WRITTEN, including the `strain_vol * mu` term of the first two. */
+static int oracle_energy(int model, void *ctx, CeedInt Q, const CeedScalar *const *in, CeedScalar *const *out) {
+  const OraclePhysics *ph = (const OraclePhysics *)ctx;
+  double lambda, TwoMu;
+  lame(ph, &lambda, &TwoMu);
+  const double mu = TwoMu / 2;
+  for (CeedInt i = 0; i < Q; i++) {
+    m33 du, dXdx, g;
+    load_ref_grad(in[0], Q, i, du);
+    const double wdetJ = load_qdata(in[1], Q, i, dXdx);
+    to_physical(du, dXdx, g);
+    double en;
+    if (model == 2) {
+      double E2w[6];
+      for (int m = 0; m < 6; m++) {
+        double s = g[VJ[m]][VK[m]] + g[VK[m]][VJ[m]];
+        for (int n = 0; n < 3; n++) s += g[n][VJ[m]] * g[n][VK[m]];
+        E2w[m] = s;
+      }
+      const double detCm1 =
+          E2w[0] * (E2w[1] * E2w[2] - E2w[3] * E2w[3]) + E2w[5] * (E2w[4] * E2w[3] - E2w[5] * E2w[2]) +
+          E2w[4] * (E2w[5] * E2w[3] - E2w[4] * E2w[1]) + E2w[0] + E2w[1] + E2w[2] + E2w[0] * E2w[1] +
+          E2w[0] * E2w[2] + E2w[1] * E2w[2] - E2w[5] * E2w[5] - E2w[4] * E2w[4] - E2w[3] * E2w[3];
+      const double logj = log1p_series4_shifted(detCm1) / 2.;
+      en = lambda * logj * logj / 2. - mu * logj + mu * (E2w[0] + E2w[1] + E2w[2]) / 2.;
+    } else {
+      m33 e;
+      sym_part(g, e);
+      const double sv = e[0][0] + e[1][1] + e[2][2];
+      const double shear = (e[0][1] * e[0][1] + e[0][2] * e[0][2] + e[1][2] * e[1][2]) * 2 * mu;
+      if (model == 0) en = lambda * sv * sv / 2. + sv * mu + shear;
+      else en = lambda * (1 + sv) * (log1p_series4(sv) - 1) + sv * mu + shear;
+    }
+    out[0][i] = en * wdetJ;
+  }
+  return 0;
+}
+static int Oracle_LinElasEnergy(void *ctx, CeedInt Q, const CeedScalar *const *in, CeedScalar *const *out) { return oracle_energy(0, ctx, Q, in, out); }
+static int Oracle_HyperSSEnergy(void *ctx, CeedInt Q, const CeedScalar *const *in, CeedScalar *const *out) { return oracle_energy(1, ctx, Q, in, out); }
+static int Oracle_HyperFSEnergy(void *ctx, CeedInt Q, const CeedScalar *const *in, CeedScalar *const *out) { return oracle_energy(2, ctx, Q, in, out); }
+
 /* ------------------------------------------------------------------------- */
 CEED_EXTERN CeedQFunctionUser OracleGetQFunction(const char *name) {
   static const struct { const char *n; CeedQFunctionUser f; } tab[] = {
@@ -383,6 +426,9 @@ CEED_EXTERN CeedQFunctionUser OracleGetQFunction(const char *name) {
       {"SetupConstantForce", Oracle_SetupConstantForce},
       {"SetupMMSForce", Oracle_SetupMMSForce},
       {"MMSTrueSoln", Oracle_MMSTrueSoln},
+      {"LinElasEnergy", Oracle_LinElasEnergy},
+      {"HyperSSEnergy", Oracle_HyperSSEnergy},
+      {"HyperFSEnergy", Oracle_HyperFSEnergy},
   };
   for (size_t i = 0; i < sizeof tab / sizeof tab[0]; i++)
     if (!strcmp(tab[i].n, name)) return tab[i].f;

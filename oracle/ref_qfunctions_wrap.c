@@ -26,6 +26,7 @@ static const struct { const char *name; CeedQFunctionUser f; const char *loc; } 
     REF_ENTRY(HyperSSF),   REF_ENTRY(HyperSSdF), REF_ENTRY(HyperFSF),
     REF_ENTRY(HyperFSdF),  REF_ENTRY(SetupConstantForce),
     REF_ENTRY(SetupMMSForce), REF_ENTRY(MMSTrueSoln),
+    REF_ENTRY(LinElasEnergy), REF_ENTRY(HyperSSEnergy), REF_ENTRY(HyperFSEnergy),
 };
 
 CEED_EXTERN CeedQFunctionUser RefGetQFunction(const char *name) {

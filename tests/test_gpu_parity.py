@@ -382,3 +382,18 @@ def test_config1_mms_on_the_device(gpu):
     u = s.U.to_numpy() + s.bc_values(1.0)
     err = np.linalg.norm(u - ut) / np.linalg.norm(ut)
     assert err < 0.05 and err < 5e-3, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("problem", ["linElas", "hyperSS", "hyperFS"])
+def test_strain_energy_operator_matches_oracle(oracle, gpu, problem):
+    """opEnergy / ComputeStrainEnergy (setuplibceed.c:651-670, matops.c:247-296) on the device."""
+    from ceedpetscsolid_amd.postprocess import StrainEnergy
+    mesh = hollow_cylinder_mesh(2, 8, 3)
+    res = []
+    for c in (oracle, gpu):
+        p = SolidProblem(c, mesh, 3, problem, nu=0.3, E=1e3, bc_sides=[998], multigrid="none")
+        se = StrainEnergy(p, problem)
+        X = c.vector(p.lsize()).set_array(p.smooth_state(0.05))
+        res.append((se.compute(X), se.eloc.to_numpy()))
+    assert abs(res[1][0] - res[0][0]) < TOL * abs(res[0][0]) and rel_err(res[1][1], res[0][1]) < TOL

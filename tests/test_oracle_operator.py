@@ -2,6 +2,8 @@
 volume, FD-consistency of the tangent, symmetry, rigid-body null space, adjointness of the
 p-multigrid transfer, diagonal, overwrite semantics, the sizeof(pointer) context quirk,
 and the MMS check of BASELINE config 1."""
+import os
+
 import numpy as np
 import pytest
 
@@ -153,3 +155,32 @@ def test_config1_mms_linear_elasticity(oracle):
         d = r + rn / rr * d; rr = rn
     err = np.linalg.norm((u + ubc) - ut) / np.linalg.norm(ut)
     assert err < 0.05 and err < 5e-3, err
+
+
+@pytest.mark.parametrize("problem", ["linElas", "hyperSS", "hyperFS"])
+def test_strain_energy_operator_on_oracle(oracle, problem):
+    """opEnergy (setuplibceed.c:651-670) + ComputeStrainEnergy (matops.c:247-296).  The energy QFunctions are
+    pinned against the reference headers in test_oracle_qfunctions; here the operator plumbing: the energy
+    L-vector sums to the plain quadrature of the density (partition of unity of the energy basis), which for a
+    homogeneous deformation u = A x is density(A) x volume."""
+    from ceedpetscsolid_amd.postprocess import StrainEnergy
+    import ctypes as C
+    mesh = box_mesh(2, 3, 2)
+    p = SolidProblem(oracle, mesh, 2, problem, nu=0.3, E=10.0, bc_sides=[], multigrid="none")
+    se = StrainEnergy(p, problem)
+    A = np.array([[0.02, 0.01, -0.005], [0.0, -0.015, 0.02], [0.01, 0.0, 0.03]])
+    X = p.levels[p.fine].dofmap.node_coords
+    u = (X @ A.T).reshape(-1)
+    en = se.compute(oracle.vector(p.lsize()).set_array(u))
+    # density at one point from the oracle's own QFunction: reference gradient = A with dXdx = I, w detJ = 1
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liboracle_ceed.so"))
+    lib.OracleGetQFunction.restype = C.c_void_p
+    name = {"linElas": b"LinElasEnergy", "hyperSS": b"HyperSSEnergy", "hyperFS": b"HyperFSEnergy"}[problem]
+    f = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_double)))(lib.OracleGetQFunction(name))
+    ug = np.ascontiguousarray(A.T.reshape(9, 1))           # ug[d*3+c] = du_c/dX_d
+    qd = np.ascontiguousarray(np.concatenate([[1.0], np.eye(3).reshape(-1)]).reshape(10, 1))
+    out = np.zeros((1, 1)); phys = np.array([0.3, 10.0])
+    dp = C.POINTER(C.c_double)
+    assert f(phys.ctypes.data_as(C.c_void_p), 1, (dp * 2)(ug.ctypes.data_as(dp), qd.ctypes.data_as(dp)), (dp * 1)(out.ctypes.data_as(dp))) == 0
+    volume = 1.0                                           # box_mesh default is the unit cube
+    assert abs(en - out[0, 0] * volume) < 1e-12 * max(1.0, abs(en)), (en, out[0, 0])

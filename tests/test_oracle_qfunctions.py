@@ -46,6 +46,9 @@ CASES = [
     ("HyperFSdF", lambda g: [g["dug"], g["SetupGeo.qdata"], g["HyperFSF.gradu"]], [9], ["HyperFSdF.dv"]),
     ("SetupMMSForce", lambda g: [g["x"], g["SetupGeo.qdata"]], [3], ["SetupMMSForce.force"]),
     ("MMSTrueSoln", lambda g: [g["x"]], [3], ["MMSTrueSoln.true_soln"]),
+    ("LinElasEnergy", lambda g: [g["ug"], g["SetupGeo.qdata"]], [1], ["LinElasEnergy.energy"]),
+    ("HyperSSEnergy", lambda g: [g["ug"], g["SetupGeo.qdata"]], [1], ["HyperSSEnergy.energy"]),
+    ("HyperFSEnergy", lambda g: [g["ug"], g["SetupGeo.qdata"]], [1], ["HyperFSEnergy.energy"]),
 ]
 
 
