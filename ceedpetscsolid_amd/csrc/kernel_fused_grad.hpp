@@ -1,12 +1,12 @@
-// kernel_fused_grad.hpp -- the whole CeedOperatorApply of the residual / Jacobian
-// operators (setuplibceed.c:517-542, :817-839) in ONE launch:
-//   E-vector gather (offsets, Dirichlet flags) -> sum-factorised interpolation to
-//   the Gauss points -> gradient (z-derivative for free inside the z-pass, x/y by
-//   the collocated derivative) -> pointwise physics in registers (q-point data
-//   streamed once, coalesced, prefetched one point-slot ahead) -> gradient^T ->
-//   interpolation^T -> f64 atomic scatter-add.
-// Nothing but the L-vectors and the q-point data touches HBM: no E-vector, no
-// quadrature-point intermediate is ever written out.
+// kernel_fused_grad.hpp -- FIRST-GENERATION fused operator kernel (one output point per lane), kept
+// for A/B against kernel_fused_pencil.hpp (CEED_MI355X_FUSED=rows).  The whole CeedOperatorApply of
+// the residual / Jacobian operators (setuplibceed.c:517-542, :817-839) in ONE launch:
+//   gather (offsets, Dirichlet flags) -> sum-factorised interpolation to the Gauss points ->
+//   gradient (z-derivative for free inside the z-pass, x/y by the collocated derivative) ->
+//   pointwise physics in registers (q-point data streamed once, coalesced, prefetched a full
+//   element ahead) -> gradient^T -> interpolation^T -> element results to the E-vector (summed by
+//   k_assemble) or, with CEED_MI355X_SCATTER=atomic, f64 atomic scatter-add.
+// No quadrature-point intermediate is ever written out.
 //
 // Wave-per-element, barrier-free.  A workgroup is ONE wave64 and owns its
 // element(s) outright, so every LDS write -> read dependency stays inside one

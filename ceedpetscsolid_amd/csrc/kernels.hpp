@@ -24,7 +24,8 @@ enum QFKind : int {
 
 constexpr int MAXN1D = 8;  // largest P or Q supported by the kernel tables
 
-// 1-D tables handed to kernels by value (kernarg segment -> LDS once per block).
+// 1-D tables handed to kernels by value: they live in the kernarg segment; the pencil kernel reads them from
+// there as scalar operands, the other kernels stage them into LDS once per block.
 struct BasisTables {
   double interp[MAXN1D * MAXN1D];  // B[q][p], Q x P row-major (CeedBasis interp1d)
   double colo[MAXN1D * MAXN1D];    // Dq[q][m], Q x Q: derivative of the Lagrange basis on the

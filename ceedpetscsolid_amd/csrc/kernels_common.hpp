@@ -1,15 +1,11 @@
 // kernels_common.hpp -- device building blocks shared by the gfx950 kernels.
 //
-// Thread mapping (wave64-first): one lane per quadrature point.  An element owns
-// TPE lanes (Q^3 rounded up to a whole number of waves, or to a power of two when
-// several elements share a wave), a workgroup owns EPB elements, so every
-// global access of q-point data is one contiguous run per wave-instruction and
-// the pointwise physics runs with (almost) all lanes busy:
-//   Q=3: 27/32 lanes, 8 elements / 256-lane workgroup     Q=5: 125/128, 2 elements
-//   Q=4: 64/64,       4 elements                          Q=7: 343/384, 1 element
-// The 1-D sum-factorised contractions go through an LDS element slab of 9*Q^3
-// doubles; coefficient rows are pulled into registers once per pass and reused
-// for the three displacement components.
+// `Geom<Q>` is the point-per-lane mapping of the SET-UP and TRANSFER kernels (kernels_misc.hip:
+// k_setup_geo, k_transfer, k_diag): an element owns TPE lanes (Q^3 rounded up to a whole number of
+// waves, or to a power of two when several elements share a wave) and a workgroup owns EPB elements;
+// their 1-D contractions (interp_forward / interp_transpose below) go through an LDS element slab with
+// workgroup barriers.  The operator-apply kernels (kernel_fused_pencil.hpp, kernel_fused_grad.hpp) have
+// their own barrier-free wave-level mappings.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
