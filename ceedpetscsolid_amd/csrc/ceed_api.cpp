@@ -1055,11 +1055,23 @@ static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool 
     a.off_f = pro ? (fout ? fout : rf->d_offsets) : (fin ? fin : rf->d_offsets);
     a.x = px; a.y = py; a.scale_f = psc; a.nelem = rc->nelem;
     a.mask_in = (op->mask_mode & 1) ? 1 : 0; a.mask_out = (op->mask_mode & 2) ? 1 : 0;
-    if (!add) CHK(dev_zero(op->ceed, py, (size_t)out->length));
+    // deterministic scatter, as for the residual / Jacobian: element results -> E-vector -> per-node sums in
+    // element order over the OUTPUT restriction's transpose map (masked entries travel as zeros)
+    CeedElemRestriction ro = pro ? rf : rc;
+    const bool use_evec = !op->ceed->atomic_scatter;
+    if (use_evec) {
+      CHK(build_csr(ro, ro->csr, nullptr));
+      CHK(ceed_need_evec(op->ceed, (size_t)ro->nelem * ro->ncomp * ro->elemsize));
+      a.evec = op->ceed->evec;
+    }
+    if (!add && !(use_evec && ro->csr.full_cover)) CHK(dev_zero(op->ceed, py, (size_t)out->length));
     TimerScope ts(op, s);
     hipError_t e = launch_transfer(b->P1d, b->Q1d, pro, op->tables, a, s, &kname);
     if (e == hipErrorInvalidValue && !*kname) return ceed_error("no transfer kernel for Pc=%d Pf=%d", b->P1d, b->Q1d);
     HIPCHK(e);
+    if (use_evec)
+      HIPCHK(launch_assemble(ro->csr.d_rowptr, ro->csr.d_cols, ro->csr.d_node_off, nullptr, a.evec, py, ro->csr.nnodes,
+                             ro->elemsize, add ? 1 : 0, s));
     op->launches++;
     break;
   }
@@ -1149,10 +1161,19 @@ extern "C" int CeedOperatorLinearAssembleDiagonal(CeedOperator op, CeedVector as
   CHK(read_phys(qf, &a.nu, &a.E));
   lame_constants(a.nu, a.E, &a.lambda, &a.TwoMu);
   CHK(dev_zero(op->ceed, pd, (size_t)assembled->length));  // overwrite semantics (matops.c:227)
+  const bool use_evec = !op->ceed->atomic_scatter;
+  if (use_evec) {  // deterministic: element contributions -> E-vector -> per-node sums in element order
+    CHK(build_csr(ai.rstr, ai.rstr->csr, nullptr));
+    CHK(ceed_need_evec(op->ceed, (size_t)ai.rstr->nelem * ai.rstr->ncomp * ai.rstr->elemsize));
+    a.evec = op->ceed->evec;
+  }
   const char *kname = "";
   hipError_t e = launch_diag(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, a, s, &kname);
   if (e == hipErrorInvalidValue && !*kname) return ceed_error("no diagonal kernel for P=%d Q=%d %s", ai.basis->P1d, ai.basis->Q1d, qf->name.c_str());
   HIPCHK(e);
+  if (use_evec)
+    HIPCHK(launch_assemble(ai.rstr->csr.d_rowptr, ai.rstr->csr.d_cols, ai.rstr->csr.d_node_off, nullptr, a.evec, pd,
+                           ai.rstr->csr.nnodes, ai.rstr->elemsize, 0, s));
   return 0;
 }
 
@@ -1289,10 +1310,9 @@ extern "C" int CeedXVectorDot(CeedVector x, CeedVector y, CeedVector weight, dou
   if (weight && weight != CEED_VECTOR_NONE) CHK(vec_dev(weight, false, &pw));
   hipStream_t s = x->ceed->stream;
   if (x->ceed->capturing) return ceed_error("CeedXVectorDot during graph capture (it returns a host value)");
-  if (!x->ceed->d_scalar) HIPCHK(hipMalloc((void **)&x->ceed->d_scalar, sizeof(double)));
+  if (!x->ceed->d_scalar) HIPCHK(hipMalloc((void **)&x->ceed->d_scalar, sizeof(double) * (1 + 2048)));  // result + per-block partials
   if (!x->ceed->h_scalar) HIPCHK(hipHostMalloc((void **)&x->ceed->h_scalar, sizeof(double), hipHostMallocDefault));
   dres = x->ceed->d_scalar;
-  HIPCHK(hipMemsetAsync(dres, 0, sizeof(double), s));
   HIPCHK(launch_dot(px, py, pw, (size_t)x->length, dres, s));
   HIPCHK(hipMemcpyAsync(x->ceed->h_scalar, dres, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));

@@ -65,6 +65,8 @@ struct TransferArgs {
   const double *scale_f;  // optional per-dof scale on the fine side (multiplicity^-1), or null
   int nelem;
   int mask_in, mask_out;
+  double *evec;           // if set: element results go here ([elem][output nodes][3], masked entries as zeros) and
+                          // launch_assemble() sums them into y in element order; else f64 atomics into y
 };
 
 struct SetupGeoArgs {
@@ -80,6 +82,7 @@ struct DiagArgs {
   const double *qdata, *state_in;
   int nelem, mask_out;
   double nu, E, lambda, TwoMu;
+  double *evec;  // if set: element contributions go here ([elem][P^3][3]) and launch_assemble() sums them; else atomics
 };
 
 // Each returns hipSuccess or the launch error; `name` receives a static string
@@ -150,6 +153,6 @@ hipError_t launch_rstr_scatter_add(const uint32_t *off, int nelem, int elemsize,
 hipError_t launch_multiplicity(const uint32_t *off, int nelem, int elemsize, int ncomp, int compstride,
                                double *l, hipStream_t s);
 hipError_t launch_dot(const double *x, const double *y, const double *w, size_t n, double *result_dev,
-                      hipStream_t s);  // *result_dev (pre-zeroed) += sum w_i x_i y_i (w may be null)
+                      hipStream_t s);  // result_dev[0] = sum w_i x_i y_i (w may be null), reproducibly; result_dev: 1 + 2048 doubles
 
 }  // namespace cps

@@ -102,8 +102,11 @@ __global__ __launch_bounds__(Geom<PF>::BLOCK) void k_transfer(const BasisTables 
     if (fnode) {
       const uint32_t base = offf & OFF_MASK, fl = a.mask_out ? (offf >> OFF_FLAG_SHIFT) : 0u;
 #pragma unroll
-      for (int c = 0; c < 3; c++)
-        if (!((fl >> c) & 1u)) atomic_add_f64(a.y + base + c, a.scale_f ? v[c] * a.scale_f[base + c] : v[c]);
+      for (int c = 0; c < 3; c++) {
+        const double val = a.scale_f ? v[c] * a.scale_f[base + c] : v[c];
+        if (a.evec) a.evec[((size_t)e * F3 + q) * 3 + c] = ((fl >> c) & 1u) ? 0. : val;
+        else if (!((fl >> c) & 1u)) atomic_add_f64(a.y + base + c, val);
+      }
     }
   } else {
     if (q < F3) {
@@ -121,8 +124,10 @@ __global__ __launch_bounds__(Geom<PF>::BLOCK) void k_transfer(const BasisTables 
     if (cnode) {
       const uint32_t base = offc & OFF_MASK, fl = a.mask_out ? (offc >> OFF_FLAG_SHIFT) : 0u;
 #pragma unroll
-      for (int c = 0; c < 3; c++)
-        if (!((fl >> c) & 1u)) atomic_add_f64(a.y + base + c, v[c]);
+      for (int c = 0; c < 3; c++) {
+        if (a.evec) a.evec[((size_t)e * C3 + q) * 3 + c] = ((fl >> c) & 1u) ? 0. : v[c];
+        else if (!((fl >> c) & 1u)) atomic_add_f64(a.y + base + c, v[c]);
+      }
     }
   }
 }
@@ -203,8 +208,10 @@ __global__ __launch_bounds__(Geom<Q>::TPE) void k_diag(const BasisTables tab, co
     const uint32_t off = a.offsets[(size_t)e * P3 + q];
     const uint32_t base = off & OFF_MASK, fl = a.mask_out ? (off >> OFF_FLAG_SHIFT) : 0u;
 #pragma unroll
-    for (int c = 0; c < 3; c++)
-      if (!((fl >> c) & 1u)) atomic_add_f64(a.diag + base + c, acc[c]);
+    for (int c = 0; c < 3; c++) {
+      if (a.evec) a.evec[((size_t)e * P3 + q) * 3 + c] = ((fl >> c) & 1u) ? 0. : acc[c];  // summed by launch_assemble()
+      else if (!((fl >> c) & 1u)) atomic_add_f64(a.diag + base + c, acc[c]);
+    }
   }
 }
 template <int P, int Q, int QF>
@@ -342,7 +349,20 @@ __global__ void k_dot(const double *x, const double *y, const double *w, size_t 
   __shared__ double part[4];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomic_add_f64(result, part[0] + part[1] + part[2] + part[3]);
+  // per-block partial, summed in a fixed order by k_dot_final: the dot is reproducible run to run
+  if (threadIdx.x == 0) result[1 + blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(256) void k_dot_final(double *result, int nparts) {
+  __shared__ double sh[256];
+  double s = 0.;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += result[1 + i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) result[0] = sh[0];
 }
 
 hipError_t launch_set_value(double *v, size_t n, double val, hipStream_t s) {
@@ -404,8 +424,10 @@ hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const u
   return hipGetLastError();
 }
 hipError_t launch_dot(const double *x, const double *y, const double *w, size_t n, double *result_dev, hipStream_t s) {
-  if (!n) return hipSuccess;
-  hipLaunchKernelGGL(k_dot, stream_grid(n), dim3(256), 0, s, x, y, w, n, result_dev);
+  // result_dev: 1 + 2048 doubles ([0] the result, then the per-block partials)
+  const dim3 g = n ? stream_grid(n) : dim3(1);
+  hipLaunchKernelGGL(k_dot, g, dim3(256), 0, s, x, y, w, n, result_dev);
+  hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(256), 0, s, result_dev, (int)g.x);
   return hipGetLastError();
 }
 

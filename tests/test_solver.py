@@ -78,9 +78,10 @@ def test_graph_replayed_vcycle_matches_eager_vcycle(gpu):
         st = s.solve(2)
         assert st.converged
         out.append((s.U.to_numpy(), st.newton_its, st.ksp_its, st.jacobian_applies))
-    assert out[0][1] == out[1][1] and abs(out[0][2] - out[1][2]) <= 2
-    # Restrict_Ceed sums with f64 atomics (order varies run to run), so agreement is to solver tolerance
-    assert rel_err(out[1][0], out[0][0]) < 1e-8
+    # every scatter in the V-cycle (Jacobian, Prolong_Ceed, Restrict_Ceed) is a deterministic E-vector +
+    # per-node sum, so the replayed solve is BITWISE the eager one
+    assert out[0][1:3] == out[1][1:3]                 # Newton and Krylov iteration counts
+    assert np.array_equal(out[0][0], out[1][0])
     x, y = gpu.vector(8).set_value(1.0), gpu.vector(8).set_value(2.0)
 
     def bad():
