@@ -609,7 +609,8 @@ static int resolve_qf(const std::string &name) {
       {"HyperSSF", QF_HYPERSS_F},    {"HyperSSdF", QF_HYPERSS_DF},   {"HyperFSF", QF_HYPERFS_F},
       {"HyperFSdF", QF_HYPERFS_DF},  {"SetupConstantForce", QF_CONST_FORCE}, {"SetupMMSForce", QF_MMS_FORCE},
       {"MMSTrueSoln", QF_MMS_TRUE},  {"LinElasEnergy", QF_ENERGY_LINELAS}, {"HyperSSEnergy", QF_ENERGY_HYPERSS},
-      {"HyperFSEnergy", QF_ENERGY_HYPERFS},
+      {"HyperFSEnergy", QF_ENERGY_HYPERFS}, {"LinElasDiagnostic", QF_DIAG_LINELAS}, {"HyperSSDiagnostic", QF_DIAG_HYPERSS},
+      {"HyperFSDiagnostic", QF_DIAG_HYPERFS},
   };
   for (auto &t : tab) if (name == t.n) return t.k;
   return QF_NONE;
@@ -887,6 +888,26 @@ static int op_plan(CeedOperator op) {
     op->plan = PLAN_ENERGY;
     return 0;
   }
+  if (k == QF_DIAG_LINELAS || k == QF_DIAG_HYPERSS || k == QF_DIAG_HYPERFS) {
+    // opDiagnostic (setuplibceed.c:712-737): (u INTERP, du GRAD, qdata NONE) -> diagnostic NONE, 8 components
+    if (qf->in.size() != 3 || qf->out.size() != 1) return unsupported("diagnostic takes (u, du, qdata) -> diagnostic");
+    if (qf->in[0].emode != CEED_EVAL_INTERP || qf->in[0].size != 3 || qf->in[1].emode != CEED_EVAL_GRAD || qf->in[1].size != 9 ||
+        qf->in[2].emode != CEED_EVAL_NONE || qf->in[2].size != 10 || qf->out[0].emode != CEED_EVAL_NONE || qf->out[0].size != 8)
+      return unsupported("diagnostic eval modes must be INTERP(3), GRAD(9), NONE(10) -> NONE(8)");
+    OpField &u = op->in[0], &du = op->in[1], &qd = op->in[2], &dg = op->out[0];
+    if (op->in[0].vec != CEED_VECTOR_ACTIVE || op->in[1].vec != CEED_VECTOR_ACTIVE || u.rstr != du.rstr || u.basis != du.basis)
+      return unsupported("u and du must be the same active field");
+    if (!is_offsets(u.rstr) || u.rstr->ncomp != 3 || u.rstr->compstride != 1 || u.basis == CEED_BASIS_COLLOCATED) return unsupported("displacement field");
+    const int P = u.basis->P1d, Q = u.basis->Q1d;
+    if (u.rstr->elemsize != P * P * P) return unsupported("restriction element size is not P^3");
+    if (!is_strided(qd.rstr) || qd.rstr->ncomp != 10 || qd.rstr->elemsize != Q * Q * Q) return unsupported("qdata must be strided 10 x Q^3");
+    if (!is_offsets(dg.rstr) || dg.rstr->ncomp != 8 || dg.rstr->compstride != 1 || dg.rstr->nelem != u.rstr->nelem ||
+        dg.rstr->elemsize != Q * Q * Q || dg.basis != CEED_BASIS_COLLOCATED)
+      return unsupported("diagnostic field must be 8 interlaced components collocated with the points");
+    op->i_active = 0; op->i_qdata = 2; op->o_active = 0;
+    op->plan = PLAN_ENERGY;
+    return 0;
+  }
   if (k == QF_CONST_FORCE || k == QF_MMS_FORCE || k == QF_MMS_TRUE) {
     // opSetupForce: (x INTERP, qdata NONE) -> force INTERP (setuplibceed.c:555-583); opTrue: x INTERP -> true_soln NONE (:608-623)
     const bool force = k != QF_MMS_TRUE;
@@ -1080,19 +1101,22 @@ static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool 
     if (!in || in->length < u.rstr->lsize || !out || out->length < en.rstr->lsize) return ceed_error("displacement / energy vector too short");
     EnergyOpArgs a{};
     double *pu, *py, *pq;
-    CHK(vec_dev(in, false, &pu)); CHK(vec_dev(out, true, &py)); CHK(vec_dev(op->in[1].vec, false, &pq));
+    CHK(vec_dev(in, false, &pu)); CHK(vec_dev(out, true, &py)); CHK(vec_dev(op->in[op->i_qdata].vec, false, &pq));
     a.off_u = u.rstr->d_offsets; a.u = pu; a.off_e = en.rstr->d_offsets; a.y = py; a.qdata = pq;
     a.nelem = u.rstr->nelem; a.Q = u.basis->Q1d; a.P = u.basis->P1d;
-    a.model = qf->kind == QF_ENERGY_LINELAS ? 0 : (qf->kind == QF_ENERGY_HYPERSS ? 1 : 2);
+    const int kd = qf->kind;
+    a.diag = (kd == QF_DIAG_LINELAS || kd == QF_DIAG_HYPERSS || kd == QF_DIAG_HYPERFS) ? 1 : 0;
+    a.model = (kd == QF_ENERGY_LINELAS || kd == QF_DIAG_LINELAS) ? 0 : ((kd == QF_ENERGY_HYPERSS || kd == QF_DIAG_HYPERSS) ? 1 : 2);
     CHK(read_phys(qf, &a.nu, &a.E));
     memcpy(a.interp, u.basis->interp1d.data(), sizeof(double) * u.basis->interp1d.size());
     memcpy(a.grad, u.basis->grad1d.data(), sizeof(double) * u.basis->grad1d.size());
-    memcpy(a.interp_e, en.basis->interp1d.data(), sizeof(double) * en.basis->interp1d.size());
+    if (!a.diag) memcpy(a.interp_e, en.basis->interp1d.data(), sizeof(double) * en.basis->interp1d.size());
     if (!add) CHK(dev_zero(op->ceed, py, (size_t)out->length));
     hipError_t e = launch_energy_op(a, s);
     if (e == hipErrorInvalidValue) return ceed_error("energy operator: Q=%d / P=%d outside the supported range", a.Q, a.P);
     HIPCHK(e);
-    kname = a.model == 0 ? "energy_op<LinElasEnergy>" : (a.model == 1 ? "energy_op<HyperSSEnergy>" : "energy_op<HyperFSEnergy>");
+    kname = a.diag ? (a.model == 0 ? "diagnostic_op<LinElasDiagnostic>" : (a.model == 1 ? "diagnostic_op<HyperSSDiagnostic>" : "diagnostic_op<HyperFSDiagnostic>"))
+                   : (a.model == 0 ? "energy_op<LinElasEnergy>" : (a.model == 1 ? "energy_op<HyperSSEnergy>" : "energy_op<HyperFSEnergy>"));
     op->launches++;
     break;
   }

@@ -20,6 +20,9 @@ enum QFKind : int {
   QF_ENERGY_LINELAS,
   QF_ENERGY_HYPERSS,
   QF_ENERGY_HYPERFS,
+  QF_DIAG_LINELAS,
+  QF_DIAG_HYPERSS,
+  QF_DIAG_HYPERFS,
 };
 
 constexpr int MAXN1D = 8;  // largest P or Q supported by the kernel tables
@@ -123,7 +126,9 @@ struct EnergyOpArgs {
   const uint32_t *off_e;   // [nelem][P^3] energy restriction (1 component)
   double *y;               // energy L-vector, pre-zeroed
   const double *qdata;     // [nelem][10][Q^3]
-  int nelem, Q, P, model;  // model 0: LinElasEnergy, 1: HyperSSEnergy, 2: HyperFSEnergy
+  int nelem, Q, P, model;  // model 0: LinElas, 1: HyperSS, 2: HyperFS
+  int diag;                // 0: *Energy -> 1 component through INTERP^T; 1: *Diagnostic (opDiagnostic, setuplibceed.c:712-737)
+                           // -> 8 components collocated with the points, off_e then is the [nelem][Q^3] diagnostic restriction
   double nu, E;
   double interp[MAXN1D * MAXN1D], grad[MAXN1D * MAXN1D];  // displacement basis, Q x P
   double interp_e[MAXN1D * MAXN1D];                        // energy basis, Q x P

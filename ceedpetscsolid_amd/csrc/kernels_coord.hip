@@ -119,7 +119,9 @@ CPS_DEV double log1p_series4_shifted_e(double x) {  // hyperFS.h:45-67
 }
 // model 0: LinElasEnergy (linElas.h:285-370), 1: HyperSSEnergy (hyperSS.h:326-412), 2: HyperFSEnergy
 // (hyperFS.h:469-553), restated as written (including the `strain_vol * mu` term of the first two)
-CPS_DEV double qf_energy(int model, double nu, double E, const double *ug, const double *qd) {
+// returns the energy DENSITY; `dg` (optional) receives pressure, tr(strain), tr(strain^2), J of the diagnostic
+// QFunctions (linElas.h:376-480, hyperSS.h:418-523, hyperFS.h:559-662)
+CPS_DEV double qf_energy(int model, double nu, double E, const double *ug, const double *qd, double *dg) {
   const double TwoMu = E / (1 + nu), mu = TwoMu / 2, Kbulk = E / (3 * (1 - 2 * nu)), lambda = (3 * Kbulk - TwoMu) / 3;
   double g[3][3];  // grad u [component][derivative] = sum_m du[c][m] dXdx[m][k], ug[(d*3+c)] = du[c][d]
   for (int c = 0; c < 3; c++)
@@ -142,14 +144,27 @@ CPS_DEV double qf_energy(int model, double nu, double E, const double *ug, const
                           w[1] * w[2] - w[5] * w[5] - w[4] * w[4] - w[3] * w[3];
     const double logj = log1p_series4_shifted_e(detCm1) / 2.;
     en = lambda * logj * logj / 2. - mu * logj + mu * (w[0] + w[1] + w[2]) / 2.;
+    if (dg) {
+      dg[0] = -lambda * logj;
+      dg[1] = (w[0] + w[1] + w[2]) / 2.;
+      dg[2] = (w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + 2. * (w[3] * w[3] + w[4] * w[4] + w[5] * w[5])) / 4.;
+      dg[3] = sqrt(detCm1 + 1);
+    }
   } else {
     const double e01 = (g[0][1] + g[1][0]) / 2., e02 = (g[0][2] + g[2][0]) / 2., e12 = (g[1][2] + g[2][1]) / 2.;
     const double sv = (g[0][0] + g[0][0]) / 2. + (g[1][1] + g[1][1]) / 2. + (g[2][2] + g[2][2]) / 2.;
     const double shear = (e01 * e01 + e02 * e02 + e12 * e12) * 2 * mu;
-    en = model == 0 ? lambda * sv * sv / 2. + sv * mu + shear
-                    : lambda * (1 + sv) * (log1p_series4_e(sv) - 1) + sv * mu + shear;
+    const double llv = model == 1 ? log1p_series4_e(sv) : 0.;
+    en = model == 0 ? lambda * sv * sv / 2. + sv * mu + shear : lambda * (1 + sv) * (llv - 1) + sv * mu + shear;
+    if (dg) {
+      const double e00 = (g[0][0] + g[0][0]) / 2., e11 = (g[1][1] + g[1][1]) / 2., e22 = (g[2][2] + g[2][2]) / 2.;
+      dg[0] = model == 0 ? -lambda * sv : -lambda * llv;
+      dg[1] = sv;
+      dg[2] = e00 * e00 + e11 * e11 + e22 * e22 + 2. * (e01 * e01 + e02 * e02 + e12 * e12);
+      dg[3] = 1 + sv;
+    }
   }
-  return en * qd[0];
+  return en;
 }
 
 __global__ __launch_bounds__(512) void k_energy_op(const EnergyOpArgs a) {
@@ -164,7 +179,7 @@ __global__ __launch_bounds__(512) void k_energy_op(const EnergyOpArgs a) {
   __syncthreads();
   if (t < Q3) {
     const int i = t % Q, j = (t / Q) % Q, k = t / (Q * Q);
-    double ug[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
+    double ug[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.}, uv[3] = {0., 0., 0.};
     for (int cc = 0; cc < P; cc++)
       for (int b = 0; b < P; b++) {
         const double bk = a.interp[k * P + cc], gk = a.grad[k * P + cc], bj = a.interp[j * P + b], gj = a.grad[j * P + b];
@@ -175,13 +190,24 @@ __global__ __launch_bounds__(512) void k_energy_op(const EnergyOpArgs a) {
           for (int c = 0; c < 3; c++) {
             const double v = su[c * P3 + n];
             ug[0 * 3 + c] += w0 * v; ug[1 * 3 + c] += w1 * v; ug[2 * 3 + c] += w2 * v;
+            uv[c] += bi * bj * bk * v;
           }
         }
       }
     double qd[10];
     for (int c = 0; c < 10; c++) qd[c] = a.qdata[(size_t)e * 10 * Q3 + (size_t)c * Q3 + t];
-    se[t] = qf_energy(a.model, a.nu, a.E, ug, qd);
+    if (a.diag) {   // opDiagnostic: 8 fields, collocated with the points, summed over the elements sharing a node
+      double dg[4];
+      const double en = qf_energy(a.model, a.nu, a.E, ug, qd, dg);
+      double *dst = a.y + (a.off_e[(size_t)e * Q3 + t] & OFF_MASK);
+      for (int c = 0; c < 3; c++) atomic_add_f64(dst + c, uv[c]);
+      for (int c = 0; c < 4; c++) atomic_add_f64(dst + 3 + c, dg[c]);
+      atomic_add_f64(dst + 7, en);
+    } else {
+      se[t] = qf_energy(a.model, a.nu, a.E, ug, qd, nullptr) * qd[0];
+    }
   }
+  if (a.diag) return;
   __syncthreads();
   if (t < P3) {
     const int i = t % P, j = (t / P) % P, k = t / (P * P);

@@ -92,6 +92,8 @@ def main():
     for fam in ("LinElas", "HyperSS", "HyperFS"):   # strain energy density x w detJ (post-processing operator opEnergy)
         (en,) = call_qf(ref(fam + "Energy"), phys, Q, [ug, qdata], [1])
         out[f"{fam}Energy.energy"] = en
+        (dg,) = call_qf(ref(fam + "Diagnostic"), phys, Q, [d["x"], ug, qdata], [8])   # u := the sample coordinates
+        out[f"{fam}Diagnostic.diagnostic"] = dg
     (f1,) = call_qf(ref("SetupConstantForce"), force_dir, Q, [d["x"], qdata], [3])
     out["SetupConstantForce.force"] = f1
     (f2,) = call_qf(ref("SetupMMSForce"), phys, Q, [d["x"], qdata], [3])

@@ -373,17 +373,22 @@ static int Oracle_SetupMMSForce(void *ctx, CeedInt Q, const CeedScalar *const *i
 /* ---- strain energy (opEnergy, setuplibceed.c:651-670): energy density x w detJ ------------------
  * LinElasEnergy linElas.h:285-370, HyperSSEnergy hyperSS.h:326-412, HyperFSEnergy hyperFS.h:469-553;
  * restated AS WRITTEN, including the `strain_vol * mu` term of the first two. */
-static int oracle_energy(int model, void *ctx, CeedInt Q, const CeedScalar *const *in, CeedScalar *const *out) {
+/* diag = 0: energy density x w detJ (1 output; inputs du, qdata);
+ * diag = 1: the 8 diagnostic fields (inputs u, du, qdata): u (3), pressure, tr(strain), tr(strain^2), J, energy
+ *           density -- LinElasDiagnostic linElas.h:376-480, HyperSSDiagnostic hyperSS.h:418-523, HyperFSDiagnostic
+ *           hyperFS.h:559-662, as written */
+static int oracle_energy(int model, int diag, void *ctx, CeedInt Q, const CeedScalar *const *in, CeedScalar *const *out) {
   const OraclePhysics *ph = (const OraclePhysics *)ctx;
   double lambda, TwoMu;
   lame(ph, &lambda, &TwoMu);
   const double mu = TwoMu / 2;
+  const CeedScalar *ug = in[diag ? 1 : 0], *qd = in[diag ? 2 : 1];
   for (CeedInt i = 0; i < Q; i++) {
     m33 du, dXdx, g;
-    load_ref_grad(in[0], Q, i, du);
-    const double wdetJ = load_qdata(in[1], Q, i, dXdx);
+    load_ref_grad(ug, Q, i, du);
+    const double wdetJ = load_qdata(qd, Q, i, dXdx);
     to_physical(du, dXdx, g);
-    double en;
+    double en, press, tr1, tr2, J;
     if (model == 2) {
       double E2w[6];
       for (int m = 0; m < 6; m++) {
@@ -397,21 +402,41 @@ static int oracle_energy(int model, void *ctx, CeedInt Q, const CeedScalar *cons
           E2w[0] * E2w[2] + E2w[1] * E2w[2] - E2w[5] * E2w[5] - E2w[4] * E2w[4] - E2w[3] * E2w[3];
       const double logj = log1p_series4_shifted(detCm1) / 2.;
       en = lambda * logj * logj / 2. - mu * logj + mu * (E2w[0] + E2w[1] + E2w[2]) / 2.;
+      m33 E2;
+      unpack6(E2w, E2);
+      press = -lambda * logj;
+      tr1 = (E2[0][0] + E2[1][1] + E2[2][2]) / 2.;
+      tr2 = 0.;
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) tr2 += E2[a][b] * E2[b][a] / 4.;
+      J = sqrt(detCm1 + 1);
     } else {
       m33 e;
       sym_part(g, e);
       const double sv = e[0][0] + e[1][1] + e[2][2];
       const double shear = (e[0][1] * e[0][1] + e[0][2] * e[0][2] + e[1][2] * e[1][2]) * 2 * mu;
+      const double llv = model == 1 ? log1p_series4(sv) : 0.;
       if (model == 0) en = lambda * sv * sv / 2. + sv * mu + shear;
-      else en = lambda * (1 + sv) * (log1p_series4(sv) - 1) + sv * mu + shear;
+      else en = lambda * (1 + sv) * (llv - 1) + sv * mu + shear;
+      press = model == 0 ? -lambda * sv : -lambda * llv;
+      tr1 = sv;
+      tr2 = 0.;
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) tr2 += e[a][b] * e[b][a];
+      J = 1 + sv;
     }
-    out[0][i] = en * wdetJ;
+    if (!diag) out[0][i] = en * wdetJ;
+    else {
+      for (int c = 0; c < 3; c++) out[0][c * Q + i] = in[0][c * Q + i];
+      out[0][3 * Q + i] = press; out[0][4 * Q + i] = tr1; out[0][5 * Q + i] = tr2; out[0][6 * Q + i] = J; out[0][7 * Q + i] = en;
+    }
   }
   return 0;
 }
-static int Oracle_LinElasEnergy(void *ctx, CeedInt Q, const CeedScalar *const *in, CeedScalar *const *out) { return oracle_energy(0, ctx, Q, in, out); }
-static int Oracle_HyperSSEnergy(void *ctx, CeedInt Q, const CeedScalar *const *in, CeedScalar *const *out) { return oracle_energy(1, ctx, Q, in, out); }
-static int Oracle_HyperFSEnergy(void *ctx, CeedInt Q, const CeedScalar *const *in, CeedScalar *const *out) { return oracle_energy(2, ctx, Q, in, out); }
+static int Oracle_LinElasEnergy(void *ctx, CeedInt Q, const CeedScalar *const *in, CeedScalar *const *out) { return oracle_energy(0, 0, ctx, Q, in, out); }
+static int Oracle_HyperSSEnergy(void *ctx, CeedInt Q, const CeedScalar *const *in, CeedScalar *const *out) { return oracle_energy(1, 0, ctx, Q, in, out); }
+static int Oracle_HyperFSEnergy(void *ctx, CeedInt Q, const CeedScalar *const *in, CeedScalar *const *out) { return oracle_energy(2, 0, ctx, Q, in, out); }
+static int Oracle_LinElasDiagnostic(void *ctx, CeedInt Q, const CeedScalar *const *in, CeedScalar *const *out) { return oracle_energy(0, 1, ctx, Q, in, out); }
+static int Oracle_HyperSSDiagnostic(void *ctx, CeedInt Q, const CeedScalar *const *in, CeedScalar *const *out) { return oracle_energy(1, 1, ctx, Q, in, out); }
+static int Oracle_HyperFSDiagnostic(void *ctx, CeedInt Q, const CeedScalar *const *in, CeedScalar *const *out) { return oracle_energy(2, 1, ctx, Q, in, out); }
 
 /* ------------------------------------------------------------------------- */
 CEED_EXTERN CeedQFunctionUser OracleGetQFunction(const char *name) {
@@ -429,6 +454,9 @@ CEED_EXTERN CeedQFunctionUser OracleGetQFunction(const char *name) {
       {"LinElasEnergy", Oracle_LinElasEnergy},
       {"HyperSSEnergy", Oracle_HyperSSEnergy},
       {"HyperFSEnergy", Oracle_HyperFSEnergy},
+      {"LinElasDiagnostic", Oracle_LinElasDiagnostic},
+      {"HyperSSDiagnostic", Oracle_HyperSSDiagnostic},
+      {"HyperFSDiagnostic", Oracle_HyperFSDiagnostic},
   };
   for (size_t i = 0; i < sizeof tab / sizeof tab[0]; i++)
     if (!strcmp(tab[i].n, name)) return tab[i].f;

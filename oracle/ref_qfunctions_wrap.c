@@ -27,6 +27,7 @@ static const struct { const char *name; CeedQFunctionUser f; const char *loc; } 
     REF_ENTRY(HyperFSdF),  REF_ENTRY(SetupConstantForce),
     REF_ENTRY(SetupMMSForce), REF_ENTRY(MMSTrueSoln),
     REF_ENTRY(LinElasEnergy), REF_ENTRY(HyperSSEnergy), REF_ENTRY(HyperFSEnergy),
+    REF_ENTRY(LinElasDiagnostic), REF_ENTRY(HyperSSDiagnostic), REF_ENTRY(HyperFSDiagnostic),
 };
 
 CEED_EXTERN CeedQFunctionUser RefGetQFunction(const char *name) {

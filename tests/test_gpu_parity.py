@@ -397,3 +397,18 @@ def test_strain_energy_operator_matches_oracle(oracle, gpu, problem):
         X = c.vector(p.lsize()).set_array(p.smooth_state(0.05))
         res.append((se.compute(X), se.eloc.to_numpy()))
     assert abs(res[1][0] - res[0][0]) < TOL * abs(res[0][0]) and rel_err(res[1][1], res[0][1]) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("problem", ["linElas", "hyperSS", "hyperFS"])
+def test_diagnostic_operator_matches_oracle(oracle, gpu, problem):
+    """opDiagnostic (setuplibceed.c:679-737) incl. its SetupGeo on the GLL points, on the device."""
+    from ceedpetscsolid_amd.postprocess import Diagnostics
+    mesh = hollow_cylinder_mesh(2, 8, 3)
+    res = []
+    for c in (oracle, gpu):
+        p = SolidProblem(c, mesh, 3, problem, nu=0.3, E=1e3, bc_sides=[998], multigrid="none")
+        d = Diagnostics(p, problem)
+        res.append(d.compute(c.vector(p.lsize()).set_array(p.smooth_state(0.05))))
+    for k in range(8):
+        assert rel_err(res[1][:, k], res[0][:, k]) < TOL, k

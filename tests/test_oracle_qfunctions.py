@@ -49,6 +49,9 @@ CASES = [
     ("LinElasEnergy", lambda g: [g["ug"], g["SetupGeo.qdata"]], [1], ["LinElasEnergy.energy"]),
     ("HyperSSEnergy", lambda g: [g["ug"], g["SetupGeo.qdata"]], [1], ["HyperSSEnergy.energy"]),
     ("HyperFSEnergy", lambda g: [g["ug"], g["SetupGeo.qdata"]], [1], ["HyperFSEnergy.energy"]),
+    ("LinElasDiagnostic", lambda g: [g["x"], g["ug"], g["SetupGeo.qdata"]], [8], ["LinElasDiagnostic.diagnostic"]),
+    ("HyperSSDiagnostic", lambda g: [g["x"], g["ug"], g["SetupGeo.qdata"]], [8], ["HyperSSDiagnostic.diagnostic"]),
+    ("HyperFSDiagnostic", lambda g: [g["x"], g["ug"], g["SetupGeo.qdata"]], [8], ["HyperFSDiagnostic.diagnostic"]),
 ]
 
 
