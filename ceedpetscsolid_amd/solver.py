@@ -105,23 +105,47 @@ class NewtonPMG:
         self.ksp_rtol, self.snes_rtol, self.snes_maxit, self.verbose = ksp_rtol, snes_rtol, snes_maxit, verbose
         self.nlev = len(prob.levels)
         c = self.ceed
-        mk = lambda lv: c.vector(prob.lsize(lv)).set_value(0.0)
+        # Several ranks (one element partition per rank, halo.py): `halo` is one HaloExchange per multigrid level.
+        # Every vector then aliases a torch tensor (host memory for the CPU oracle, device memory otherwise; the
+        # Ceed's stream must be torch's current stream, as in bench.py), so the interface sums of halo.add() act on
+        # the operators' outputs in place: after each Jacobian / residual / transfer / diagonal, the L -> G sum of
+        # matops.c:57.  Dots are weighted by ownership and all-reduced.
+        self.halos = None
+        if halo is not None and not isinstance(halo, (list, tuple)):
+            if halo.world > 1 and len(prob.levels) > 1:
+                raise ValueError("a multi-rank multigrid solve needs one HaloExchange per level")
+            halo = [halo]
+        if halo is not None and halo[-1].world > 1:
+            if len(halo) != len(prob.levels):
+                raise ValueError("one HaloExchange per multigrid level expected")
+            if self.graph:
+                raise ValueError("graph=True is a single-rank feature (torch.distributed calls cannot be recorded)")
+            self.halos = list(halo)
+        self.halo = self.halos[-1] if self.halos else None
+        mk = lambda lv: self._vec(prob.lsize(lv), lv)
         self.w = [{k: mk(lv) for k in ("x", "b", "r", "d", "t", "dinv", "z")} for lv in range(self.nlev)]
         self.emax = [1.0] * self.nlev
         self._x0 = {}
         n = prob.lsize()
-        self.U, self.R, self.dU, self.Xloc, self.bcv, self.Rtry, self.Utry = (c.vector(n).set_value(0.0) for _ in range(7))
-        self.kp, self.kz, self.kAp, self.kzold = (c.vector(n).set_value(0.0) for _ in range(4))
+        top = self.nlev - 1
+        self.U, self.R, self.dU, self.Xloc, self.bcv, self.Rtry, self.Utry = (self._vec(n, top) for _ in range(7))
+        self.kp, self.kz, self.kAp, self.kzold = (self._vec(n, top) for _ in range(4))
         lvf = prob.levels[prob.fine]
         self.free = (lvf.mask == 0)
-        self.weight = None
-        if halo is not None and halo.world > 1:
-            self.weight = c.vector(n).set_array(halo.owner_weight * self.free)
+        self.weights = [None] * self.nlev
+        if self.halos:
+            for lv in range(self.nlev):
+                wv = self._vec(prob.lsize(lv), lv)
+                self._set(wv, self.halos[lv].owner_weight * (prob.levels[lv].mask == 0))
+                self.weights[lv] = wv
+                self._refresh_multiplicity(lv)
         # body force vector (opSetupForce output, setuplibceed.c:555-583): SNESSolve(snes, F, U) solves
         # residual(U) = load * F on the unconstrained dofs (elasticity.c:645-654)
         self.fv = None
         if forcing is not None:
-            self.fv = c.vector(n).set_array(np.asarray(forcing, dtype=np.float64) * self.free)
+            self.fv = self._vec(n, top)
+            self._set(self.fv, np.asarray(forcing, dtype=np.float64) * self.free)
+            self._halo_sum(top, self.fv)
         self.load = 1.0
         self.stats = SolveStats()
         self._bc_nodes = self._collect_bc_nodes()
@@ -136,30 +160,74 @@ class NewtonPMG:
     def pmult(self, w, x, y):
         self.L.chk(self.L.lib.CeedXVectorPointwiseMult(w.h, x.h, y.h))
 
-    def dot(self, x, y, fine_weight=False) -> float:
+    def dot(self, x, y, fine_weight=False, lv=None) -> float:
+        """x . y; on several ranks each dof counts once (owner weights of level `lv`, default the fine level)."""
         r = C.c_double()
-        wv = self.weight.h if (fine_weight and self.weight is not None) else None
+        lv = self.nlev - 1 if lv is None else lv
+        wv = self.weights[lv].h if self.weights[lv] is not None else None
         self.L.chk(self.L.lib.CeedXVectorDot(x.h, y.h, wv, C.byref(r)))
         v = r.value
-        if self.halo is not None and self.halo.world > 1:
+        if self.halos:
             import torch, torch.distributed as dist
-            t = torch.tensor([v], dtype=torch.float64)
-            dist.all_reduce(t)
+            t = torch.tensor([v], dtype=torch.float64, device="cpu" if self.halos[lv].device.type == "cpu" or self.halos[lv].stage_host else self.halos[lv].device)
+            dist.all_reduce(t, group=self.halos[lv].group)
             v = float(t.item())
         return v
 
-    def _halo_add(self, vec):
-        if self.halo is not None and self.halo.world > 1:
-            raise NotImplementedError("multi-rank solve: wrap the vectors' device buffers as torch tensors and call halo.add")
+    # ---- vectors that alias torch tensors (several ranks only) ----------------------------------------
+    def _vec(self, n, lv):
+        c = self.ceed
+        if not self.halos:
+            return c.vector(n).set_value(0.0)
+        import torch
+        dev = self.halos[lv].device
+        v = c.vector(n)
+        v.t = torch.zeros(n, dtype=torch.float64, device=dev)
+        if dev.type == "cuda":
+            v.set_device_pointer(v.t.data_ptr())
+        else:
+            v.set_array(v.t.numpy(), copy=False)
+        return v
+
+    def _set(self, vec, arr):
+        """vec := arr (host array), keeping the torch alias intact."""
+        if hasattr(vec, "t"):
+            import torch
+            vec.t.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)))
+            self._touched(vec)
+        else:
+            vec.set_array(arr)
+
+    def _touched(self, vec):
+        """The tensor behind a device vector was modified outside the Ceed: drop its host mirror."""
+        if vec.t.device.type == "cuda":
+            vec.set_device_pointer(vec.t.data_ptr())
+
+    def _halo_sum(self, lv, vec):
+        """Interface sum of an operator output at level lv (the DMLocalToGlobal(ADD_VALUES) of matops.c:57)."""
+        if self.halos:
+            if vec.t.device.type == "cuda":
+                self.ceed.synchronize()
+            self.halos[lv].add(vec.t)
+            self._touched(vec)
+
+    def _refresh_multiplicity(self, lv):
+        """multVec of misc.c:115-143 counted over ALL ranks: 1 / (halo-summed element multiplicity)."""
+        level = self.p.levels[lv]
+        m = self._vec(self.p.lsize(lv), lv)
+        level.Erestrictu.multiplicity(m)
+        self._halo_sum(lv, m)
+        self._set(level.multinv, 1.0 / m.to_numpy())
 
     # ---- operators ---------------------------------------------------------------------------
     def A(self, lv, x, y):
         if lv == 0 and self.asm is not None:
             self.asm.apply(x, y)
             self.stats.coarse_spmv += 1
-            return
-        self.p.apply_jacobian(lv, x, y)
-        self.stats.jacobian_applies += 1
+        else:
+            self.p.apply_jacobian(lv, x, y)
+            self.stats.jacobian_applies += 1
+        self._halo_sum(lv, y)
 
     def _collect_bc_nodes(self):
         from .mesh import side_set_nodes
@@ -186,6 +254,7 @@ class NewtonPMG:
         self.copy(self.Xloc, U)
         self.axpby(self.Xloc, 1.0, self.bcv, 1.0)
         self.p.form_residual(self.Xloc, R)
+        self._halo_sum(self.nlev - 1, R)
         if self.fv is not None:
             self.axpby(R, -self.load, self.fv, 1.0)
         self.stats.residual_evals += 1
@@ -199,25 +268,51 @@ class NewtonPMG:
         for lv in range(self.nlev):
             w = self.w[lv]
             self.p.get_diag(lv, w["dinv"])
+            self._halo_sum(lv, w["dinv"])
             d = w["dinv"].to_numpy()
             mask = self.p.levels[lv].mask != 0
             d[mask] = 1.0                       # constrained rows: identity
-            w["dinv"].set_array(1.0 / d)
+            self._set(w["dinv"], 1.0 / d)
             # largest eigenvalue of D^-1 A by power iteration from a noisy start (the reference lets
             # PETSc estimate it with a few CG-Lanczos steps on a noisy right-hand side, :546-549).
             # The start vector is drawn once per level; no BLAS on the host (a threaded BLAS call
             # leaves its worker pool spinning, which starves a CPU-quota'd process for ~0.1 s a call).
             if lv not in self._x0:
-                x = np.random.default_rng(1234 + lv).uniform(-1, 1, d.size) * (~mask)
-                self._x0[lv] = x / np.sqrt(np.square(x).sum())
-            w["x"].set_array(self._x0[lv])
-            lam = 1.0
-            for _ in range(12):
-                self.A(lv, w["x"], w["t"])
-                self.pmult(w["t"], w["t"], w["dinv"])
-                lam = np.sqrt(self.dot(w["t"], w["t"]))
-                self.axpby(w["x"], 1.0 / lam, w["t"], 0.0)
-            self.emax[lv] = lam
+                if self.halos:   # shared nodes must get the same value on every rank: a hash of the coordinates
+                    X = self.p.levels[lv].dofmap.node_coords
+                    k = np.array([[12.9898, 78.233, 37.719], [93.989, 67.345, 24.113], [45.164, 11.135, 83.951]])
+                    v = np.sin(X @ k.T) * 437.5453
+                    x = (2.0 * (v - np.floor(v)) - 1.0).reshape(-1) * (~mask)
+                else:
+                    x = np.random.default_rng(1234 + lv).uniform(-1, 1, d.size) * (~mask)
+                self._x0[lv] = x / np.sqrt(np.square(x).sum())     # (any positive scale: the iteration renormalises)
+            # largest eigenvalue of D^-1 A: 10 steps of Jacobi-preconditioned CG on the noisy right-hand side and
+            # the largest eigenvalue of its Lanczos tridiagonal -- what KSPChebyshevEstEig does (elasticity.c:546-549).
+            # (A plain power iteration from the same vector was 2x low after 12 steps on the config-3 mesh.)
+            r, z, pv, Ap = w["r"], w["z"], w["d"], w["t"]
+            self._set(r, self._x0[lv])
+            self.pmult(z, r, w["dinv"]); self.copy(pv, z)
+            rz = self.dot(r, z, lv=lv)
+            alphas, betas = [], []
+            for _ in range(10):
+                self.A(lv, pv, Ap)
+                pAp = self.dot(pv, Ap, lv=lv)
+                if not (pAp > 0.0 and rz > 0.0):
+                    break
+                alpha = rz / pAp
+                self.axpby(r, -alpha, Ap, 1.0)
+                self.pmult(z, r, w["dinv"])
+                rz_new = self.dot(r, z, lv=lv)
+                alphas.append(alpha); betas.append(rz_new / rz)
+                self.axpby(pv, 1.0, z, rz_new / rz)
+                rz = rz_new
+            k = len(alphas)
+            T = np.zeros((max(k, 1), max(k, 1)))
+            for j in range(k):
+                T[j, j] = 1.0 / alphas[j] + (betas[j - 1] / alphas[j - 1] if j else 0.0)
+                if j + 1 < k:
+                    T[j, j + 1] = T[j + 1, j] = np.sqrt(max(betas[j], 0.0)) / alphas[j]
+            self.emax[lv] = float(np.linalg.eigvalsh(T).max()) if k else 1.0
 
     def chebyshev(self, lv, b, x, its, zero_guess, lmin_frac=0.1):
         """Chebyshev iteration on D^-1 A with bounds [0.1, 1.1] x emax (KSPChebyshevEstEigSet(0,0.1,0,1.1))."""
@@ -249,16 +344,16 @@ class NewtonPMG:
         x.set_value(0.0)
         self.copy(r, b)
         self.pmult(z, r, w["dinv"]); self.copy(d, z)
-        rz = self.dot(r, z)
+        rz = self.dot(r, z, lv=0)
         rz0 = rz
         if rz0 <= 0.0:
             return
         for it in range(self.coarse_maxit):
             self.A(0, d, t)
-            alpha = rz / self.dot(d, t)
+            alpha = rz / self.dot(d, t, lv=0)
             self.axpby(x, alpha, d, 1.0); self.axpby(r, -alpha, t, 1.0)
             self.pmult(z, r, w["dinv"])
-            rz_new = self.dot(r, z)
+            rz_new = self.dot(r, z, lv=0)
             self.stats.coarse_its += 1
             if rz_new <= self.coarse_rtol ** 2 * rz0:
                 break
@@ -281,8 +376,10 @@ class NewtonPMG:
         self.A(lv, x, w["t"])
         self.copy(w["z"], b); self.axpby(w["z"], -1.0, w["t"], 1.0)      # residual
         self.p.restrict(lv, w["z"], wc["b"])                                # Restrict_Ceed
+        self._halo_sum(lv - 1, wc["b"])
         self.vcycle(lv - 1, wc["b"], wc["x"])
         self.p.prolong(lv, wc["x"], w["z"])                                 # Prolong_Ceed
+        self._halo_sum(lv, w["z"])
         self.axpby(x, 1.0, w["z"], 1.0)
         self.chebyshev(lv, b, x, self.smooth_its, False)
 
@@ -352,7 +449,7 @@ class NewtonPMG:
         for inc in range(1, num_increments + 1):
             load = inc / num_increments
             self.load = load
-            self.bcv.set_array(self.bc_values(load))
+            self._set(self.bcv, self.bc_values(load))
             self.residual(self.U, self.R)
             rnorm0 = np.sqrt(self.dot(self.R, self.R, True))
             rnorm = rnorm0

@@ -35,15 +35,34 @@ ap.add_argument("--coarse-maxit", type=int, default=200)
 ap.add_argument("--coarse-rtol", type=float, default=1e-3)
 args = ap.parse_args()
 
+# several GPUs: `python -m torch.distributed.run --nproc-per-node N examples/solve_config3.py ...` -- one element
+# partition (z-slabs) per rank, halo sums inside the solver (SOLVE_DIST_BACKEND=gloo rehearses it on one GPU)
+world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+halos = None
+mesh = load_mesh_npz(args.mesh)
+if world > 1:
+    import torch, torch.distributed as dist
+    from ceedpetscsolid_amd.halo import HaloExchange
+    from ceedpetscsolid_amd.mesh import partition_slabs, submesh
+    backend = os.environ.get("SOLVE_DIST_BACKEND", "gloo" if args.oracle else "nccl")
+    if not args.oracle:
+        torch.cuda.set_device(local_rank if backend == "nccl" else 0)
+    dist.init_process_group(backend)
+    mesh = submesh(mesh, partition_slabs(mesh, world)[rank])
 if args.oracle:
     lib = cd.CeedLib(os.path.join(ROOT, "oracle", "liboracle_ceed.so")); ceed = cd.Ceed(lib, "/cpu/self/oracle")
 else:
     lib = cd.CeedLib(cd.PRODUCT_LIB); ceed = cd.Ceed(lib, "/gpu/hip/mi355x")
-mesh = load_mesh_npz(args.mesh)
+    if world > 1:
+        ceed.set_stream(torch.cuda.current_stream().cuda_stream)
 t0 = time.perf_counter()
-prob = SolidProblem(ceed, mesh, args.degree, args.problem, nu=args.nu, E=args.E, bc_sides=[998, 999])
+bc_sides = [s for s in (998, 999) if s in mesh.side_sets and len(mesh.side_sets[s])]
+prob = SolidProblem(ceed, mesh, args.degree, args.problem, nu=args.nu, E=args.E, bc_sides=bc_sides)
+if world > 1:
+    halos = [HaloExchange(mesh, lv.dofmap, device="cpu" if args.oracle else torch.device("cuda", torch.cuda.current_device()))
+             for lv in prob.levels]
 tr = tuple(float(t) for t in args.translate.split(","))
-solver = NewtonPMG(prob, clamp={998: dict(translate=tr), 999: dict()}, verbose=args.verbose,
+solver = NewtonPMG(prob, clamp={s: (dict(translate=tr) if s == 998 else dict()) for s in bc_sides}, halo=halos, verbose=args.verbose and rank == 0,
                    coarse_maxit=args.coarse_maxit, coarse_rtol=args.coarse_rtol, coarse=args.coarse, graph=args.graph,
                    coarse_cheb_its=args.coarse_cheb_its, coarse_cheb_ratio=args.coarse_cheb_ratio)
 t_setup = time.perf_counter() - t0
@@ -54,6 +73,10 @@ out = {"resource": ceed.resource, "problem": args.problem, "mesh": os.path.basen
        "translate_998": list(tr), "coarse_solver": args.coarse, "vcycle_graph": args.graph, "load_increments": st.increments, "converged": st.converged, "snes_its": st.newton_its, "ksp_its": st.ksp_its,
        "coarse_cg_its": st.coarse_its, "jacobian_applies": st.jacobian_applies, "residual_evals": st.residual_evals, "coarse_spmv": st.coarse_spmv,
        "setup_s": t_setup, "snes_solve_s": st.seconds,
-       "MDoFs_per_s_in_SNES": 1e-6 * prob.n_free() * st.ksp_its / st.seconds,   # elasticity.c:755-764
+       "ranks": world,
+       "MDoFs_per_s_in_SNES": 1e-6 * (halos[-1].global_count((prob.levels[prob.fine].mask == 0).astype(np.float64)) if halos else prob.n_free()) * st.ksp_its / st.seconds,   # elasticity.c:755-764
        "max_abs_displacement": np.abs(u).max(axis=0).tolist(), "final_residual_norm": st.history[-1][4] if st.history else None}
-print(json.dumps(out))
+if rank == 0:
+    print(json.dumps(out))
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()

@@ -50,3 +50,29 @@ def test_two_rank_jacobian_matches_single_rank(oracle, mode):
         assert np.array_equal(kfull[idx], kp[shared_kind])
         got = part["y"].reshape(-1, 3)[shared_kind]
         assert rel_err(got, yref[idx]) < 1e-12
+
+
+@pytest.mark.parametrize("coarse", ["chebyshev", "assembled"])
+def test_two_rank_solve_matches_single_rank(oracle, coarse):
+    """The whole Newton - PCG - pMG solve on two element partitions (halo sums after every operator, ownership-
+    weighted dots, globally counted multiplicity) gives the single-rank solution."""
+    import _solver_worker
+    from ceedpetscsolid_amd.solver import NewtonPMG
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        initfile = os.path.join(d, "init")
+        mp.spawn(_solver_worker.run, args=(world, initfile, d, coarse), nprocs=world, join=True)
+        parts = [np.load(os.path.join(d, f"solve_{r}.npz")) for r in range(world)]
+    full = hollow_cylinder_mesh(1, 6, 2 * world, z0=-1.0, z1=1.0)
+    p = SolidProblem(oracle, full, 2, "hyperSS", nu=0.3, E=10.0, bc_sides=[998, 999])
+    s = NewtonPMG(p, clamp={998: dict(translate=(0.0, -0.05, 0.1)), 999: dict()}, coarse=coarse, coarse_cheb_its=20,
+                  coarse_cheb_ratio=50.0)
+    st = s.solve(1)
+    assert st.converged
+    X = p.levels[p.fine].dofmap.node_coords
+    key = {tuple(np.round(x, 9)): i for i, x in enumerate(X)}
+    U = s.U.to_numpy().reshape(-1, 3)
+    for part in parts:
+        assert bool(part["converged"]) and int(part["newton"]) == st.newton_its
+        idx = np.array([key[tuple(np.round(x, 9))] for x in part["coords"]])
+        assert rel_err(part["U"].reshape(-1, 3), U[idx]) < 1e-7

@@ -33,7 +33,7 @@ def test_solver_converges_on_oracle(oracle, problem, incs):
     u = s.U.to_numpy()
     # converged state: residual with the final boundary values is small relative to the first residual
     first = [h[4] for h in st.history if h[0] == incs][0]
-    assert st.history[-1][4] < 1e-6 * max(first, 1e-300) or st.history[-1][4] < 1e-10
+    assert st.history[-1][4] < 1e-6 * max(first, 1e-300) or st.history[-1][4] < 1e-9
     assert np.all(u[p.levels[p.fine].mask != 0] == 0.0)          # L-layout: constrained entries stay zero
     if problem == "linElas":
         assert st.newton_its == 1                                   # linear problem: one Newton step
