@@ -412,3 +412,21 @@ def test_diagnostic_operator_matches_oracle(oracle, gpu, problem):
         res.append(d.compute(c.vector(p.lsize()).set_array(p.smooth_state(0.05))))
     for k in range(8):
         assert rel_err(res[1][:, k], res[0][:, k]) < TOL, k
+
+
+@pytest.mark.gpu
+def test_reference_testargs_case_on_the_device(gpu):
+    """The reference's ONLY scripted test, elasticity.c:36: `-test -degree 3 -nu 0.3 -E 1 -dm_plex_box_faces 3,3,3`
+    (MMS forcing, BCMMS on the whole boundary); it passes when the relative L2 error is <= 0.05 (:807-811)."""
+    from ceedpetscsolid_amd.solver import NewtonPMG
+    p = SolidProblem(gpu, box_mesh(3, 3, 3), 3, "linElas", nu=0.3, E=1.0, bc_all_boundary=True)
+    lv = p.levels[p.fine]
+    f = _forcing_and_true(gpu, p, "mms")
+    ut = _forcing_and_true(gpu, p, "true")
+    mult = gpu.vector(p.lsize()); lv.Erestrictu.multiplicity(mult)
+    ut = ut / mult.to_numpy()
+    s = NewtonPMG(p, mms=True, forcing=f)
+    st = s.solve(1)
+    assert st.converged
+    err = np.linalg.norm(s.U.to_numpy() + s.bc_values(1.0) - ut) / np.linalg.norm(ut)
+    assert err <= 0.05, err
