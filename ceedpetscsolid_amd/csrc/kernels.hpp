@@ -56,7 +56,7 @@ struct FusedGradArgs {
   unsigned long long *stamps;  // diagnostic builds only (-DCPS_STAMPS): 8 s_memtime stamps per wave
   double *evec;                // if set: element results go here ([elem][P^3][3], plain coalesced stores)
                                // and launch_assemble() sums them into y; else f64 atomics straight into y
-  int variant;                 // host-side dispatch only: 0 = row kernel (kernel_fused_grad.hpp),
+  int variant;                // host-side dispatch only: 0 = row kernel (kernel_fused_grad.hpp),
                                // 1 = pencil kernel (kernel_fused_pencil.hpp)
 };
 
