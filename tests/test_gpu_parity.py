@@ -135,6 +135,28 @@ def test_log1p_range_shift_branches_on_gpu(oracle, gpu):
         assert rel_err(yb.to_numpy(), ya.to_numpy()) < TOL
 
 
+@pytest.mark.parametrize("nu,amp", [(0.49, 0.15), (0.3, 1e-7), (0.3, 0.3), (0.45, 0.3)],
+                         ids=["nearly incompressible", "tiny strain", "large strain", "large strain nu .45"])
+def test_hyperfs_tangent_spatial_form_extremes(oracle, gpu, nu, amp):
+    """The device evaluates HyperFSdF (hyperFS.h:286-464) in the algebraically equal spatial form
+    dP = mu grad(du) + (lambda tr(h) I - f h^T) F^-T (qfunctions_device.hpp); the oracle keeps the reference's
+    order of operations.  The two must agree to the parity bar where rounding differs most: lambda >> mu,
+    strains at rounding level, and strains of 30 % on distorted elements."""
+    mesh = distorted_box(3, 2, 2, seed=4, amp=0.15)
+    pa, pb = build_pair(oracle, gpu, mesh, 3, "hyperFS", nu=nu, E=3.0, bc_sides=[1])
+    n = pa.lsize()
+    u = pa.smooth_state(amp)
+    xa, xb = vec_pair(pa, pb, n, u); ya, yb = vec_pair(pa, pb, n)
+    pa.form_residual(xa, ya); pb.form_residual(xb, yb)
+    x = np.random.default_rng(11).uniform(-1, 1, n)
+    xa, xb = vec_pair(pa, pb, n, x)
+    pa.apply_jacobian(pa.fine, xa, ya); pb.apply_jacobian(pb.fine, xb, yb)
+    assert rel_err(yb.to_numpy(), ya.to_numpy()) < TOL
+    da, db = vec_pair(pa, pb, n)
+    pa.get_diag(pa.fine, da); pb.get_diag(pb.fine, db)
+    assert rel_err(db.to_numpy(), da.to_numpy()) < TOL
+
+
 def test_config2_cube4096_p3_linelas(oracle, gpu):
     """BASELINE config 2: linElas, cube8_4096e_6ss_s, degree 3, Jacobian apply vs the CPU path."""
     mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cube8_4096e_6ss_s.npz"))
