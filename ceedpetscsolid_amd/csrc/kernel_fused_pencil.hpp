@@ -86,8 +86,28 @@ CPS_DEV void pencil_st(ldsp_t a, const double *r) {
 // out of the element loop (150 SGPRs: it then spilled them to VGPR lanes, 900 v_readlane per group).
 typedef const __attribute__((address_space(4))) double *ktab_t;
 CPS_DEV ktab_t ktab_fresh(ktab_t p) {
-  asm volatile("" : "+s"(p));
+  // "memory": the previous pass's last stores (and the FMAs feeding them) stay above this point, so two passes'
+  // tables are never live together (they do not fit the SGPR file: 16 of them were spilled to VGPR lanes)
+  asm volatile("" : "+s"(p) : : "memory");
   return p;
+}
+// a fresh table pointer that the compiler cannot use before the N values at `dep` have been computed
+template <int N>
+CPS_DEV ktab_t ktab_fresh_after(ktab_t p, const double *dep) {
+#pragma unroll
+  for (int i = 0; i < N; i++) asm volatile("" : "+s"(p) : "v"(dep[i]));
+  return p;
+}
+// The launch arguments are read the same way: a laundered pointer into the kernarg segment at every use site, so
+// that pointers and scalars are re-read with s_load (no VALU) where they are needed instead of living in SGPRs
+// through the whole element loop, where the register allocator spills them to VGPR lanes (v_readlane per use).
+typedef const __attribute__((address_space(4))) FusedGradArgs *kargs_t;
+template <bool LAUNDER>
+CPS_DEV kargs_t kargs_fresh() {
+  static_assert(sizeof(BasisTables) % 8 == 0, "second kernel argument follows the tables without padding");
+  auto p = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(BasisTables);
+  if constexpr (LAUNDER) asm volatile("" : "+s"(p));
+  return (kargs_t)p;
 }
 // out[o] += sum_m M(o, m) in[m];  M(o, m) = TR ? tab[m * LD + o] : tab[o * LD + m]  (wave-uniform -> SGPR operands)
 template <int NOUT, int NIN, int LD, bool TR>
@@ -105,20 +125,59 @@ CPS_DEV bool pencil_ok(int lane, int r, int ntask) { return (r + 1) * 64 <= ntas
 // applies the NOUT x NIN matrix and writes NOUT entries to array DST (DST == SRC: in place).  All
 // rounds' reads are issued first, so the waits are counted ones and the FMAs of one round overlap the
 // reads of the next; tasks are disjoint pencils, so reads may pass the in-place writes of other rounds.
+// A NOUT x NIN table is 2 NOUT NIN SGPRs: 50 at 5 x 5, but 98 at 7 x 7 and 128 at 8 x 8 -- more than the SGPR file, and
+// the register allocator then spills coefficients to VGPR lanes (~950 v_readlane / v_writelane per element at Q = 7,
+// a fifth of the VALU work).  Larger tables are therefore applied in SPLITS of whole output rows, each split loaded
+// (s_load) only after the previous one's FMAs: all rounds of a pass keep their inputs and outputs in VGPRs meanwhile.
+template <int NOUT, int NIN> constexpr int table_splits() { return NOUT * NIN <= 30 ? 1 : (NOUT * NIN <= 56 ? 2 : 3); }
+// rows [O0, O1) of the product of pencil_mac
+template <int O0, int O1, int NIN, int LD, bool TR>
+CPS_DEV void pencil_mac_rows(ktab_t tab, const double *in, double *out) {
+#pragma unroll
+  for (int o = O0; o < O1; o++) {
+#pragma unroll
+    for (int m = 0; m < NIN; m++) out[o] += (TR ? tab[m * LD + o] : tab[o * LD + m]) * in[m];
+  }
+}
+// out[r] += M in[r] for all rounds r of a pass, the table taken in table_splits() row blocks
+// (DEP0: the first block, too, waits for the values already in `out` -- a previous product accumulated there)
+template <int NOUT, int NIN, int LD, bool TR, int R, bool DEP0 = false, int S = 0>
+CPS_DEV void mac_rounds(ktab_t table, const double (&in)[R][NIN], double (&out)[R][NOUT], int lane, int ntask) {
+  constexpr int NS = table_splits<NOUT, NIN>(), H = (NOUT + NS - 1) / NS;
+  if constexpr (S < NS) {
+    const ktab_t t = (S > 0 || DEP0) ? ktab_fresh_after<R * NOUT>(table, &out[0][0]) : ktab_fresh(table);
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if (pencil_ok(lane, r, ntask)) pencil_mac_rows<S * H, ((S + 1) * H < NOUT ? (S + 1) * H : NOUT), NIN, LD, TR>(t, in[r], out[r]);
+    mac_rounds<NOUT, NIN, LD, TR, R, DEP0, S + 1>(table, in, out, lane, ntask);
+  }
+}
 template <int NIN, int NOUT, int LD, bool TR, int SB, int SRC, int DST, int R>
 CPS_DEV void pencil_pass(ktab_t table, const ldsp_t (&addr)[R], int lane, int ntask) {
-  const ktab_t t = ktab_fresh(table);
   double in[R][NIN];
 #pragma unroll
   for (int r = 0; r < R; r++)
     if (pencil_ok(lane, r, ntask)) pencil_ld<NIN, SB, SRC>(addr[r], in[r]);
+  if constexpr (table_splits<NOUT, NIN>() == 1) {
+    const ktab_t t = ktab_fresh(table);
 #pragma unroll
-  for (int r = 0; r < R; r++)
-    if (pencil_ok(lane, r, ntask)) {
-      double out[NOUT] = {};
-      pencil_mac<NOUT, NIN, LD, TR>(t, in[r], out);
-      pencil_st<NOUT, SB, DST>(addr[r], out);
-    }
+    for (int r = 0; r < R; r++)
+      if (pencil_ok(lane, r, ntask)) {
+        double out[NOUT] = {};
+        pencil_mac<NOUT, NIN, LD, TR>(t, in[r], out);
+        pencil_st<NOUT, SB, DST>(addr[r], out);
+      }
+  } else {
+    double out[R][NOUT];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+      for (int o = 0; o < NOUT; o++) out[r][o] = 0.;
+    mac_rounds<NOUT, NIN, LD, TR, R>(table, in, out, lane, ntask);
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if (pencil_ok(lane, r, ntask)) pencil_st<NOUT, SB, DST>(addr[r], out[r]);
+  }
 }
 
 #ifndef CPS_PENCIL_MINW
@@ -127,6 +186,9 @@ CPS_DEV void pencil_pass(ktab_t table, const ldsp_t (&addr)[R], int lane, int nt
 #ifndef CPS_PENCIL_NSET
 #define CPS_PENCIL_NSET 2   // q-point register sets: 2 = every round's data is requested two rounds ahead
 #endif                      // (231 VGPRs with the hyperFS tangent; 1 set: 190 VGPRs, 4-6 % slower)
+#ifndef CPS_PENCIL_NSET_BIGQ
+#define CPS_PENCIL_NSET_BIGQ 1   // Q >= 6: the split-table passes keep all rounds' pencils in VGPRs; a second q-point set
+#endif                           // would push the hyperFS tangent past 256 VGPRs (26 spilled to scratch)
 template <int P, int Q, int QF>
 __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const BasisTables tab_, const FusedGradArgs a) {
   static_assert(offsetof(BasisTables, interp) == 0 && offsetof(BasisTables, colo) == 8 * MAXN1D * MAXN1D &&
@@ -141,6 +203,9 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
   constexpr int oA = 0, oBX = 8 * G::ARR, oBZ = 16 * G::ARR;         // byte offsets of the arrays
   constexpr bool ST_IN = QFTraits<QF>::state_in, ST_OUT = QFTraits<QF>::state_out;
   static_assert(P <= Q, "interpolation to at least as many points as nodes");
+  // re-read the launch arguments at every use (kargs_fresh) where that frees the SGPR file of spills: Q <= 5.  At
+  // Q >= 6 one coefficient table alone (2 Q^2 SGPRs) overflows it and the extra scalar-load waits only cost (measured).
+  constexpr bool KA = Q <= 5;
 
   __shared__ __attribute__((aligned(16))) double slab[E * SE];
   const ldsp_t lds0 = (lds_double *)slab;
@@ -203,14 +268,15 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
   // Addressing: a wave-uniform 64-bit base per group (SGPRs) plus a 32-bit per-lane index inside the
   // group's block.  Lanes of a dead element (only in the last, partial group) read the group's last
   // live element instead.
-  auto nlive_of = [&](int g) { const int n = a.nelem - g * E; return n < E ? n : E; };  // uniform, >= 1
-  constexpr int NSET = RQ >= 2 ? CPS_PENCIL_NSET : 1;
+  auto nlive_of = [&](int nelem, int g) { const int n = nelem - g * E; return n < E ? n : E; };  // uniform, >= 1
+  constexpr int NSET = RQ >= 2 ? (Q >= 6 ? CPS_PENCIL_NSET_BIGQ : CPS_PENCIL_NSET) : 1;
   double qd[NSET][10], st[NSET][9];
   auto load_point = [&](double *qdv, double *stv, int g, int r) {
+    const kargs_t ka = kargs_fresh<KA>();  // one scalar load for the fields used here
     const int t = lane + 64 * r, el0 = el_of(t, Q3);
-    const int q = min(t - el0 * Q3, Q3 - 1), el = min(el0, nlive_of(g) - 1);
-    const size_t e0 = (size_t)(a.elem_begin + g * E);
-    const double *qb = a.qdata + e0 * (10 * Q3);
+    const int q = min(t - el0 * Q3, Q3 - 1), el = min(el0, nlive_of(ka->nelem, g) - 1);
+    const size_t e0 = (size_t)(ka->elem_begin + g * E);
+    const double *qb = ka->qdata + e0 * (10 * Q3);
     const uint32_t vo = (uint32_t)(el * (10 * Q3) + q);
 #ifdef CPS_ABLATE_QDATA  // timing-only build: no q-point stream (WRONG results)
     for (int c = 0; c < 10; c++) qdv[c] = (c == 1 || c == 5 || c == 9 || c == 0) ? 1.0 + 1e-3 * q : 1e-3 * c;
@@ -220,27 +286,30 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
 #pragma unroll
     for (int c = 0; c < 10; c++) qdv[c] = (qb + c * Q3)[vo];
     if constexpr (ST_IN) {
-      const double *sb = a.state_in + e0 * (9 * Q3);
+      const double *sb = ka->state_in + e0 * (9 * Q3);
       const uint32_t vs = (uint32_t)(el * (9 * Q3) + q);
 #pragma unroll
       for (int c = 0; c < 9; c++) stv[c] = (sb + c * Q3)[vs];
     }
   };
   auto load_offsets = [&](int g, uint32_t *o) {
-    const uint32_t *ob = a.offsets + (size_t)(a.elem_begin + g * E) * P3;
+    const kargs_t ka = kargs_fresh<KA>();
+    const uint32_t *ob = ka->offsets + (size_t)(ka->elem_begin + g * E) * P3;
+    const int nlive = nlive_of(ka->nelem, g);
 #pragma unroll
     for (int r = 0; r < RN; r++) {
       const int t = lane + 64 * r, el0 = el_of(t, P3);
-      const int n = min(t - el0 * P3, P3 - 1), el = min(el0, nlive_of(g) - 1);
+      const int n = min(t - el0 * P3, P3 - 1), el = min(el0, nlive - 1);
       o[r] = ob[(uint32_t)(el * P3 + n)];
     }
   };
   auto load_x = [&](const uint32_t *o, double (*xv)[3]) {
+    const double *xb = kargs_fresh<KA>()->x;
 #pragma unroll
     for (int r = 0; r < RN; r++) {
       const uint32_t base = o[r] & OFF_MASK;
 #pragma unroll
-      for (int c = 0; c < 3; c++) xv[r][c] = a.x[base + c];
+      for (int c = 0; c < 3; c++) xv[r][c] = xb[base + c];
     }
   };
 
@@ -258,11 +327,13 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
     load_offsets(g_nx, off_nx);
 
     // ---- gather: x -> A at the nodes (Dirichlet flags applied; dead elements of the last group zero) ----
+    const kargs_t kg = kargs_fresh<KA>();
+    const int g_nelem = kg->nelem, g_mask_in = kg->mask_in;
 #pragma unroll
     for (int r = 0; r < RN; r++) {
       if (pencil_ok(lane, r, E * P3)) {
-        const bool live = grp * E + el_of(lane + 64 * r, P3) < a.nelem;
-        const uint32_t fl = live ? (a.mask_in ? (off[r] >> OFF_FLAG_SHIFT) : 0u) : 7u;
+        const bool live = grp * E + el_of(lane + 64 * r, P3) < g_nelem;
+        const uint32_t fl = live ? (g_mask_in ? (off[r] >> OFF_FLAG_SHIFT) : 0u) : 7u;
         lds_wr<oA + 0 * BC>(aNd[r], (fl & 1u) ? 0. : xin[r][0]);
         lds_wr<oA + 1 * BC>(aNd[r], (fl & 2u) ? 0. : xin[r][1]);
         lds_wr<oA + 2 * BC>(aNd[r], (fl & 4u) ? 0. : xin[r][2]);
@@ -274,26 +345,44 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
     pencil_pass<P, Q, P, false, BJ, oA, oA>(ktB, aJP, lane, E * T_JP);   // F2: along j at (i', nodal k)
     {  // F3: along k at (i', j'): U -> A in place and dU/dz -> BZ (grad1d on the nodal values), one
        // table at a time (both = 100 SGPRs = SGPR spills)
-      const ktab_t tB = ktab_fresh(ktB);
       double in[R_K][P];
 #pragma unroll
       for (int r = 0; r < R_K; r++)
         if (pencil_ok(lane, r, E * T_K)) pencil_ld<P, BK, oA>(aK[r], in[r]);
+      if constexpr (table_splits<Q, P>() == 1) {
+        const ktab_t tB = ktab_fresh(ktB);
 #pragma unroll
-      for (int r = 0; r < R_K; r++)
-        if (pencil_ok(lane, r, E * T_K)) {
-          double out[Q] = {};
-          pencil_mac<Q, P, P, false>(tB, in[r], out);
-          pencil_st<Q, BK, oA>(aK[r], out);
-        }
-      const ktab_t tG = ktab_fresh(ktG);
+        for (int r = 0; r < R_K; r++)
+          if (pencil_ok(lane, r, E * T_K)) {
+            double out[Q] = {};
+            pencil_mac<Q, P, P, false>(tB, in[r], out);
+            pencil_st<Q, BK, oA>(aK[r], out);
+          }
+        const ktab_t tG = ktab_fresh(ktG);
 #pragma unroll
-      for (int r = 0; r < R_K; r++)
-        if (pencil_ok(lane, r, E * T_K)) {
-          double dz[Q] = {};
-          pencil_mac<Q, P, P, false>(tG, in[r], dz);
-          pencil_st<Q, BK, oBZ>(aK[r], dz);
+        for (int r = 0; r < R_K; r++)
+          if (pencil_ok(lane, r, E * T_K)) {
+            double dz[Q] = {};
+            pencil_mac<Q, P, P, false>(tG, in[r], dz);
+            pencil_st<Q, BK, oBZ>(aK[r], dz);
+          }
+      } else {  // large tables: row blocks (mac_rounds), one product after the other
+        double out[R_K][Q];
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+          for (int r = 0; r < R_K; r++)
+#pragma unroll
+            for (int o = 0; o < Q; o++) out[r][o] = 0.;
+          mac_rounds<Q, P, P, false, R_K>(pass == 0 ? ktB : ktG, in, out, lane, E * T_K);
+#pragma unroll
+          for (int r = 0; r < R_K; r++)
+            if (pencil_ok(lane, r, E * T_K)) {
+              if (pass == 0) pencil_st<Q, BK, oA>(aK[r], out[r]);
+              else pencil_st<Q, BK, oBZ>(aK[r], out[r]);
+            }
         }
+      }
     }
     // ---- collocated gradient on the quadrature points -----------------------------------------------------
     pencil_pass<Q, Q, Q, false, BI, oA, oBX>(ktD, aIQ, lane, E * T_IQ);  // F4: d/dx: A -> BX
@@ -302,9 +391,10 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
     // ---- physics: point owners, one round at a time; ug[d*3+c] from (BX, A, BZ), dv back in place ----
 #pragma unroll
     for (int r = 0; r < RQ; r++) {
+      const kargs_t ka = kargs_fresh<KA>();
       const bool okp = pencil_ok(lane, r, E * Q3);
       const int pel = el_of(lane + 64 * r, Q3), pq = lane + 64 * r - pel * Q3;
-      const bool live = okp && (grp * E + pel < a.nelem);
+      const bool live = okp && (grp * E + pel < ka->nelem);
       double ug[9], dv[9], sto[9];
       if (okp) {
         ug[0] = lds_rd<oBX + 0 * BC>(aPt[r]); ug[1] = lds_rd<oBX + 1 * BC>(aPt[r]); ug[2] = lds_rd<oBX + 2 * BC>(aPt[r]);
@@ -312,9 +402,9 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
         ug[6] = lds_rd<oBZ + 0 * BC>(aPt[r]); ug[7] = lds_rd<oBZ + 1 * BC>(aPt[r]); ug[8] = lds_rd<oBZ + 2 * BC>(aPt[r]);
       }
       if (live) {
-        qf_point<QF>(Phys{a.nu, a.E, a.lambda, a.TwoMu}, ug, qd[r % NSET], st[r % NSET], dv, sto);
+        qf_point<QF>(Phys{ka->nu, ka->E, ka->lambda, ka->TwoMu}, ug, qd[r % NSET], st[r % NSET], dv, sto);
         if constexpr (ST_OUT) {
-          double *sb = a.state_out + (size_t)(a.elem_begin + grp * E) * (9 * Q3);
+          double *sb = ka->state_out + (size_t)(ka->elem_begin + grp * E) * (9 * Q3);
           const uint32_t vs = (uint32_t)(pel * (9 * Q3) + pq);
 #pragma unroll
           for (int c = 0; c < 9; c++) (sb + c * Q3)[vs] = sto[c];
@@ -337,23 +427,54 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
     pencil_pass<Q, Q, Q, true, BI, oBX, oBX>(ktD, aIQ, lane, E * T_IQ);  // B1: W1 = Dx^T g0, BX in place
     {  // B2: W2 = W1 + Dy^T g1, A in place.  Two inputs per task: software-pipelined over the rounds
        // (two rounds of inputs live instead of all)
-      const ktab_t tD = ktab_fresh(ktD);
-      double in[2][Q], acc[2][Q];
-      if (pencil_ok(lane, 0, E * T_JQ)) { pencil_ld<Q, BJ, oA>(aJQ[0], in[0]); pencil_ld<Q, BJ, oBX>(aJQ[0], acc[0]); }
+      if constexpr (table_splits<Q, Q>() == 1) {
+        const ktab_t tD = ktab_fresh(ktD);
+        double in[2][Q], acc[2][Q];
+        if (pencil_ok(lane, 0, E * T_JQ)) { pencil_ld<Q, BJ, oA>(aJQ[0], in[0]); pencil_ld<Q, BJ, oBX>(aJQ[0], acc[0]); }
 #pragma unroll
-      for (int r = 0; r < R_JQ; r++) {
-        if (r + 1 < R_JQ && pencil_ok(lane, r + 1, E * T_JQ)) {
-          pencil_ld<Q, BJ, oA>(aJQ[r + 1], in[(r + 1) & 1]);
-          pencil_ld<Q, BJ, oBX>(aJQ[r + 1], acc[(r + 1) & 1]);
+        for (int r = 0; r < R_JQ; r++) {
+          if (r + 1 < R_JQ && pencil_ok(lane, r + 1, E * T_JQ)) {
+            pencil_ld<Q, BJ, oA>(aJQ[r + 1], in[(r + 1) & 1]);
+            pencil_ld<Q, BJ, oBX>(aJQ[r + 1], acc[(r + 1) & 1]);
+          }
+          if (pencil_ok(lane, r, E * T_JQ)) {
+            pencil_mac<Q, Q, Q, true>(tD, in[r & 1], acc[r & 1]);
+            pencil_st<Q, BJ, oA>(aJQ[r], acc[r & 1]);
+          }
         }
-        if (pencil_ok(lane, r, E * T_JQ)) {
-          pencil_mac<Q, Q, Q, true>(tD, in[r & 1], acc[r & 1]);
-          pencil_st<Q, BJ, oA>(aJQ[r], acc[r & 1]);
+      } else {  // large tables: all rounds live, the table in row blocks
+        double in[R_JQ][Q], acc[R_JQ][Q];
+#pragma unroll
+        for (int r = 0; r < R_JQ; r++) {
+#pragma unroll
+          for (int o = 0; o < Q; o++) acc[r][o] = 0.;
+          if (pencil_ok(lane, r, E * T_JQ)) { pencil_ld<Q, BJ, oA>(aJQ[r], in[r]); pencil_ld<Q, BJ, oBX>(aJQ[r], acc[r]); }
         }
+        mac_rounds<Q, Q, Q, true, R_JQ>(ktD, in, acc, lane, E * T_JQ);
+#pragma unroll
+        for (int r = 0; r < R_JQ; r++)
+          if (pencil_ok(lane, r, E * T_JQ)) pencil_st<Q, BJ, oA>(aJQ[r], acc[r]);
       }
     }
     {  // B3: along k: A[k<P] = B^T W2 + G^T g2, in two sweeps so that one coefficient table is live at a time
       double out[R_K][P];
+      if constexpr (table_splits<P, Q>() > 1) {  // large tables: all rounds live, the tables in row blocks
+        double in[R_K][Q];
+#pragma unroll
+        for (int r = 0; r < R_K; r++) {
+#pragma unroll
+          for (int m = 0; m < P; m++) out[r][m] = 0.;
+          if (pencil_ok(lane, r, E * T_K)) pencil_ld<Q, BK, oA>(aK[r], in[r]);
+        }
+        mac_rounds<P, Q, P, true, R_K>(ktB, in, out, lane, E * T_K);
+#pragma unroll
+        for (int r = 0; r < R_K; r++)
+          if (pencil_ok(lane, r, E * T_K)) pencil_ld<Q, BK, oBZ>(aK[r], in[r]);
+        mac_rounds<P, Q, P, true, R_K, true>(ktG, in, out, lane, E * T_K);
+#pragma unroll
+        for (int r = 0; r < R_K; r++)
+          if (pencil_ok(lane, r, E * T_K)) pencil_st<P, BK, oA>(aK[r], out[r]);
+      } else {
       {
         const ktab_t tB = ktab_fresh(ktB);
         double in[2][Q];
@@ -367,7 +488,8 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
         }
       }
       {
-        const ktab_t tG = ktab_fresh(ktG);
+        // not before the first sweep has used its table: both at once do not fit the SGPR file (they were spilled)
+        const ktab_t tG = ktab_fresh_after<R_K * P>(ktG, &out[0][0]);
         double in2[2][Q];
         if (pencil_ok(lane, 0, E * T_K)) pencil_ld<Q, BK, oBZ>(aK[0], in2[0]);
 #pragma unroll
@@ -378,6 +500,7 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
             pencil_st<P, BK, oA>(aK[r], out[r]);
           }
         }
+      }
       }
     }
     load_x(off_nx, xin);  // next group's x (its offsets landed long ago): issued this late so its 6 RN registers
@@ -394,20 +517,21 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
         if (pencil_ok(lane, r, E * P3)) {
           v[r][0] = lds_rd<oA + 0 * BC>(aNd[r]); v[r][1] = lds_rd<oA + 1 * BC>(aNd[r]); v[r][2] = lds_rd<oA + 2 * BC>(aNd[r]);
         }
+      const kargs_t ka = kargs_fresh<KA>();
 #pragma unroll
       for (int r = 0; r < RN; r++) {
         const int nel = el_of(lane + 64 * r, P3), nn = lane + 64 * r - nel * P3;
-        if (pencil_ok(lane, r, E * P3) && grp * E + nel < a.nelem) {
-          if (a.evec) {
-            double *eb = a.evec + (size_t)(a.elem_begin + grp * E) * (3 * P3);
+        if (pencil_ok(lane, r, E * P3) && grp * E + nel < ka->nelem) {
+          if (ka->evec) {
+            double *eb = ka->evec + (size_t)(ka->elem_begin + grp * E) * (3 * P3);
             const uint32_t ve = (uint32_t)((nel * P3 + nn) * 3);
             eb[ve] = v[r][0]; (eb + 1)[ve] = v[r][1]; (eb + 2)[ve] = v[r][2];
           } else {
             const uint32_t base = off[r] & OFF_MASK;
-            const uint32_t fl = a.mask_out ? (off[r] >> OFF_FLAG_SHIFT) : 0u;
+            const uint32_t fl = ka->mask_out ? (off[r] >> OFF_FLAG_SHIFT) : 0u;
 #pragma unroll
             for (int c = 0; c < 3; c++)
-              if (!((fl >> c) & 1u)) atomic_add_f64(a.y + base + c, v[r][c]);
+              if (!((fl >> c) & 1u)) atomic_add_f64(ka->y + base + c, v[r][c]);
           }
         }
       }
