@@ -33,7 +33,10 @@ namespace cps {
 
 template <int P, int Q> struct PencilGeom {
   static constexpr int Q3 = Q * Q * Q, P3 = P * P * P;
-  static constexpr int E = Q <= 2 ? 8 : (Q <= 4 ? 4 : (Q == 5 ? 2 : 1));  // elements per wave
+#ifndef CPS_PENCIL_E5
+#define CPS_PENCIL_E5 2
+#endif
+  static constexpr int E = Q <= 2 ? 8 : (Q <= 4 ? 4 : (Q == 5 ? CPS_PENCIL_E5 : 1));  // elements per wave
   static constexpr int SJ = Q, SK = Q * Q, SC = Q3;                         // strides in doubles
   static constexpr int ARR = 3 * SC;                                        // one 3-component array
   static constexpr int PAD = Q == 5 ? 5 : 1;                                // tools/pencil_layout_search.py
@@ -186,11 +189,15 @@ CPS_DEV void pencil_pass(ktab_t table, const ldsp_t (&addr)[R], int lane, int nt
 #ifndef CPS_PENCIL_NSET
 #define CPS_PENCIL_NSET 2   // q-point register sets: 2 = every round's data is requested two rounds ahead
 #endif                      // (231 VGPRs with the hyperFS tangent; 1 set: 190 VGPRs, 4-6 % slower)
+#ifndef CPS_PENCIL_MINW5
+#define CPS_PENCIL_MINW5 CPS_PENCIL_MINW   // tuning hook: Q = 5 only
+#endif
+constexpr int pencil_minw(int Q) { return Q == 5 ? CPS_PENCIL_MINW5 : CPS_PENCIL_MINW; }
 #ifndef CPS_PENCIL_NSET_BIGQ
 #define CPS_PENCIL_NSET_BIGQ 1   // Q >= 6: the split-table passes keep all rounds' pencils in VGPRs; a second q-point set
 #endif                           // would push the hyperFS tangent past 256 VGPRs (26 spilled to scratch)
 template <int P, int Q, int QF>
-__global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const BasisTables tab_, const FusedGradArgs a) {
+__global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const BasisTables tab_, const FusedGradArgs a) {
   static_assert(offsetof(BasisTables, interp) == 0 && offsetof(BasisTables, colo) == 8 * MAXN1D * MAXN1D &&
                 offsetof(BasisTables, grad) == 16 * MAXN1D * MAXN1D, "kernarg layout of the tables");
   (void)tab_;  // first kernel argument: lives at offset 0 of the kernarg segment, read through kt below
@@ -545,7 +552,7 @@ __global__ __launch_bounds__(64, CPS_PENCIL_MINW) void k_fused_pencil(const Basi
 
 template <int P, int Q> constexpr int pencil_waves_per_cu() {
   constexpr int by_lds = (160 * 1024) / PencilGeom<P, Q>::LDS_BYTES;
-  return by_lds < 1 ? 1 : (by_lds > 8 ? 8 : by_lds);  // 8 waves per CU = 2 per SIMD at <= 256 VGPRs
+  return by_lds < 1 ? 1 : (by_lds > 4 * pencil_minw(Q) ? 4 * pencil_minw(Q) : by_lds);  // 8 waves per CU = 2 per SIMD at <= 256 VGPRs
 }
 
 template <int P, int Q, int QF>
