@@ -188,7 +188,7 @@ CPS_DEV void pencil_pass(ktab_t table, const ldsp_t (&addr)[R], int lane, int nt
 #endif
 #ifndef CPS_PENCIL_NSET
 #define CPS_PENCIL_NSET 2   // q-point register sets: 2 = every round's data is requested two rounds ahead
-#endif                      // (231 VGPRs with the hyperFS tangent; 1 set: 190 VGPRs, 4-6 % slower)
+#endif                      // (198 VGPRs with the hyperFS tangent; 1 set: 4-6 % slower; 3 sets: no gain)
 #ifndef CPS_PENCIL_MINW5
 #define CPS_PENCIL_MINW5 CPS_PENCIL_MINW   // tuning hook: Q = 5 only
 #endif
@@ -347,6 +347,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       }
     }
 
+#ifndef CPS_ABLATE_PASSES  // (CPS_ABLATE_*: timing-only diagnostic builds for tools/ablate_run.sh, WRONG results, never shipped)
     // ---- B: nodes -> points, in place -----------------------------------------------------------------
     pencil_pass<P, Q, P, false, BI, oA, oA>(ktB, aIP, lane, E * T_IP);   // F1: along i at nodal (j, k)
     pencil_pass<P, Q, P, false, BJ, oA, oA>(ktB, aJP, lane, E * T_JP);   // F2: along j at (i', nodal k)
@@ -394,6 +395,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     // ---- collocated gradient on the quadrature points -----------------------------------------------------
     pencil_pass<Q, Q, Q, false, BI, oA, oBX>(ktD, aIQ, lane, E * T_IQ);  // F4: d/dx: A -> BX
     pencil_pass<Q, Q, Q, false, BJ, oA, oA>(ktD, aJQ, lane, E * T_JQ);   // F5: d/dy: A -> A in place
+#endif
 
     // ---- physics: point owners, one round at a time; ug[d*3+c] from (BX, A, BZ), dv back in place ----
 #pragma unroll
@@ -409,7 +411,11 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
         ug[6] = lds_rd<oBZ + 0 * BC>(aPt[r]); ug[7] = lds_rd<oBZ + 1 * BC>(aPt[r]); ug[8] = lds_rd<oBZ + 2 * BC>(aPt[r]);
       }
       if (live) {
+#ifdef CPS_ABLATE_QF
+        for (int c = 0; c < 9; c++) { dv[c] = ug[c] * qd[r % NSET][c] + (ST_IN ? st[r % NSET][c] : qd[r % NSET][9]); sto[c] = dv[c]; }
+#else
         qf_point<QF>(Phys{ka->nu, ka->E, ka->lambda, ka->TwoMu}, ug, qd[r % NSET], st[r % NSET], dv, sto);
+#endif
         if constexpr (ST_OUT) {
           double *sb = ka->state_out + (size_t)(ka->elem_begin + grp * E) * (9 * Q3);
           const uint32_t vs = (uint32_t)(pel * (9 * Q3) + pq);
@@ -430,6 +436,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       }
     }
 
+#ifndef CPS_ABLATE_PASSES
     // ---- gradient^T --------------------------------------------------------------------------------------
     pencil_pass<Q, Q, Q, true, BI, oBX, oBX>(ktD, aIQ, lane, E * T_IQ);  // B1: W1 = Dx^T g0, BX in place
     {  // B2: W2 = W1 + Dy^T g1, A in place.  Two inputs per task: software-pipelined over the rounds
@@ -510,12 +517,15 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       }
       }
     }
+#endif
     load_x(off_nx, xin);  // next group's x (its offsets landed long ago): issued this late so its 6 RN registers
                           // are not live across the physics and the register-hungry passes; B4, B5, the
                           // final store and the next gather's address work hide most of its latency
     // ---- B^T: points -> nodes ---------------------------------------------------------------------------
+#ifndef CPS_ABLATE_PASSES
     pencil_pass<Q, P, P, true, BJ, oA, oA>(ktB, aJP, lane, E * T_JP);    // B4: along j
     pencil_pass<Q, P, P, true, BI, oA, oA>(ktB, aIP, lane, E * T_IP);    // B5: along i
+#endif
     // ---- final: node owners -> E-vector (plain coalesced stores) or f64 atomics ---------------------------
     {
       double v[RN][3];
@@ -532,7 +542,11 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
           if (ka->evec) {
             double *eb = ka->evec + (size_t)(ka->elem_begin + grp * E) * (3 * P3);
             const uint32_t ve = (uint32_t)((nel * P3 + nn) * 3);
+#ifndef CPS_ABLATE_STORE
             eb[ve] = v[r][0]; (eb + 1)[ve] = v[r][1]; (eb + 2)[ve] = v[r][2];
+#else
+            if (v[r][0] == 1.2345e-300) eb[ve] = v[r][1] + v[r][2];
+#endif
           } else {
             const uint32_t base = off[r] & OFF_MASK;
             const uint32_t fl = ka->mask_out ? (off[r] >> OFF_FLAG_SHIFT) : 0u;
