@@ -258,7 +258,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(op.kernel_name, mesh.nelem),
                          "algorithmic_bytes_per_launch": abytes, "kernel_avg_us": avg_s * 1e6,
                          "kernel_launches_timed": launches,
-                         "kernels": "k_fused_pencil (gather..physics..E-vector) + k_assemble (deterministic per-node sum): the two launches of one CeedOperatorApply, timed together with hipEvents on their stream",
+                         "kernels": "k_fused_pencil (gather..physics..shell E-vector, interior nodes straight to y) + k_assemble (deterministic per-node sum of the shared nodes): the two launches of one CeedOperatorApply, timed together with hipEvents on their stream",
                          "peak_measured_copy_GBs": 6290.0},
         }
         if not args.no_cpu_baseline and world == 1 and args.workload == "cylinder":

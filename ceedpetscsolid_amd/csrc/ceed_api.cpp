@@ -67,6 +67,7 @@ struct Ceed_private {
   size_t evec_len = 0;
   bool atomic_scatter = false;  // CEED_MI355X_SCATTER=atomic: f64 atomics instead of E-vector + assembly
   int fused_variant = 1;        // CEED_MI355X_FUSED=rows: the first-generation row kernel (A/B); default pencil
+  bool direct_interior = true;  // pencil kernel: element-interior nodes go straight to y (CEED_MI355X_DIRECT=0: all via the E-vector)
   double *d_scalar = nullptr;   // device scalar for reductions
   double *h_scalar = nullptr;   // pinned host landing slot for it (pageable targets make the runtime stage + pin per copy)
   // hipGraph capture (CeedXGraphBeginCapture): device work is recorded on `capture_stream`
@@ -94,7 +95,7 @@ struct CeedVector_private {
 // "priority" nodes when the map was built with a priority mask (split-phase apply).
 struct CsrMap {
   bool built = false, full_cover = false;
-  int nnodes = 0, nprio = 0;
+  int nnodes = 0, nprio = 0, nskipped = 0;
   std::vector<uint32_t> h_node_off;
   uint32_t *d_rowptr = nullptr, *d_cols = nullptr, *d_node_off = nullptr;
   void release() {
@@ -116,6 +117,8 @@ struct CeedElemRestriction_private {
   // transpose map for the atomic-free scatter: distinct node offsets (ascending), their contributors
   // (E-vector positions e*elemsize + n, in element order) -- built on first use
   CsrMap csr;   // default map (nodes in ascending offset order)
+  CsrMap csr_shell;        // the same without the element-interior nodes (FusedGradArgs::direct)
+  int interior_private = 0;  // 0: not checked yet; 1: every element-interior node has one contributor; -1: not so
 };
 
 struct CeedBasis_private {
@@ -160,6 +163,7 @@ struct CeedOperator_private {
   uint32_t *d_off_flagged_in = nullptr, *d_off_flagged_out = nullptr;  // same array unless transfer
   unsigned char *d_node_flags = nullptr;      // per node of the restriction's transpose map
   unsigned char *d_node_flags_ovl = nullptr;  // per node of the operator's own (priority-first) map
+  unsigned char *d_node_flags_shell = nullptr;  // per node of the restriction's shell map (direct-store mode)
   std::vector<unsigned char> h_mask;      // copy of the output mask (node flags are derived lazily)
   int mask_mode = 0;
   // optional fine-side scale for transfers
@@ -213,6 +217,8 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   c->atomic_scatter = sc && !strcmp(sc, "atomic");
   const char *fv = getenv("CEED_MI355X_FUSED");
   c->fused_variant = (fv && !strcmp(fv, "rows")) ? 0 : 1;
+  const char *di = getenv("CEED_MI355X_DIRECT");
+  c->direct_interior = c->fused_variant == 1 && !c->atomic_scatter && !(di && !strcmp(di, "0"));
   *ceed = c;
   return 0;
 }
@@ -490,6 +496,7 @@ extern "C" int CeedElemRestrictionDestroy(CeedElemRestriction *rstr) {
   if (--r->refcount > 0) return 0;
   if (r->d_offsets) (void)hipFree(r->d_offsets);
   r->csr.release();
+  r->csr_shell.release();
   ceed_unref(r->ceed);
   delete r;
   return 0;
@@ -708,7 +715,8 @@ static void op_free_flags(CeedOperator o) {
   o->d_off_flagged_in = o->d_off_flagged_out = nullptr;
   if (o->d_node_flags) (void)hipFree(o->d_node_flags);
   if (o->d_node_flags_ovl) (void)hipFree(o->d_node_flags_ovl);
-  o->d_node_flags = o->d_node_flags_ovl = nullptr;
+  if (o->d_node_flags_shell) (void)hipFree(o->d_node_flags_shell);
+  o->d_node_flags = o->d_node_flags_ovl = o->d_node_flags_shell = nullptr;
   o->h_mask.clear();
   o->mask_mode = 0;
 }
@@ -739,11 +747,17 @@ extern "C" int CeedOperatorDestroy(CeedOperator *op) {
 // Build a transpose map (setup time, host): counting sort over the L-vector.  With `prio`
 // (one byte per L-vector entry, tested at each node's component-0 offset) the flagged nodes
 // come first.
-static int build_csr(CeedElemRestriction r, CsrMap &M, const unsigned char *prio) {
+// `skipP` > 0 (elemsize == skipP^3): nodes interior to an element are left out of the map -- the fused kernel
+// stores them itself (FusedGradArgs::direct); the caller has checked rstr_interior_private().
+static int build_csr(CeedElemRestriction r, CsrMap &M, const unsigned char *prio, int skipP = 0) {
   if (M.built) return 0;
   const size_t n = r->h_offsets.size();
   std::vector<uint32_t> cnt((size_t)r->lsize + 1, 0u);
   for (size_t i = 0; i < n; i++) cnt[(size_t)r->h_offsets[i]]++;
+  M.nskipped = 0;
+  if (skipP > 0)
+    for (size_t i = 0; i < n; i++)
+      if (node_is_element_interior((int)(i % (size_t)r->elemsize), skipP)) { cnt[(size_t)r->h_offsets[i]] = 0; M.nskipped++; }
   std::vector<uint32_t> slot((size_t)r->lsize, 0xFFFFFFFFu), rowptr;
   M.h_node_off.clear();
   rowptr.push_back(0u);
@@ -759,10 +773,16 @@ static int build_csr(CeedElemRestriction r, CsrMap &M, const unsigned char *prio
     }
   const int nn = (int)M.h_node_off.size();
   std::vector<uint32_t> cursor(rowptr.begin(), rowptr.end() - 1), cols(n ? n : 1);
-  for (size_t i = 0; i < n; i++)  // element order => each node's contributors are sorted by element
-    cols[cursor[slot[(size_t)r->h_offsets[i]]]++] = (uint32_t)i;  // E position e * elemsize + n
+  for (size_t i = 0; i < n; i++) {  // element order => each node's contributors are sorted by element
+    const uint32_t sl = slot[(size_t)r->h_offsets[i]];
+    if (sl == 0xFFFFFFFFu) continue;
+    // E position: e * elemsize + n, or in the shell-only E-vector of the direct-store mode e * shell size + shell rank
+    const size_t e = i / (size_t)r->elemsize; const int ln = (int)(i % (size_t)r->elemsize);
+    cols[cursor[sl]++] = skipP > 0 ? (uint32_t)(e * (size_t)element_shell_size(skipP) + (size_t)node_shell_rank(ln, skipP)) : (uint32_t)i;
+  }
   M.nnodes = nn;
-  M.full_cover = (size_t)nn * (size_t)r->ncomp == (size_t)r->lsize;  // every L-vector entry is written by the assembly
+  // every L-vector entry is written by the assembly (or, for the skipped nodes, by the fused kernel)
+  M.full_cover = ((size_t)nn + (size_t)M.nskipped) * (size_t)r->ncomp == (size_t)r->lsize;
   HIPCHK(hipMalloc((void **)&M.d_rowptr, sizeof(uint32_t) * (nn + 1)));
   HIPCHK(hipMalloc((void **)&M.d_cols, sizeof(uint32_t) * cols.size()));
   HIPCHK(hipMalloc((void **)&M.d_node_off, sizeof(uint32_t) * (nn ? nn : 1)));
@@ -771,6 +791,22 @@ static int build_csr(CeedElemRestriction r, CsrMap &M, const unsigned char *prio
   HIPCHK(hipMemcpy(M.d_node_off, M.h_node_off.data(), sizeof(uint32_t) * nn, hipMemcpyHostToDevice));
   M.built = true;
   return 0;
+}
+// Are the element-interior nodes (local index 0 < i,j,k < P-1) of an offsets restriction private to their
+// element?  True for every conforming mesh; checked because offsets are caller data.
+static bool rstr_interior_private(CeedElemRestriction r, int P) {
+  if (r->interior_private) return r->interior_private > 0;
+  r->interior_private = -1;
+  if (P < 3 || (size_t)P * P * P != (size_t)r->elemsize || r->ncomp != 3 || r->compstride != 1) return false;
+  std::vector<unsigned char> cnt((size_t)r->lsize, 0);
+  for (size_t i = 0; i < r->h_offsets.size(); i++) {
+    unsigned char &c = cnt[(size_t)r->h_offsets[i]];
+    if (c < 2) c++;
+  }
+  for (size_t i = 0; i < r->h_offsets.size(); i++)
+    if (node_is_element_interior((int)(i % (size_t)r->elemsize), P) && cnt[(size_t)r->h_offsets[i]] != 1) return false;
+  r->interior_private = 1;
+  return true;
 }
 static int ceed_need_evec(Ceed c, size_t len) {
   if (c->evec_len >= len) return 0;
@@ -995,9 +1031,16 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
   const CsrMap *M = nullptr;
   int row0 = 0, nrows = 0;
   a.elem_begin = 0; a.nelem = r->nelem;
+  // element-interior nodes straight to y: overwrite mode only (split maps are built to match, see SetOverlapSplit)
+  const bool direct = use_evec && !add && op->ceed->direct_interior && rstr_interior_private(r, ai.basis->P1d);
+  a.direct = direct ? 1 : 0;
   if (use_evec) {  // atomic-free, deterministic scatter: element results -> E-vector -> per-node sums
-    if (split) M = &op->ovl_csr; else { CHK(build_csr(r, r->csr, nullptr)); M = &r->csr; }
-    unsigned char **flagsp = split ? &op->d_node_flags_ovl : &op->d_node_flags;
+    if (split) {
+      M = &op->ovl_csr;
+      if ((M->nskipped > 0) != direct) return ceed_error("split-phase map and direct-store mode disagree");
+    } else if (direct) { CHK(build_csr(r, r->csr_shell, nullptr, ai.basis->P1d)); M = &r->csr_shell; }
+    else { CHK(build_csr(r, r->csr, nullptr)); M = &r->csr; }
+    unsigned char **flagsp = split ? &op->d_node_flags_ovl : (direct ? &op->d_node_flags_shell : &op->d_node_flags);
     if (!*flagsp && !op->h_mask.empty()) {
       std::vector<unsigned char> fl((size_t)M->nnodes, 0);
       for (int i = 0; i < M->nnodes; i++)
@@ -1024,7 +1067,7 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
       return ceed_error("no fused kernel instantiated for P=%d Q=%d QFunction %s", ai.basis->P1d, ai.basis->Q1d, qf->name.c_str());
     HIPCHK(e);
     if (use_evec) {  // timed together with the fused kernel: the two launches ARE the operator apply
-      const unsigned char *fl = (op->mask_mode & 2) ? (split ? op->d_node_flags_ovl : op->d_node_flags) : nullptr;
+      const unsigned char *fl = (op->mask_mode & 2) ? (split ? op->d_node_flags_ovl : (direct ? op->d_node_flags_shell : op->d_node_flags)) : nullptr;
       HIPCHK(launch_assemble(M->d_rowptr + row0, M->d_cols, M->d_node_off + row0, fl ? fl + row0 : nullptr, a.evec, py,
                              nrows, r->elemsize, add ? 1 : 0, s));
     }
@@ -1286,7 +1329,8 @@ extern "C" int CeedXOperatorSetOverlapSplit(CeedOperator op, CeedInt n_leading_e
   for (size_t i = 0; i < r->h_offsets.size(); i++)
     if (priority[(size_t)r->h_offsets[i]] && i / es >= (size_t)n_leading_elems)
       return ceed_error("element %zu touches a priority node but is not among the %d leading elements", i / es, n_leading_elems);
-  CHK(build_csr(r, op->ovl_csr, priority));
+  const int P1 = op->in[op->i_active].basis->P1d;
+  CHK(build_csr(r, op->ovl_csr, priority, (op->ceed->direct_interior && rstr_interior_private(r, P1)) ? P1 : 0));
   op->ovl_lead = n_leading_elems;
   return 0;
 }

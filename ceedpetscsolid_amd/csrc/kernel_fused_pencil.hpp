@@ -257,11 +257,17 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     const int t = lane + 64 * r, el = t / Q3, q = t % Q3;
     aPt[r] = lds0 + (el * SE + (q / (Q * Q)) * SK + ((q / Q) % Q) * SJ + q % Q);
   }
+  uint32_t nd_interior = 0;  // bit r: this lane's node of round r is interior to its element (direct store to y)
+  uint32_t ev_idx[(RN + 1) / 2] = {};  // E-vector entry (in doubles) of this lane's node within the group's block, 16 bits each
+  static_assert(E * P3 * 3 < 65536, "16-bit E-vector entry index");
 #pragma unroll
   for (int r = 0; r < RN; r++) {
     const int t = lane + 64 * r, el = t / P3, n = t % P3;
     aNd[r] = lds0 + (el * SE + (n / (P * P)) * SK + ((n / P) % P) * SJ + n % P);
+    if (a.direct && node_is_element_interior(n, P)) nd_interior |= 1u << r;
+    ev_idx[r / 2] |= (a.direct ? (uint32_t)((el * element_shell_size(P) + node_shell_rank(n, P)) * 3) : (uint32_t)(min(t, E * P3 - 1) * 3)) << (16 * (r % 2));
   }
+  const int ev_per_elem = 3 * (a.direct ? element_shell_size(P) : P3);
   // element-in-group of owner slot t, recomputed where needed (a few compares) instead of held in
   // registers through the physics
   auto el_of = [&](int t, int n3) {
@@ -539,15 +545,22 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       for (int r = 0; r < RN; r++) {
         const int nel = el_of(lane + 64 * r, P3), nn = lane + 64 * r - nel * P3;
         if (pencil_ok(lane, r, E * P3) && grp * E + nel < ka->nelem) {
-          if (ka->evec) {
-            double *eb = ka->evec + (size_t)(ka->elem_begin + grp * E) * (3 * P3);
-            const uint32_t ve = (uint32_t)((nel * P3 + nn) * 3);
+          const bool interior = (nd_interior >> r) & 1u;
+          if (ka->evec && interior) {  // sole contributor: the node's final value goes straight to y
+            const uint32_t base = off[r] & OFF_MASK;
+            const uint32_t fl = ka->mask_out ? (off[r] >> OFF_FLAG_SHIFT) : 0u;
+            double *yb = ka->y;
+            yb[base] = (fl & 1u) ? 0. : v[r][0]; (yb + 1)[base] = (fl & 2u) ? 0. : v[r][1]; (yb + 2)[base] = (fl & 4u) ? 0. : v[r][2];
+          }
+          if (ka->evec && !interior) {
+            double *eb = ka->evec + (size_t)(ka->elem_begin + grp * E) * ev_per_elem;
+            const uint32_t ve = (r % 2) ? (ev_idx[r / 2] >> 16) : (ev_idx[r / 2] & 0xFFFFu);
 #ifndef CPS_ABLATE_STORE
             eb[ve] = v[r][0]; (eb + 1)[ve] = v[r][1]; (eb + 2)[ve] = v[r][2];
 #else
             if (v[r][0] == 1.2345e-300) eb[ve] = v[r][1] + v[r][2];
 #endif
-          } else {
+          } else if (!ka->evec) {
             const uint32_t base = off[r] & OFF_MASK;
             const uint32_t fl = ka->mask_out ? (off[r] >> OFF_FLAG_SHIFT) : 0u;
 #pragma unroll

@@ -58,7 +58,39 @@ struct FusedGradArgs {
                                // and launch_assemble() sums them into y; else f64 atomics straight into y
   int variant;                // host-side dispatch only: 0 = row kernel (kernel_fused_grad.hpp),
                                // 1 = pencil kernel (kernel_fused_pencil.hpp)
+  int direct;                 // pencil kernel + evec: results at ELEMENT-INTERIOR nodes (0 < i,j,k < P-1; one contributor,
+                               // verified on the host) are stored straight into y and skip the E-vector round trip; the
+                               // E-vector then is [elem][shell node][3] and the transpose map handed to launch_assemble()
+                               // holds the shell nodes only, its columns being positions e * element_shell_size(P) + rank
 };
+// element-interior test shared by the kernel and the host-side map builder
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline bool node_is_element_interior(int n, int P) {
+  const int i = n % P, j = (n / P) % P, k = n / (P * P);
+  return i > 0 && i < P - 1 && j > 0 && j < P - 1 && k > 0 && k < P - 1;
+}
+// rank of node n among the SHELL (non-interior) nodes of its element, in local lexicographic order: the E-vector of the
+// direct-store mode holds shell entries only, [element][shell rank][component]
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline int node_shell_rank(int n, int P) {
+  const int m = P - 2, i = n % P, j = (n / P) % P, k = n / (P * P);
+#define CPS_CLAMPM(v) ((v) < 0 ? 0 : ((v) > m ? m : (v)))
+  int before = CPS_CLAMPM(k - 1) * m * m;                  // interior nodes in the planes below
+  if (k > 0 && k < P - 1) {
+    before += CPS_CLAMPM(j - 1) * m;                       // ... in the rows below of this plane
+    if (j > 0 && j < P - 1) before += CPS_CLAMPM(i - 1);   // ... to the left in this row
+  }
+#undef CPS_CLAMPM
+  return n - before;
+}
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline int element_shell_size(int P) { return P * P * P - (P > 2 ? (P - 2) * (P - 2) * (P - 2) : 0); }
 
 struct TransferArgs {
   const uint32_t *off_c;  // coarse [nelem][Pc^3]

@@ -320,9 +320,14 @@ def build_dofmap(mesh: HexMesh, p: int, ncomp: int = 3, locality_order: bool = T
     flat = ids.reshape(ne, P ** 3)
     kflat = keys.reshape(ne * P ** 3, 7)
     if locality_order:
+        # shell nodes (vertices, edges, faces: shared between elements) in first-touch order of the element sweep, so an
+        # element's new nodes are contiguous; then the element-INTERIOR nodes, [element][k][j][i]: one contiguous run per
+        # element, which the fused kernel reads and writes as whole lines (FusedGradArgs::direct)
         uniq, first = np.unique(flat.ravel(), return_index=True)
         assert uniq.size == nn, (uniq.size, nn)
-        order = np.argsort(first, kind="stable")
+        n_int = ne * max(m, 0) ** 3
+        shell = uniq < nn - n_int                     # raw ids: interiors are the last ne * m^3
+        order = np.concatenate([np.flatnonzero(shell)[np.argsort(first[shell], kind="stable")], np.flatnonzero(~shell)])
         new = np.empty(nn, dtype=np.int64)
         new[uniq[order]] = np.arange(nn)
         flat = new[flat]

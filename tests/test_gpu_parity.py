@@ -312,6 +312,39 @@ def test_apply_add_and_empty_vectors(gpu):
 
 
 @pytest.mark.gpu
+def test_direct_interior_stores_equal_the_assembled_path(gpu, product_lib):
+    """Element-interior nodes have one contributor: the pencil kernel stores them straight into y and keeps a shell-only
+    E-vector (FusedGradArgs::direct).  CEED_MI355X_DIRECT=0 sends every node through the E-vector; the two must give
+    the SAME numbers (a single-term sum is exact), with Dirichlet rows, on every level, split-phase included."""
+    old = os.environ.get("CEED_MI355X_DIRECT")
+    os.environ["CEED_MI355X_DIRECT"] = "0"
+    try:
+        plain = cd.Ceed(product_lib, "/gpu/hip/mi355x")      # read at CeedInit
+    finally:
+        if old is None:
+            os.environ.pop("CEED_MI355X_DIRECT", None)
+        else:
+            os.environ["CEED_MI355X_DIRECT"] = old
+    for mesh, degree in ((distorted_box(3, 2, 3, seed=2), 4), (distorted_box(2, 2, 1, seed=3), 6), (distorted_box(5, 1, 1), 2)):
+        outs = []
+        for c in (gpu, plain):
+            p = SolidProblem(c, mesh, degree, "hyperFS", nu=0.3, E=2.0, bc_sides=[1])
+            n = p.lsize()
+            X, R = c.vector(n), c.vector(n)
+            X.set_array(p.smooth_state(0.1)); p.form_residual(X, R)
+            res = [R.to_numpy()]
+            for lv in range(len(p.levels)):
+                nl = p.lsize(lv)
+                x = c.vector(nl).set_array(np.random.default_rng(7 + lv).uniform(-1, 1, nl))
+                y = c.vector(nl).set_value(3.0)               # overwritten, interior nodes included
+                p.apply_jacobian(lv, x, y)
+                res.append(y.to_numpy())
+            outs.append(res)
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_row_kernel_variant_matches_pencil_kernel(gpu, product_lib):
     """Both generations of the fused kernel ship (CEED_MI355X_FUSED=rows selects the first); they must agree
     to rounding on every level of a multigrid hierarchy (P < Q on the coarse levels) and both be reproducible."""
