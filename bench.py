@@ -235,7 +235,7 @@ def main():
     if rank == 0:
         P, Q = args.degree + 1, args.degree + 1
         abytes = algorithmic_bytes(mesh.nelem, P, Q, n, args.problem != "linElas")
-        avg_s = kernel_ms * 1e-3 / max(launches, 1)
+        avg_s = kernel_ms * 1e-3 / max(args.steps, 1)   # per APPLY (a split-phase apply is two timed launch pairs)
         achieved = abytes / avg_s / 1e9
         out = {
             "metric": "MDoF/s for matrix-free Jacobian apply, p=4 hyperFS hex, 1/2/4/8 GPU",
