@@ -67,6 +67,7 @@ struct Ceed_private {
   size_t evec_len = 0;
   bool atomic_scatter = false;  // CEED_MI355X_SCATTER=atomic: f64 atomics instead of E-vector + assembly
   int fused_variant = 1;        // CEED_MI355X_FUSED=rows: the first-generation row kernel (A/B); default pencil
+  bool recompute_geo = true;    // fused pencil kernel recomputes SetupGeo's factors from the element maps (CEED_MI355X_GEO=0: reads qdata)
   bool direct_interior = true;  // pencil kernel: element-interior nodes go straight to y (CEED_MI355X_DIRECT=0: all via the E-vector)
   double *d_scalar = nullptr;   // device scalar for reductions
   double *h_scalar = nullptr;   // pinned host landing slot for it (pageable targets make the runtime stage + pin per copy)
@@ -88,7 +89,14 @@ struct CeedVector_private {
   double *h = nullptr, *d = nullptr;   // current host / device storage
   bool h_owned = false, d_owned = false;
   bool h_valid = false, d_valid = false;
+  // provenance of a qdata vector: written by the SetupGeo operator from trilinear elements whose map coefficients
+  // are kept here ([nelem][GEO_NCOEF], device).  The fused kernels then recompute the geometric factors instead of
+  // reading them (FusedGradArgs::geo).  Dropped by any other write to the vector.
+  double *geo = nullptr;
+  int geo_nelem = 0, geo_Q = 0;
+  double geo_qref[MAXN1D] = {0}, geo_qwt[MAXN1D] = {0};
 };
+static void vec_drop_geo(CeedVector v) { if (v->geo) (void)hipFree(v->geo); v->geo = nullptr; v->geo_nelem = v->geo_Q = 0; }
 
 // Transpose map of an offsets restriction: distinct node offsets and, per node, the E-vector
 // positions (e*elemsize + n) of its contributors in element order.  Rows [0, nprio) are the
@@ -217,6 +225,8 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   c->atomic_scatter = sc && !strcmp(sc, "atomic");
   const char *fv = getenv("CEED_MI355X_FUSED");
   c->fused_variant = (fv && !strcmp(fv, "rows")) ? 0 : 1;
+  const char *rg = getenv("CEED_MI355X_GEO");
+  c->recompute_geo = c->fused_variant == 1 && !(rg && !strcmp(rg, "0"));
   const char *di = getenv("CEED_MI355X_DIRECT");
   c->direct_interior = c->fused_variant == 1 && !c->atomic_scatter && !(di && !strcmp(di, "0"));
   *ceed = c;
@@ -328,7 +338,7 @@ static int vec_sync_to(CeedVector v, CeedMemType m) {
 // device pointer for kernels; write=true invalidates the host mirror
 static int vec_dev(CeedVector v, bool write, double **p) {
   CHK(vec_sync_to(v, CEED_MEM_DEVICE));
-  if (write) v->h_valid = false;
+  if (write) { v->h_valid = false; vec_drop_geo(v); }
   *p = v->d;
   return 0;
 }
@@ -353,7 +363,7 @@ extern "C" int CeedVectorSetArray(CeedVector v, CeedMemType mtype, CeedCopyMode 
       vec_drop_host(v);
       v->h = array; v->h_owned = (cmode == CEED_OWN_POINTER);
     }
-    v->h_valid = true; v->d_valid = false;
+    v->h_valid = true; v->d_valid = false; vec_drop_geo(v);
   } else {
     if (cmode == CEED_COPY_VALUES) {
       if (!v->d_owned) v->d = nullptr;
@@ -363,7 +373,7 @@ extern "C" int CeedVectorSetArray(CeedVector v, CeedMemType mtype, CeedCopyMode 
       vec_drop_dev(v);
       v->d = array; v->d_owned = (cmode == CEED_OWN_POINTER);
     }
-    v->d_valid = true; v->h_valid = false;
+    v->d_valid = true; v->h_valid = false; vec_drop_geo(v);
   }
   return 0;
 }
@@ -372,10 +382,12 @@ extern "C" int CeedVectorTakeArray(CeedVector v, CeedMemType mtype, CeedScalar *
     if (v->h || v->d_valid) CHK(vec_sync_to(v, CEED_MEM_HOST));
     if (array) *array = v->h;
     v->h = nullptr; v->h_owned = false; v->h_valid = false;
+    if (!v->d_valid) vec_drop_geo(v);
   } else {
     if (v->d || v->h_valid) CHK(vec_sync_to(v, CEED_MEM_DEVICE));
     if (array) *array = v->d;
     v->d = nullptr; v->d_owned = false; v->d_valid = false;
+    vec_drop_geo(v);
   }
   return 0;
 }
@@ -383,7 +395,7 @@ extern "C" int CeedVectorSetValue(CeedVector v, CeedScalar value) {
   CHK(vec_need_dev(v));
   if (value == 0.) CHK(dev_zero(v->ceed, v->d, (size_t)v->length));
   else HIPCHK(launch_set_value(v->d, (size_t)v->length, value, v->ceed->stream));
-  v->d_valid = true; v->h_valid = false;
+  v->d_valid = true; v->h_valid = false; vec_drop_geo(v);
   return 0;
 }
 extern "C" int CeedVectorSyncArray(CeedVector v, CeedMemType mtype) { return vec_sync_to(v, mtype); }
@@ -391,6 +403,7 @@ extern "C" int CeedVectorGetArray(CeedVector v, CeedMemType mtype, CeedScalar **
   CHK(vec_sync_to(v, mtype));
   if (mtype == CEED_MEM_HOST) { *array = v->h; v->d_valid = false; }
   else { *array = v->d; v->h_valid = false; }
+  vec_drop_geo(v);   // write access
   return 0;
 }
 extern "C" int CeedVectorGetArrayRead(CeedVector v, CeedMemType mtype, const CeedScalar **array) {
@@ -413,7 +426,7 @@ extern "C" int CeedVectorDestroy(CeedVector *vec) {
   *vec = nullptr;
   if (v == CEED_VECTOR_ACTIVE || v == CEED_VECTOR_NONE) return 0;
   if (--v->refcount > 0) return 0;
-  vec_drop_host(v); vec_drop_dev(v);
+  vec_drop_host(v); vec_drop_dev(v); vec_drop_geo(v);
   ceed_unref(v->ceed);
   delete v;
   return 0;
@@ -1019,6 +1032,16 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
     CHK(vec_dev(sv, true, &ps)); a.state_out = ps;  // every point is overwritten
   }
   a.mask_in = (op->mask_mode & 1) ? 1 : 0; a.mask_out = (op->mask_mode & 2) ? 1 : 0;
+  {  // geometric factors recomputed in the kernel if the qdata vector still is what SetupGeo wrote on these elements
+    CeedVector qv = op->in[op->i_qdata].vec;
+    bool same_rule = qv->geo && qv->geo_nelem == r->nelem && qv->geo_Q == ai.basis->Q1d;
+    for (int i = 0; same_rule && i < ai.basis->Q1d; i++)
+      same_rule = qv->geo_qref[i] == ai.basis->qref1d[i] && qv->geo_qwt[i] == ai.basis->qweight1d[i];
+    if (same_rule && op->ceed->recompute_geo) {
+      a.geo = qv->geo;
+      for (int i = 0; i < ai.basis->Q1d; i++) { a.qref[i] = qv->geo_qref[i]; a.qwt[i] = qv->geo_qwt[i]; }
+    }
+  }
   CHK(read_phys(qf, &a.nu, &a.E));
   lame_constants(a.nu, a.E, &a.lambda, &a.TwoMu);
   a.stamps = op->stamps;
@@ -1099,6 +1122,14 @@ static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool 
     if (e == hipErrorInvalidValue && !*kname) return ceed_error("no setup_geo kernel for Q=%d", x.basis->Q1d);
     HIPCHK(e);
     op->launches++;
+    // provenance for the fused kernels: trilinear elements (coordinate basis P = 2) -> keep the map coefficients with
+    // the qdata vector; operators reading this vector may then recompute the factors instead of streaming them
+    if (op->ceed->recompute_geo && x.basis->P1d == 2 && x.rstr->elemsize == 8 && x.rstr->ncomp == 3 && x.rstr->compstride == 1) {
+      HIPCHK(hipMalloc((void **)&out->geo, sizeof(double) * GEO_NCOEF * (size_t)a.nelem));
+      HIPCHK(launch_geo_coeffs(a.off_x, px, out->geo, a.nelem, s));
+      out->geo_nelem = a.nelem; out->geo_Q = x.basis->Q1d;
+      for (int i = 0; i < x.basis->Q1d && i < MAXN1D; i++) { out->geo_qref[i] = x.basis->qref1d[i]; out->geo_qwt[i] = x.basis->qweight1d[i]; }
+    }
     break;
   }
   case PLAN_PROLONG:

@@ -43,7 +43,8 @@ template <int P, int Q> struct PencilGeom {
   static constexpr int SE = 3 * ARR + PAD;                                  // element slab: A, BX, BZ
   static constexpr int RQ = (E * Q3 + 63) / 64;                             // point rounds per group
   static constexpr int RN = (E * P3 + 63) / 64;                             // node rounds per group
-  static constexpr int LDS_BYTES = E * SE * 8;
+  static constexpr int GEO = E * GEO_NCOEF + 2 * Q;                           // element map coefficients + 1-D points / weights
+  static constexpr int LDS_BYTES = (E * SE + GEO) * 8;
 };
 
 // ---- LDS accessors: VOLATILE 8-byte accesses through an LDS pointer + constant offset ----------
@@ -196,7 +197,7 @@ constexpr int pencil_minw(int Q) { return Q == 5 ? CPS_PENCIL_MINW5 : CPS_PENCIL
 #ifndef CPS_PENCIL_NSET_BIGQ
 #define CPS_PENCIL_NSET_BIGQ 1   // Q >= 6: the split-table passes keep all rounds' pencils in VGPRs; a second q-point set
 #endif                           // would push the hyperFS tangent past 256 VGPRs (26 spilled to scratch)
-template <int P, int Q, int QF>
+template <int P, int Q, int QF, bool GEO>
 __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const BasisTables tab_, const FusedGradArgs a) {
   static_assert(offsetof(BasisTables, interp) == 0 && offsetof(BasisTables, colo) == 8 * MAXN1D * MAXN1D &&
                 offsetof(BasisTables, grad) == 16 * MAXN1D * MAXN1D, "kernarg layout of the tables");
@@ -214,8 +215,9 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
   // Q >= 6 one coefficient table alone (2 Q^2 SGPRs) overflows it and the extra scalar-load waits only cost (measured).
   constexpr bool KA = Q <= 5;
 
-  __shared__ __attribute__((aligned(16))) double slab[E * SE];
+  __shared__ __attribute__((aligned(16))) double slab[E * SE + G::GEO];
   const ldsp_t lds0 = (lds_double *)slab;
+  constexpr bool geo = GEO;   // recompute the geometric factors per point instead of reading qdata (FusedGradArgs::geo set)
   const int lane = threadIdx.x;
 
   // ---- work list of this wave (XCD-aware, as in the row kernel) ---------------------------------
@@ -257,6 +259,19 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     const int t = lane + 64 * r, el = t / Q3, q = t % Q3;
     aPt[r] = lds0 + (el * SE + (q / (Q * Q)) * SK + ((q / Q) % Q) * SJ + q % Q);
   }
+  // geometry recompute: packed byte offsets of the point's 1-D indices into the LDS tables, and its element
+  uint32_t pqi[RQ];
+#pragma unroll
+  for (int r = 0; r < RQ; r++) {
+    const int t = min(lane + 64 * r, E * Q3 - 1), el = t / Q3, q = t % Q3;
+    pqi[r] = (uint32_t)((q % Q) * 8) | ((uint32_t)(((q / Q) % Q) * 8) << 8) | ((uint32_t)((q / (Q * Q)) * 8) << 16) | ((uint32_t)el << 24);
+  }
+  constexpr int oGC = E * SE * 8, oGT = oGC + E * GEO_NCOEF * 8;   // byte offsets of the coefficient / table areas
+  if (geo && lane < 2 * Q) {   // 1-D points then weights (written once; the LDS queue orders it before any read)
+    const auto kp = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(BasisTables);
+    const double v = lane < Q ? ((kargs_t)kp)->qref[lane] : ((kargs_t)kp)->qwt[lane - Q];
+    *(ldsp_t)((volatile __attribute__((address_space(3))) char *)lds0 + oGT + lane * 8) = v;
+  }
   uint32_t nd_interior = 0;  // bit r: this lane's node of round r is interior to its element (direct store to y)
   uint32_t ev_idx[(RN + 1) / 2] = {};  // E-vector entry (in doubles) of this lane's node within the group's block, 16 bits each
   static_assert(E * P3 * 3 < 65536, "16-bit E-vector entry index");
@@ -296,8 +311,10 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     for (int c = 0; c < 9; c++) stv[c] = 1e-3 * (c + lane);
     return;
 #endif
+    if (!geo) {
 #pragma unroll
-    for (int c = 0; c < 10; c++) qdv[c] = (qb + c * Q3)[vo];
+      for (int c = 0; c < 10; c++) qdv[c] = (qb + c * Q3)[vo];
+    }
     if constexpr (ST_IN) {
       const double *sb = ka->state_in + e0 * (9 * Q3);
       const uint32_t vs = (uint32_t)(el * (9 * Q3) + q);
@@ -338,6 +355,18 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     const bool more = grp_nx < gend;  // wave-uniform
     const int g_nx = more ? grp_nx : grp;
     load_offsets(g_nx, off_nx);
+    constexpr int RG = (E * GEO_NCOEF + 63) / 64;
+    double gcoef[RG];    // this group's element-map coefficients, lane + 64 i; into LDS right before the physics
+    if (geo) {
+      const kargs_t ka = kargs_fresh<KA>();
+      const int nlive = nlive_of(ka->nelem, grp);
+      const double *gb = ka->geo + (size_t)(ka->elem_begin + grp * E) * GEO_NCOEF;
+#pragma unroll
+      for (int i = 0; i < RG; i++) {
+        const int t = min(lane + 64 * i, E * GEO_NCOEF - 1), el = min(t / GEO_NCOEF, nlive - 1);
+        gcoef[i] = gb[(uint32_t)(el * GEO_NCOEF + t % GEO_NCOEF)];
+      }
+    }
 
     // ---- gather: x -> A at the nodes (Dirichlet flags applied; dead elements of the last group zero) ----
     const kargs_t kg = kargs_fresh<KA>();
@@ -403,6 +432,12 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     pencil_pass<Q, Q, Q, false, BJ, oA, oA>(ktD, aJQ, lane, E * T_JQ);   // F5: d/dy: A -> A in place
 #endif
 
+    if (geo) {
+#pragma unroll
+      for (int i = 0; i < RG; i++)
+        if (lane + 64 * i < E * GEO_NCOEF)
+          *(ldsp_t)((volatile __attribute__((address_space(3))) char *)lds0 + oGC + (lane + 64 * i) * 8) = gcoef[i];
+    }
     // ---- physics: point owners, one round at a time; ug[d*3+c] from (BX, A, BZ), dv back in place ----
 #pragma unroll
     for (int r = 0; r < RQ; r++) {
@@ -416,11 +451,33 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
         ug[3] = lds_rd<oA + 0 * BC>(aPt[r]);  ug[4] = lds_rd<oA + 1 * BC>(aPt[r]);  ug[5] = lds_rd<oA + 2 * BC>(aPt[r]);
         ug[6] = lds_rd<oBZ + 0 * BC>(aPt[r]); ug[7] = lds_rd<oBZ + 1 * BC>(aPt[r]); ug[8] = lds_rd<oBZ + 2 * BC>(aPt[r]);
       }
+      double qdl[10];
+      if (geo) {  // SetupGeo (common.h:47-101) recomputed at this point from the element's trilinear map
+        const uint32_t pk = pqi[r];
+        const auto lb = (volatile __attribute__((address_space(3))) char *)lds0;
+        const ldsp_t ti = (ldsp_t)(lb + oGT + (pk & 0xFFu)), tj = (ldsp_t)(lb + oGT + ((pk >> 8) & 0xFFu)),
+                     tk = (ldsp_t)(lb + oGT + ((pk >> 16) & 0xFFu)), cf = (ldsp_t)(lb + oGC + (pk >> 24) * (GEO_NCOEF * 8));
+        const double xi = ti[0], eta = tj[0], zeta = tk[0], w = ti[Q] * tj[Q] * tk[Q];
+        const double xe = xi * eta, xz = xi * zeta, ez = eta * zeta;
+        double Jg[9];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {  // m: 0 xi, 1 eta, 2 zeta, 3 xi eta, 4 xi zeta, 5 eta zeta, 6 xi eta zeta
+          const double a0 = cf[c * 7 + 0], a1 = cf[c * 7 + 1], a2 = cf[c * 7 + 2], a3 = cf[c * 7 + 3], a4 = cf[c * 7 + 4],
+                       a5 = cf[c * 7 + 5], a6 = cf[c * 7 + 6];
+          Jg[0 * 3 + c] = a0 + a3 * eta + a4 * zeta + a6 * ez;
+          Jg[1 * 3 + c] = a1 + a3 * xi + a5 * zeta + a6 * xz;
+          Jg[2 * 3 + c] = a2 + a4 * xi + a5 * eta + a6 * xe;
+        }
+        qf_setup_geo_rcp(Jg, w, qdl);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 10; c++) qdl[c] = qd[r % NSET][c];
+      }
       if (live) {
 #ifdef CPS_ABLATE_QF
-        for (int c = 0; c < 9; c++) { dv[c] = ug[c] * qd[r % NSET][c] + (ST_IN ? st[r % NSET][c] : qd[r % NSET][9]); sto[c] = dv[c]; }
+        for (int c = 0; c < 9; c++) { dv[c] = ug[c] * qdl[c] + (ST_IN ? st[r % NSET][c] : qdl[9]); sto[c] = dv[c]; }
 #else
-        qf_point<QF>(Phys{ka->nu, ka->E, ka->lambda, ka->TwoMu}, ug, qd[r % NSET], st[r % NSET], dv, sto);
+        qf_point<QF>(Phys{ka->nu, ka->E, ka->lambda, ka->TwoMu}, ug, qdl, st[r % NSET], dv, sto);
 #endif
         if constexpr (ST_OUT) {
           double *sb = ka->state_out + (size_t)(ka->elem_begin + grp * E) * (9 * Q3);
@@ -598,7 +655,8 @@ hipError_t launch_fused_pencil_t(const BasisTables &t, const FusedGradArgs &a, h
   if (!wpc) { const char *e = getenv("CEED_MI355X_PENCIL_WAVES"); wpc = e && atoi(e) > 0 ? atoi(e) : -1; }
   int grid = ncu * (wpc > 0 ? wpc : pencil_waves_per_cu<P, Q>());
   if (grid > ngroups) grid = ngroups;
-  hipLaunchKernelGGL((k_fused_pencil<P, Q, QF>), dim3(grid), dim3(64), 0, s, t, a);
+  if (a.geo) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true>), dim3(grid), dim3(64), 0, s, t, a);
+  else hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, false>), dim3(grid), dim3(64), 0, s, t, a);
   return hipGetLastError();
 }
 

@@ -58,6 +58,10 @@ struct FusedGradArgs {
                                // and launch_assemble() sums them into y; else f64 atomics straight into y
   int variant;                // host-side dispatch only: 0 = row kernel (kernel_fused_grad.hpp),
                                // 1 = pencil kernel (kernel_fused_pencil.hpp)
+  const double *geo;          // pencil kernel: if set, [nelem][GEO_NCOEF] trilinear-map coefficients of the elements
+                               // (launch_geo_coeffs); the kernel then RECOMPUTES qdata = SetupGeo(x) at every point
+                               // (27 FMAs + adjugate) instead of streaming its 80 bytes per point from HBM
+  double qref[MAXN1D], qwt[MAXN1D];  // 1-D quadrature points / weights of the geometry (used with geo)
   int direct;                 // pencil kernel + evec: results at ELEMENT-INTERIOR nodes (0 < i,j,k < P-1; one contributor,
                                // verified on the host) are stored straight into y and skip the E-vector round trip; the
                                // E-vector then is [elem][shell node][3] and the transpose map handed to launch_assemble()
@@ -103,6 +107,11 @@ struct TransferArgs {
   double *evec;           // if set: element results go here ([elem][output nodes][3], masked entries as zeros) and
                           // launch_assemble() sums them into y in element order; else f64 atomics into y
 };
+
+// x_c(xi) = a0 + a[c][0] xi + a[c][1] eta + a[c][2] zeta + a[c][3] xi eta + a[c][4] xi zeta + a[c][5] eta zeta + a[c][6] xi eta zeta
+// on [-1,1]^3: the 7 coefficients per component that the Jacobian d x / d xi needs, [c][m] per element.
+constexpr int GEO_NCOEF = 21;
+hipError_t launch_geo_coeffs(const uint32_t *off_x, const double *xcoord, double *geo, int nelem, hipStream_t s);
 
 struct SetupGeoArgs {
   const uint32_t *off_x;  // [nelem][8]

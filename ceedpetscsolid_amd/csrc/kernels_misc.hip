@@ -54,6 +54,31 @@ __global__ __launch_bounds__(Geom<Q>::BLOCK) void k_setup_geo(const BasisTables 
   for (int c = 0; c < 10; c++) out[c * Q3] = qd[c];
 }
 
+// Trilinear-map coefficients of every element (vertices in tensor order v = i + 2 j + 4 k, xi_v = +-1): what the fused
+// kernel needs to recompute SetupGeo's output at a point (FusedGradArgs::geo).
+__global__ void k_geo_coeffs(const uint32_t *off_x, const double *xcoord, double *geo, int nelem) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, e = t / 3, c = t % 3;
+  if (e >= nelem) return;
+  double x[8];
+#pragma unroll
+  for (int v = 0; v < 8; v++) x[v] = xcoord[(off_x[(size_t)e * 8 + v] & OFF_MASK) + c];
+  // monomial m of the bit set B (1: xi, 2: eta, 4: zeta): a = 1/8 sum_v x_v prod_{d in B} s_d(v)
+  const int B[7] = {1, 2, 4, 3, 5, 6, 7};
+  double *out = geo + (size_t)e * GEO_NCOEF + c * 7;
+#pragma unroll
+  for (int m = 0; m < 7; m++) {
+    double s = 0.;
+#pragma unroll
+    for (int v = 0; v < 8; v++) s += (__popc((unsigned)(~v & B[m])) & 1) ? -x[v] : x[v];
+    out[m] = 0.125 * s;
+  }
+}
+hipError_t launch_geo_coeffs(const uint32_t *off_x, const double *xcoord, double *geo, int nelem, hipStream_t s) {
+  if (nelem <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_geo_coeffs, dim3((unsigned)((3 * nelem + 255) / 256)), dim3(256), 0, s, off_x, xcoord, geo, nelem);
+  return hipGetLastError();
+}
+
 template <int Q>
 static hipError_t setup_geo_t(const BasisTables &t, const SetupGeoArgs &a, hipStream_t s) {
   using G = Geom<Q>;

@@ -356,6 +356,26 @@ CPS_DEV void qf_setup_geo(const double *Jg, double w, double *qd) {
     for (int s = 0; s < 3; s++) qd[1 + 3 * r + s] = adj[r][s] / detJ;
 }
 
+// The same with one reciprocal (rcp_nr, <= 1 ulp) instead of nine divisions: used where the factors are RECOMPUTED per
+// point inside the fused kernel (FusedGradArgs::geo) rather than read back.
+CPS_DEV void qf_setup_geo_rcp(const double *Jg, double w, double *qd) {
+  double adj[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      const int a = (s + 1) % 3, b = (s + 2) % 3, c = (r + 1) % 3, d = (r + 2) % 3;
+      adj[r][s] = Jg[c * 3 + a] * Jg[d * 3 + b] - Jg[d * 3 + a] * Jg[c * 3 + b];
+    }
+  const double detJ = Jg[0] * adj[0][0] + Jg[1] * adj[0][1] + Jg[2] * adj[0][2];
+  const double rdet = rcp_nr(detJ);
+  qd[0] = w * detJ;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int s = 0; s < 3; s++) qd[1 + 3 * r + s] = adj[r][s] * rdet;
+}
+
 // ---- uniform dispatch used by the fused kernels ----------------------------
 // HAS_STATE_IN : Jacobians of the non-linear models read the stored gradu
 // HAS_STATE_OUT: their residuals write it

@@ -311,6 +311,61 @@ def test_apply_add_and_empty_vectors(gpu):
     assert e.to_numpy().size == 0
 
 
+def _ceed_with_env(product_lib, key, val):
+    old = os.environ.get(key)
+    os.environ[key] = val
+    try:
+        return cd.Ceed(product_lib, "/gpu/hip/mi355x")      # the switches are read at CeedInit
+    finally:
+        if old is None:
+            os.environ.pop(key, None)
+        else:
+            os.environ[key] = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("problem", ["linElas", "hyperSS", "hyperFS"])
+def test_recomputed_geometry_equals_stored_qdata(gpu, product_lib, problem):
+    """The pencil kernel recomputes SetupGeo's factors (common.h:47-101) per point from the element's trilinear map
+    when the qdata vector still is what the SetupGeo operator wrote (FusedGradArgs::geo); CEED_MI355X_GEO=0 reads the
+    stored 10 values per point instead.  Same numbers to rounding on distorted (non-affine) elements, every level."""
+    plain = _ceed_with_env(product_lib, "CEED_MI355X_GEO", "0")
+    for mesh, degree in ((distorted_box(3, 2, 3, seed=2, amp=0.2), 4), (distorted_box(2, 2, 1, seed=3, amp=0.2), 6),
+                         (distorted_box(5, 3, 1, seed=5, amp=0.2), 1), (hollow_cylinder_mesh(2, 8, 3), 3)):
+        outs = []
+        for c in (gpu, plain):
+            p = SolidProblem(c, mesh, degree, problem, nu=0.3, E=2.0, bc_sides=[1] if 1 in mesh.side_sets else [998])
+            n = p.lsize()
+            X, R = c.vector(n), c.vector(n)
+            X.set_array(p.smooth_state(0.1)); p.form_residual(X, R)
+            res = [R.to_numpy()]
+            for lv in range(len(p.levels)):
+                nl = p.lsize(lv)
+                x = c.vector(nl).set_array(np.random.default_rng(7 + lv).uniform(-1, 1, nl))
+                y = c.vector(nl)
+                p.apply_jacobian(lv, x, y)
+                res.append(y.to_numpy())
+            outs.append(res)
+        for a, b in zip(*outs):
+            assert rel_err(a, b) < 1e-13
+
+
+@pytest.mark.gpu
+def test_overwritten_qdata_is_read_not_recomputed(gpu):
+    """The recompute is only valid while qdata is SetupGeo's output: any other write to the vector must switch the
+    operators back to reading it.  Doubling all ten entries multiplies the linear-elastic action by 2 (w detJ) x 2 x 2
+    (dXdx on both sides)."""
+    mesh = distorted_box(2, 2, 2, seed=1, amp=0.1)
+    p = SolidProblem(gpu, mesh, 3, "linElas", nu=0.3, E=1.0, bc_sides=[1], multigrid="none")
+    n = p.lsize()
+    x = gpu.vector(n).set_array(np.random.default_rng(0).uniform(-1, 1, n))
+    y1, y2 = gpu.vector(n), gpu.vector(n)
+    p.apply_jacobian(p.fine, x, y1)
+    p.qdata.set_array(2.0 * p.qdata.to_numpy())
+    p.apply_jacobian(p.fine, x, y2)
+    assert rel_err(y2.to_numpy(), 8.0 * y1.to_numpy()) < 1e-13
+
+
 @pytest.mark.gpu
 def test_direct_interior_stores_equal_the_assembled_path(gpu, product_lib):
     """Element-interior nodes have one contributor: the pencil kernel stores them straight into y and keeps a shell-only
