@@ -7,6 +7,6 @@ for v in orig noqd noqf nopass nostore noqfpass onlymem; do
   rm -rf /tmp/ab_$v
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_$v -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline > /tmp/ab_$v.log 2>&1 || { echo "$v failed"; tail -3 /tmp/ab_$v.log; }
   f=$(find /tmp/ab_$v -name "*kernel_stats.csv" | head -1)
-  echo "$v $(grep 'k_fused_pencil<5, 5, 6>' $f | awk -F, '{print "fused_us", $(NF-4)/1000}') $(grep 'k_assemble' $f | awk -F, '{print "assemble_us", $(NF-4)/1000}')"
+  echo "$v $(grep 'k_fused_pencil<5, 5, 6' $f | awk -F, '{print "fused_us", $(NF-4)/1000}') $(grep 'k_assemble' $f | awk -F, '{print "assemble_us", $(NF-4)/1000}')"
 done
 cp /tmp/orig.so $R/$L

@@ -30,7 +30,7 @@ if kax:
 out = {"kernel": bench["config"]["kernel"], "elements_per_gpu": bench["config"]["elements_per_gpu"],
        "fetch_calibration_factor": f_cal, "write_calibration_factor": w_cal, "per_kernel": {}}
 tot = 0.0
-for name in ("k_fused_pencil<5, 5, 6>", "k_fused_grad<5, 5, 6>", "k_assemble"):
+for name in ("k_fused_pencil<5, 5, 6", "k_fused_grad<5, 5, 6>", "k_assemble"):
     kf, kw = find(fetch, name), find(write, name)
     if not kf: continue
     fb = mean(fetch[kf[0]]["FETCH_SIZE"]) * 1024.0 * (f_cal or 2.0)
