@@ -11,8 +11,7 @@
 // component): it reads the NIN inputs once, produces all NOUT outputs in registers and writes
 // them back IN PLACE.  Every value is read once and written once per pass, and the
 // coefficients are wave-uniform, so they are scalar operands (kernarg -> SGPR), not LDS
-// traffic.  Measured (PMC, config 4): LDS pipe 33 % busy instead of 71 %, LDS instructions per
-// element 441 -> 220; without the q-point stream the kernel runs in 332 us against 398 us.
+// traffic.  Measured (PMC, config 4): LDS instructions per element 441 -> 220, LDS index unit ~30 % busy.
 //
 // Pipeline for a group of E elements owned by ONE wave64 (no s_barrier anywhere: a wave's LDS
 // queue is executed in order).  Arrays A, BX, BZ: [c][k][j][i], strides (1, Q, Q^2, Q^3) doubles.
@@ -20,9 +19,11 @@
 //   F1..F3  interpolate along i, j, k in place      pencil lanes;  F3 also writes dU/dz -> BZ (grad1d)
 //   F4, F5  collocated d/dx: A -> BX, d/dy: A -> A  pencil lanes
 //   QF      9 gradient entries in, 9 out, in place  point-owner lanes, one round of 64 points at a
-//                                                   time; q-point data prefetched a round ahead
+//                                                   time; stored state prefetched two rounds ahead; the
+//                                                   geometric factors RECOMPUTED from the element's
+//                                                   trilinear map (GEO) or read with the state
 //   B1..B5  transposes of F5..F1, accumulating      pencil lanes
-//   final   A (nodes) -> E-vector / atomics         node-owner lanes
+//   final   A (nodes) -> y (element-interior nodes), shell E-vector (shared nodes) / atomics   node-owner lanes
 // Elements per wave E: 8 (Q=2), 4 (Q=3,4), 2 (Q=5), 1 (Q>=6): a pass has 3*Q^2 pencils per element,
 // E picks how well they fill 64 lanes against the LDS slab (9*Q^3 doubles per element).
 #pragma once
