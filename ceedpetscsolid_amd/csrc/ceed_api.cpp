@@ -1124,7 +1124,7 @@ static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool 
     op->launches++;
     // provenance for the fused kernels: trilinear elements (coordinate basis P = 2) -> keep the map coefficients with
     // the qdata vector; operators reading this vector may then recompute the factors instead of streaming them
-    if (op->ceed->recompute_geo && x.basis->P1d == 2 && x.rstr->elemsize == 8 && x.rstr->ncomp == 3 && x.rstr->compstride == 1) {
+    if (op->ceed->recompute_geo && !op->ceed->capturing && x.basis->P1d == 2 && x.rstr->elemsize == 8 && x.rstr->ncomp == 3 && x.rstr->compstride == 1) {
       HIPCHK(hipMalloc((void **)&out->geo, sizeof(double) * GEO_NCOEF * (size_t)a.nelem));
       HIPCHK(launch_geo_coeffs(a.off_x, px, out->geo, a.nelem, s));
       out->geo_nelem = a.nelem; out->geo_Q = x.basis->Q1d;
