@@ -18,6 +18,7 @@
 #include <ceed.h>
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -68,6 +69,7 @@ struct Ceed_private {
   bool atomic_scatter = false;  // CEED_MI355X_SCATTER=atomic: f64 atomics instead of E-vector + assembly
   int fused_variant = 1;        // CEED_MI355X_FUSED=rows: the first-generation row kernel (A/B); default pencil
   bool recompute_geo = true;    // fused pencil kernel recomputes SetupGeo's factors from the element maps (CEED_MI355X_GEO=0: reads qdata)
+  bool even_odd = true;         // pencil kernel applies the 1-D tables in even-odd form (CEED_MI355X_EO=0: plain products)
   bool direct_interior = true;  // pencil kernel: element-interior nodes go straight to y (CEED_MI355X_DIRECT=0: all via the E-vector)
   double *d_scalar = nullptr;   // device scalar for reductions
   double *h_scalar = nullptr;   // pinned host landing slot for it (pageable targets make the runtime stage + pin per copy)
@@ -227,6 +229,8 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   c->fused_variant = (fv && !strcmp(fv, "rows")) ? 0 : 1;
   const char *rg = getenv("CEED_MI355X_GEO");
   c->recompute_geo = c->fused_variant == 1 && !(rg && !strcmp(rg, "0"));
+  const char *eo = getenv("CEED_MI355X_EO");
+  c->even_odd = c->fused_variant == 1 && !(eo && !strcmp(eo, "0"));
   const char *di = getenv("CEED_MI355X_DIRECT");
   c->direct_interior = c->fused_variant == 1 && !c->atomic_scatter && !(di && !strcmp(di, "0"));
   *ceed = c;
@@ -835,6 +839,26 @@ static void fill_tables(BasisTables &t, CeedBasis b) {
   memcpy(t.colo, b->colo1d.data(), sizeof(double) * b->colo1d.size());
   memcpy(t.qw, b->qweight1d.data(), sizeof(double) * b->qweight1d.size());
 }
+// Even-odd form of one 1-D table (FusedGradArgs::eo).  M(o, m) = TR ? tab[m * LD + o] : tab[o * LD + m], NOUT x NIN,
+// expected centro-symmetric (sgn = +1) or centro-antisymmetric (sgn = -1); false if it is not (to 1e-13).
+static bool build_eo_table(const double *tab, int NOUT, int NIN, int LD, bool TR, int sgn, double *T) {
+  auto M = [&](int o, int m) { return TR ? tab[m * LD + o] : tab[o * LD + m]; };
+  double mx = 0.;
+  for (int o = 0; o < NOUT; o++) for (int m = 0; m < NIN; m++) mx = std::max(mx, fabs(M(o, m)));
+  for (int o = 0; o < NOUT; o++) for (int m = 0; m < NIN; m++)
+    if (fabs(M(NOUT - 1 - o, NIN - 1 - m) - sgn * M(o, m)) > 1e-13 * mx) return false;
+  const int HIN = NIN / 2, COUT = (NOUT + 1) / 2;
+  if (COUT > 4 || HIN > 4 || 2 * COUT * HIN + COUT > 30) return false;   // table must stay within 60 SGPRs
+  for (int i = 0; i < EO_TAB; i++) T[i] = 0.;
+  for (int r = 0; r < COUT; r++) {
+    for (int j = 0; j < HIN; j++) {
+      T[r * HIN + j] = 0.5 * (M(r, j) + M(r, NIN - 1 - j));
+      T[16 + r * HIN + j] = 0.5 * (M(r, j) - M(r, NIN - 1 - j));
+    }
+    if (NIN & 1) T[32 + r] = M(r, HIN);
+  }
+  return true;
+}
 static bool is_offsets(CeedElemRestriction r) { return r && r != CEED_ELEMRESTRICTION_NONE && !r->strided; }
 static bool is_strided(CeedElemRestriction r) { return r && r != CEED_ELEMRESTRICTION_NONE && r->strided; }
 
@@ -1032,6 +1056,13 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
     CHK(vec_dev(sv, true, &ps)); a.state_out = ps;  // every point is overwritten
   }
   a.mask_in = (op->mask_mode & 1) ? 1 : 0; a.mask_out = (op->mask_mode & 2) ? 1 : 0;
+  if (op->ceed->even_odd) {   // even-odd tables, if all six are (anti)symmetric and small enough
+    const int Pn = ai.basis->P1d, Qn = ai.basis->Q1d;
+    const BasisTables &t = op->tables;
+    a.eo_ok = build_eo_table(t.interp, Qn, Pn, Pn, false, +1, a.eo[0]) && build_eo_table(t.interp, Pn, Qn, Pn, true, +1, a.eo[1]) &&
+              build_eo_table(t.colo, Qn, Qn, Qn, false, -1, a.eo[2]) && build_eo_table(t.colo, Qn, Qn, Qn, true, -1, a.eo[3]) &&
+              build_eo_table(t.grad, Qn, Pn, Pn, false, -1, a.eo[4]) && build_eo_table(t.grad, Pn, Qn, Pn, true, -1, a.eo[5]);
+  }
   {  // geometric factors recomputed in the kernel if the qdata vector still is what SetupGeo wrote on these elements
     CeedVector qv = op->in[op->i_qdata].vec;
     bool same_rule = qv->geo && qv->geo_nelem == r->nelem && qv->geo_Q == ai.basis->Q1d;

@@ -123,6 +123,36 @@ CPS_DEV void pencil_mac(ktab_t tab, const double *in, double *out) {
     for (int m = 0; m < NIN; m++) out[o] += (TR ? tab[m * LD + o] : tab[o * LD + m]) * in[m];
   }
 }
+// The same product with the table in even-odd form (FusedGradArgs::eo; SGN = +1 centro-symmetric, -1 antisymmetric):
+// xe_j = x_j + x_{K-1-j}, xo_j = x_j - x_{K-1-j};  E_i = sum_j Me[i][j] xe_j + Mm[i] x_mid,  O_i = sum_j Mo[i][j] xo_j;
+// y_i = E_i + O_i,  y_{N-1-i} = SGN (E_i - O_i);  the middle row keeps only its non-vanishing half.
+template <int NOUT, int NIN, int SGN>
+CPS_DEV void pencil_mac_eo(ktab_t T, const double *in, double *out) {
+  constexpr int HIN = NIN / 2, HOUT = NOUT / 2;
+  double xe[HIN > 0 ? HIN : 1], xo[HIN > 0 ? HIN : 1];
+#pragma unroll
+  for (int j = 0; j < HIN; j++) { xe[j] = in[j] + in[NIN - 1 - j]; xo[j] = in[j] - in[NIN - 1 - j]; }
+#pragma unroll
+  for (int i = 0; i < HOUT; i++) {
+    double ev = (NIN & 1) ? T[32 + i] * in[HIN] : 0., od = 0.;
+#pragma unroll
+    for (int j = 0; j < HIN; j++) { ev += T[i * HIN + j] * xe[j]; od += T[16 + i * HIN + j] * xo[j]; }
+    out[i] += ev + od;
+    out[NOUT - 1 - i] += SGN > 0 ? ev - od : od - ev;
+  }
+  if constexpr (NOUT & 1) {
+    double mid = (SGN > 0 && (NIN & 1)) ? T[32 + HOUT] * in[HIN] : 0.;
+#pragma unroll
+    for (int j = 0; j < HIN; j++) mid += SGN > 0 ? T[HOUT * HIN + j] * xe[j] : T[16 + HOUT * HIN + j] * xo[j];
+    out[NOUT - 1 - HOUT] += mid;
+  }
+}
+// plain or even-odd product; `tab` is the matching table (BasisTables entry or FusedGradArgs::eo[t])
+template <int NOUT, int NIN, int LD, bool TR, int SGN, bool EO>
+CPS_DEV void mac_sel(ktab_t tab, const double *in, double *out) {
+  if constexpr (EO) pencil_mac_eo<NOUT, NIN, SGN>(tab, in, out);
+  else pencil_mac<NOUT, NIN, LD, TR>(tab, in, out);
+}
 // round r of a pass with `ntask` tasks: is this lane's task t = lane + 64 r a real one?
 CPS_DEV bool pencil_ok(int lane, int r, int ntask) { return (r + 1) * 64 <= ntask ? true : lane + 64 * r < ntask; }
 
@@ -134,7 +164,9 @@ CPS_DEV bool pencil_ok(int lane, int r, int ntask) { return (r + 1) * 64 <= ntas
 // the register allocator then spills coefficients to VGPR lanes (~950 v_readlane / v_writelane per element at Q = 7,
 // a fifth of the VALU work).  Larger tables are therefore applied in SPLITS of whole output rows, each split loaded
 // (s_load) only after the previous one's FMAs: all rounds of a pass keep their inputs and outputs in VGPRs meanwhile.
-template <int NOUT, int NIN> constexpr int table_splits() { return NOUT * NIN <= 30 ? 1 : (NOUT * NIN <= 56 ? 2 : 3); }
+template <int NOUT, int NIN, bool EO = false> constexpr int table_splits() {
+  return (EO || NOUT * NIN <= 30) ? 1 : (NOUT * NIN <= 56 ? 2 : 3);   // an even-odd table is at most 30 coefficients
+}
 // rows [O0, O1) of the product of pencil_mac
 template <int O0, int O1, int NIN, int LD, bool TR>
 CPS_DEV void pencil_mac_rows(ktab_t tab, const double *in, double *out) {
@@ -157,19 +189,19 @@ CPS_DEV void mac_rounds(ktab_t table, const double (&in)[R][NIN], double (&out)[
     mac_rounds<NOUT, NIN, LD, TR, R, DEP0, S + 1>(table, in, out, lane, ntask);
   }
 }
-template <int NIN, int NOUT, int LD, bool TR, int SB, int SRC, int DST, int R>
+template <int NIN, int NOUT, int LD, bool TR, int SB, int SRC, int DST, int SGN, bool EO, int R>
 CPS_DEV void pencil_pass(ktab_t table, const ldsp_t (&addr)[R], int lane, int ntask) {
   double in[R][NIN];
 #pragma unroll
   for (int r = 0; r < R; r++)
     if (pencil_ok(lane, r, ntask)) pencil_ld<NIN, SB, SRC>(addr[r], in[r]);
-  if constexpr (table_splits<NOUT, NIN>() == 1) {
+  if constexpr (table_splits<NOUT, NIN, EO>() == 1) {
     const ktab_t t = ktab_fresh(table);
 #pragma unroll
     for (int r = 0; r < R; r++)
       if (pencil_ok(lane, r, ntask)) {
         double out[NOUT] = {};
-        pencil_mac<NOUT, NIN, LD, TR>(t, in[r], out);
+        mac_sel<NOUT, NIN, LD, TR, SGN, EO>(t, in[r], out);
         pencil_st<NOUT, SB, DST>(addr[r], out);
       }
   } else {
@@ -198,13 +230,17 @@ constexpr int pencil_minw(int Q) { return Q == 5 ? CPS_PENCIL_MINW5 : CPS_PENCIL
 #ifndef CPS_PENCIL_NSET_BIGQ
 #define CPS_PENCIL_NSET_BIGQ 1   // Q >= 6: the split-table passes keep all rounds' pencils in VGPRs; a second q-point set
 #endif                           // would push the hyperFS tangent past 256 VGPRs (26 spilled to scratch)
-template <int P, int Q, int QF, bool GEO>
+template <int P, int Q, int QF, bool GEO, bool EO>
 __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const BasisTables tab_, const FusedGradArgs a) {
   static_assert(offsetof(BasisTables, interp) == 0 && offsetof(BasisTables, colo) == 8 * MAXN1D * MAXN1D &&
                 offsetof(BasisTables, grad) == 16 * MAXN1D * MAXN1D, "kernarg layout of the tables");
   (void)tab_;  // first kernel argument: lives at offset 0 of the kernarg segment, read through kt below
   const ktab_t kt = (ktab_t)__builtin_amdgcn_kernarg_segment_ptr();
   const ktab_t ktB = kt, ktD = kt + MAXN1D * MAXN1D, ktG = kt + 2 * MAXN1D * MAXN1D;
+  // the six products' tables: plain (B, D, G read forward or transposed) or their even-odd forms (FusedGradArgs::eo)
+  const ktab_t eo0 = (ktab_t)((const __attribute__((address_space(4))) char *)kt + sizeof(BasisTables) + offsetof(FusedGradArgs, eo));
+  const ktab_t tBf = EO ? eo0 : ktB, tBt = EO ? eo0 + EO_TAB : ktB, tDf = EO ? eo0 + 2 * EO_TAB : ktD,
+               tDt = EO ? eo0 + 3 * EO_TAB : ktD, tGf = EO ? eo0 + 4 * EO_TAB : ktG, tGt = EO ? eo0 + 5 * EO_TAB : ktG;
   using G = PencilGeom<P, Q>;
   constexpr int Q3 = G::Q3, P3 = G::P3, E = G::E, RQ = G::RQ, RN = G::RN;
   constexpr int SJ = G::SJ, SK = G::SK, SC = G::SC, SE = G::SE;
@@ -385,29 +421,29 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
 
 #ifndef CPS_ABLATE_PASSES  // (CPS_ABLATE_*: timing-only diagnostic builds for tools/ablate_run.sh, WRONG results, never shipped)
     // ---- B: nodes -> points, in place -----------------------------------------------------------------
-    pencil_pass<P, Q, P, false, BI, oA, oA>(ktB, aIP, lane, E * T_IP);   // F1: along i at nodal (j, k)
-    pencil_pass<P, Q, P, false, BJ, oA, oA>(ktB, aJP, lane, E * T_JP);   // F2: along j at (i', nodal k)
+    pencil_pass<P, Q, P, false, BI, oA, oA, +1, EO>(tBf, aIP, lane, E * T_IP);   // F1: along i at nodal (j, k)
+    pencil_pass<P, Q, P, false, BJ, oA, oA, +1, EO>(tBf, aJP, lane, E * T_JP);   // F2: along j at (i', nodal k)
     {  // F3: along k at (i', j'): U -> A in place and dU/dz -> BZ (grad1d on the nodal values), one
        // table at a time (both = 100 SGPRs = SGPR spills)
       double in[R_K][P];
 #pragma unroll
       for (int r = 0; r < R_K; r++)
         if (pencil_ok(lane, r, E * T_K)) pencil_ld<P, BK, oA>(aK[r], in[r]);
-      if constexpr (table_splits<Q, P>() == 1) {
-        const ktab_t tB = ktab_fresh(ktB);
+      if constexpr (table_splits<Q, P, EO>() == 1) {
+        const ktab_t tB = ktab_fresh(tBf);
 #pragma unroll
         for (int r = 0; r < R_K; r++)
           if (pencil_ok(lane, r, E * T_K)) {
             double out[Q] = {};
-            pencil_mac<Q, P, P, false>(tB, in[r], out);
+            mac_sel<Q, P, P, false, +1, EO>(tB, in[r], out);
             pencil_st<Q, BK, oA>(aK[r], out);
           }
-        const ktab_t tG = ktab_fresh(ktG);
+        const ktab_t tG = ktab_fresh(tGf);
 #pragma unroll
         for (int r = 0; r < R_K; r++)
           if (pencil_ok(lane, r, E * T_K)) {
             double dz[Q] = {};
-            pencil_mac<Q, P, P, false>(tG, in[r], dz);
+            mac_sel<Q, P, P, false, -1, EO>(tG, in[r], dz);
             pencil_st<Q, BK, oBZ>(aK[r], dz);
           }
       } else {  // large tables: row blocks (mac_rounds), one product after the other
@@ -429,8 +465,8 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       }
     }
     // ---- collocated gradient on the quadrature points -----------------------------------------------------
-    pencil_pass<Q, Q, Q, false, BI, oA, oBX>(ktD, aIQ, lane, E * T_IQ);  // F4: d/dx: A -> BX
-    pencil_pass<Q, Q, Q, false, BJ, oA, oA>(ktD, aJQ, lane, E * T_JQ);   // F5: d/dy: A -> A in place
+    pencil_pass<Q, Q, Q, false, BI, oA, oBX, -1, EO>(tDf, aIQ, lane, E * T_IQ);  // F4: d/dx: A -> BX
+    pencil_pass<Q, Q, Q, false, BJ, oA, oA, -1, EO>(tDf, aJQ, lane, E * T_JQ);   // F5: d/dy: A -> A in place
 #endif
 
     if (geo) {
@@ -502,11 +538,11 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
 
 #ifndef CPS_ABLATE_PASSES
     // ---- gradient^T --------------------------------------------------------------------------------------
-    pencil_pass<Q, Q, Q, true, BI, oBX, oBX>(ktD, aIQ, lane, E * T_IQ);  // B1: W1 = Dx^T g0, BX in place
+    pencil_pass<Q, Q, Q, true, BI, oBX, oBX, -1, EO>(tDt, aIQ, lane, E * T_IQ);  // B1: W1 = Dx^T g0, BX in place
     {  // B2: W2 = W1 + Dy^T g1, A in place.  Two inputs per task: software-pipelined over the rounds
        // (two rounds of inputs live instead of all)
-      if constexpr (table_splits<Q, Q>() == 1) {
-        const ktab_t tD = ktab_fresh(ktD);
+      if constexpr (table_splits<Q, Q, EO>() == 1) {
+        const ktab_t tD = ktab_fresh(tDt);
         double in[2][Q], acc[2][Q];
         if (pencil_ok(lane, 0, E * T_JQ)) { pencil_ld<Q, BJ, oA>(aJQ[0], in[0]); pencil_ld<Q, BJ, oBX>(aJQ[0], acc[0]); }
 #pragma unroll
@@ -516,7 +552,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
             pencil_ld<Q, BJ, oBX>(aJQ[r + 1], acc[(r + 1) & 1]);
           }
           if (pencil_ok(lane, r, E * T_JQ)) {
-            pencil_mac<Q, Q, Q, true>(tD, in[r & 1], acc[r & 1]);
+            mac_sel<Q, Q, Q, true, -1, EO>(tD, in[r & 1], acc[r & 1]);
             pencil_st<Q, BJ, oA>(aJQ[r], acc[r & 1]);
           }
         }
@@ -536,7 +572,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     }
     {  // B3: along k: A[k<P] = B^T W2 + G^T g2, in two sweeps so that one coefficient table is live at a time
       double out[R_K][P];
-      if constexpr (table_splits<P, Q>() > 1) {  // large tables: all rounds live, the tables in row blocks
+      if constexpr (table_splits<P, Q, EO>() > 1) {  // large tables: all rounds live, the tables in row blocks
         double in[R_K][Q];
 #pragma unroll
         for (int r = 0; r < R_K; r++) {
@@ -554,7 +590,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
           if (pencil_ok(lane, r, E * T_K)) pencil_st<P, BK, oA>(aK[r], out[r]);
       } else {
       {
-        const ktab_t tB = ktab_fresh(ktB);
+        const ktab_t tB = ktab_fresh(tBt);
         double in[2][Q];
         if (pencil_ok(lane, 0, E * T_K)) pencil_ld<Q, BK, oA>(aK[0], in[0]);
 #pragma unroll
@@ -562,19 +598,19 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
           if (r + 1 < R_K && pencil_ok(lane, r + 1, E * T_K)) pencil_ld<Q, BK, oA>(aK[r + 1], in[(r + 1) & 1]);
 #pragma unroll
           for (int m = 0; m < P; m++) out[r][m] = 0.;
-          if (pencil_ok(lane, r, E * T_K)) pencil_mac<P, Q, P, true>(tB, in[r & 1], out[r]);
+          if (pencil_ok(lane, r, E * T_K)) mac_sel<P, Q, P, true, +1, EO>(tB, in[r & 1], out[r]);
         }
       }
       {
         // not before the first sweep has used its table: both at once do not fit the SGPR file (they were spilled)
-        const ktab_t tG = ktab_fresh_after<R_K * P>(ktG, &out[0][0]);
+        const ktab_t tG = ktab_fresh_after<R_K * P>(tGt, &out[0][0]);
         double in2[2][Q];
         if (pencil_ok(lane, 0, E * T_K)) pencil_ld<Q, BK, oBZ>(aK[0], in2[0]);
 #pragma unroll
         for (int r = 0; r < R_K; r++) {
           if (r + 1 < R_K && pencil_ok(lane, r + 1, E * T_K)) pencil_ld<Q, BK, oBZ>(aK[r + 1], in2[(r + 1) & 1]);
           if (pencil_ok(lane, r, E * T_K)) {
-            pencil_mac<P, Q, P, true>(tG, in2[r & 1], out[r]);
+            mac_sel<P, Q, P, true, -1, EO>(tG, in2[r & 1], out[r]);
             pencil_st<P, BK, oA>(aK[r], out[r]);
           }
         }
@@ -587,8 +623,8 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
                           // final store and the next gather's address work hide most of its latency
     // ---- B^T: points -> nodes ---------------------------------------------------------------------------
 #ifndef CPS_ABLATE_PASSES
-    pencil_pass<Q, P, P, true, BJ, oA, oA>(ktB, aJP, lane, E * T_JP);    // B4: along j
-    pencil_pass<Q, P, P, true, BI, oA, oA>(ktB, aIP, lane, E * T_IP);    // B5: along i
+    pencil_pass<Q, P, P, true, BJ, oA, oA, +1, EO>(tBt, aJP, lane, E * T_JP);    // B4: along j
+    pencil_pass<Q, P, P, true, BI, oA, oA, +1, EO>(tBt, aIP, lane, E * T_IP);    // B5: along i
 #endif
     // ---- final: node owners -> E-vector (plain coalesced stores) or f64 atomics ---------------------------
     {
@@ -656,8 +692,10 @@ hipError_t launch_fused_pencil_t(const BasisTables &t, const FusedGradArgs &a, h
   if (!wpc) { const char *e = getenv("CEED_MI355X_PENCIL_WAVES"); wpc = e && atoi(e) > 0 ? atoi(e) : -1; }
   int grid = ncu * (wpc > 0 ? wpc : pencil_waves_per_cu<P, Q>());
   if (grid > ngroups) grid = ngroups;
-  if (a.geo) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true>), dim3(grid), dim3(64), 0, s, t, a);
-  else hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, false>), dim3(grid), dim3(64), 0, s, t, a);
+  if (a.geo && a.eo_ok) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true, true>), dim3(grid), dim3(64), 0, s, t, a);
+  else if (a.geo) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true, false>), dim3(grid), dim3(64), 0, s, t, a);
+  else if (a.eo_ok) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, false, true>), dim3(grid), dim3(64), 0, s, t, a);
+  else hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, false, false>), dim3(grid), dim3(64), 0, s, t, a);
   return hipGetLastError();
 }
 

@@ -26,6 +26,7 @@ enum QFKind : int {
 };
 
 constexpr int MAXN1D = 8;  // largest P or Q supported by the kernel tables
+constexpr int EO_TAB = 36;  // doubles per even-odd table (see FusedGradArgs::eo)
 
 // 1-D tables handed to kernels by value: they live in the kernarg segment; the pencil kernel reads them from
 // there as scalar operands, the other kernels stage them into LDS once per block.
@@ -62,6 +63,13 @@ struct FusedGradArgs {
                                // (launch_geo_coeffs); the kernel then RECOMPUTES qdata = SetupGeo(x) at every point
                                // (27 FMAs + adjugate) instead of streaming its 80 bytes per point from HBM
   double qref[MAXN1D], qwt[MAXN1D];  // 1-D quadrature points / weights of the geometry (used with geo)
+  // Even-odd form of the 1-D tables (pencil kernel, EO instantiation).  The tables of symmetric point sets are
+  // centro-symmetric (interp: M[N-1-i][K-1-j] = M[i][j]) or centro-antisymmetric (derivatives), so with
+  // xe = x_j + x_{K-1-j}, xo = x_j - x_{K-1-j} an N x K product costs ~N K / 2 FMAs + N + K adds instead of N K FMAs.
+  // eo[t]: t = 0 B, 1 B^T, 2 D, 3 D^T, 4 G, 5 G^T; per table Me[r][j] at r * (K/2) + j, Mo at 16 + r * (K/2) + j, the
+  // middle column at 32 + r (r < (N+1)/2, j < K/2); built and checked by the host (eo_ok).
+  double eo[6][EO_TAB];
+  int eo_ok;
   int direct;                 // pencil kernel + evec: results at ELEMENT-INTERIOR nodes (0 < i,j,k < P-1; one contributor,
                                // verified on the host) are stored straight into y and skip the E-vector round trip; the
                                // E-vector then is [elem][shell node][3] and the transpose map handed to launch_assemble()

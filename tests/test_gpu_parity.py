@@ -351,6 +351,32 @@ def test_recomputed_geometry_equals_stored_qdata(gpu, product_lib, problem):
 
 
 @pytest.mark.gpu
+def test_even_odd_products_equal_plain_products(gpu, product_lib):
+    """The 1-D tables of the Gauss / Gauss-Lobatto rules are centro-(anti)symmetric; the pencil kernel applies them in
+    even-odd form (FusedGradArgs::eo, about half the multiplications).  CEED_MI355X_EO=0 applies the plain tables:
+    same results to rounding on every level of a ladder (P < Q: rectangular tables) and at P = Q = 7."""
+    plain = _ceed_with_env(product_lib, "CEED_MI355X_EO", "0")
+    for mesh, degree, mg in ((distorted_box(3, 2, 2, seed=2, amp=0.2), 4, "uniform"), (distorted_box(2, 1, 2, seed=3, amp=0.2), 6, "logarithmic"),
+                             (distorted_box(3, 3, 1, seed=4, amp=0.2), 3, "logarithmic")):
+        outs = []
+        for c in (gpu, plain):
+            p = SolidProblem(c, mesh, degree, "hyperFS", nu=0.3, E=2.0, bc_sides=[1], multigrid=mg)
+            n = p.lsize()
+            X, R = c.vector(n), c.vector(n)
+            X.set_array(p.smooth_state(0.1)); p.form_residual(X, R)
+            res = [R.to_numpy()]
+            for lv in range(len(p.levels)):
+                nl = p.lsize(lv)
+                x = c.vector(nl).set_array(np.random.default_rng(3 + lv).uniform(-1, 1, nl))
+                y = c.vector(nl)
+                p.apply_jacobian(lv, x, y)
+                res.append(y.to_numpy())
+            outs.append(res)
+        for a, b in zip(*outs):
+            assert rel_err(a, b) < 1e-13
+
+
+@pytest.mark.gpu
 def test_overwritten_qdata_is_read_not_recomputed(gpu):
     """The recompute is only valid while qdata is SetupGeo's output: any other write to the vector must switch the
     operators back to reading it.  Doubling all ten entries multiplies the linear-elastic action by 2 (w detJ) x 2 x 2
