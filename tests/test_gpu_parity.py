@@ -210,6 +210,34 @@ def test_full_size_properties_config4(gpu):
     assert np.abs(J(t)).max() < 1e-11 * np.abs(jv).max()
 
 
+@pytest.mark.parametrize("which", ["config 4", "config 5 per-GPU block"])
+def test_full_size_matches_oracle(oracle, oracle_lib, gpu, which):
+    """BASELINE configs 4 and 5 (one GPU's 32^3 block, p=6) at FULL size against the oracle itself (threaded over
+    elements: a residual and a Jacobian apply of a ~20 M-dof problem take the CPU a few seconds each): the north-star
+    tolerance on the headline workloads, not only their size-independent properties."""
+    import ctypes as C
+    if which == "config 4":
+        mesh, degree, bc = hollow_cylinder_mesh(10, 110, 90), 4, [998, 999]
+    else:
+        mesh, degree, bc = box_mesh(32, 32, 32), 6, [1, 2]
+    nthreads = max(1, min(16, len(os.sched_getaffinity(0))))
+    oracle_lib.lib.OracleSetNumThreads(C.c_int(nthreads))
+    try:
+        pa, pb = build_pair(oracle, gpu, mesh, degree, "hyperFS", nu=0.3, E=1.0, bc_sides=bc, multigrid="none")
+        n = pa.lsize()
+        u = pa.smooth_state(0.1)
+        xa, xb = vec_pair(pa, pb, n, u); ya, yb = vec_pair(pa, pb, n)
+        pa.form_residual(xa, ya); pb.form_residual(xb, yb)
+        assert rel_err(yb.to_numpy(), ya.to_numpy()) < TOL
+        x = np.random.default_rng(4).uniform(-1, 1, n)
+        xa, xb = vec_pair(pa, pb, n, x)
+        pa.apply_jacobian(pa.fine, xa, ya); pb.apply_jacobian(pb.fine, xb, yb)
+        assert pb.levels[pb.fine].opJacob.kernel_name.endswith("/pencil")
+        assert rel_err(yb.to_numpy(), ya.to_numpy()) < TOL
+    finally:
+        oracle_lib.lib.OracleSetNumThreads(C.c_int(1))
+
+
 def test_device_pointer_use_pointer_roundtrip(gpu):
     """matops.c:40-50 with -memtype device: SetArray(DEVICE, USE_POINTER) / TakeArray on
     buffers owned by the caller (torch tensors standing in for PETSc's device Vecs)."""
