@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size-2 gloo, element partition + interface halo sum (replaces
+"""N > 1 path on CPU: world_size 2 and 3 (gloo), element partition + interface halo sum (replaces
 DMLocalToGlobal(ADD_VALUES), matops.c:57) against the single-rank result on the whole mesh."""
 import os
 import sys
@@ -17,9 +17,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _halo_worker  # noqa: E402
 
 
-@pytest.mark.parametrize("mode", ["slab", "partition"])
-def test_two_rank_jacobian_matches_single_rank(oracle, mode):
-    world = 2
+@pytest.mark.parametrize("mode,world", [("slab", 2), ("partition", 2), ("slab", 3)],
+                         ids=["slab-2", "partition-2", "slab-3 (an interior rank with two neighbours)"])
+def test_two_rank_jacobian_matches_single_rank(oracle, mode, world):
     with tempfile.TemporaryDirectory() as d:
         initfile = os.path.join(d, "init")
         mp.spawn(_halo_worker.run, args=(world, initfile, d, mode), nprocs=world, join=True)
@@ -36,8 +36,10 @@ def test_two_rank_jacobian_matches_single_rank(oracle, mode):
     x = _halo_worker.coord_field(xyz, lv.mask)
     X.set_array(x); p.apply_jacobian(p.fine, X, Y)
     yref = Y.to_numpy().reshape(-1, 3)
-    assert parts[0]["nglob"] == parts[1]["nglob"] == p.n_free()
-    assert parts[0]["nshared"] == parts[1]["nshared"] == 3 * (2 * 3 + 1) * (6 * 3)
+    per_interface = 3 * (2 * 3 + 1) * (6 * 3)
+    for r, part in enumerate(parts):
+        assert part["nglob"] == p.n_free()
+        assert part["nshared"] == per_interface * (1 if r in (0, world - 1) else 2)
     assert abs(parts[0]["dot"] - x @ Y.to_numpy()) < 1e-12 * abs(x @ Y.to_numpy())
     # match nodes by their partition-independent topological keys (interior-of-element keys excluded)
     kfull = key_bytes(lv.dofmap.node_keys)
