@@ -63,7 +63,7 @@ class CeedLib:
         "CeedOperatorLinearAssembleDiagonal", "CeedOperatorDestroy",
         "CeedXSetErrorReturn", "CeedXLastError", "CeedXSetStream", "CeedXSynchronize",
         "CeedXOperatorGetKernelName", "CeedXOperatorSetDirichletMask",
-        "CeedXOperatorSetTiming", "CeedXOperatorGetTiming", "CeedXOperatorSetDirichletMaskMode",
+        "CeedXOperatorSetTiming", "CeedXOperatorGetTiming", "CeedXOperatorSetDirichletMaskMode", "CeedXOperatorGetGatedStats",
         "CeedXOperatorSetFineScale", "CeedXOperatorSetOverlapSplit", "CeedXOperatorApplyPhase",
         "CeedXVectorPointwiseMult", "CeedXVectorAXPBY", "CeedXVectorDot", "CeedXVectorChebyshevUpdate",
         "CeedXGraphBeginCapture", "CeedXGraphEndCapture", "CeedXGraphLaunch", "CeedXGraphDestroy",
@@ -455,6 +455,12 @@ class Operator:
         ms, n = C.c_double(), C.c_int64()
         self.L.chk(self.L.lib.CeedXOperatorGetTiming(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def gated_stats(self) -> dict:
+        """CeedXOperatorGetGatedStats: how much of the restriction transpose ran beside the fused kernel."""
+        out = (C.c_longlong * 5)()
+        self.L.chk(self.L.lib.CeedXOperatorGetGatedStats(self.h, out))
+        return dict(items=out[0], rows=out[1], cut_rows=out[2], tail_items=out[3], applies=out[4])
 
     def destroy(self):
         if self.h:

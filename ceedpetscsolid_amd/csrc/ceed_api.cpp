@@ -66,11 +66,24 @@ struct Ceed_private {
   // scratch E-vector shared by the operators of this Ceed (applies are serialised on `stream`)
   double *evec = nullptr;
   size_t evec_len = 0;
+  // A recorded hipGraph has the scratch pointer of its capture time baked into its kernel nodes.  When the scratch has
+  // to grow while a graph of this Ceed is alive (or is being recorded), the old buffer is PARKED, not freed: replays of
+  // the older graphs keep a valid scratch of the size they were recorded with.  Parked buffers go when the last graph goes.
+  std::vector<double *> evec_parked;
+  int live_graphs = 0;
   bool atomic_scatter = false;  // CEED_MI355X_SCATTER=atomic: f64 atomics instead of E-vector + assembly
   int fused_variant = 1;        // CEED_MI355X_FUSED=rows: the first-generation row kernel (A/B); default pencil
   bool recompute_geo = true;    // fused pencil kernel recomputes SetupGeo's factors from the element maps (CEED_MI355X_GEO=0: reads qdata)
   bool even_odd = true;         // pencil kernel applies the 1-D tables in even-odd form (CEED_MI355X_EO=0: plain products)
   bool direct_interior = true;  // pencil kernel: element-interior nodes go straight to y (CEED_MI355X_DIRECT=0: all via the E-vector)
+  unsigned *queue = nullptr;    // per-XCD ticket counters of the pencil kernel's dynamic schedule (8 x QUEUE_STRIDE)
+  bool dynamic_sched = false;   // CEED_MI355X_SCHED=dynamic: dynamic group schedule also where the assembly is not gated (A/B)
+  int asm_overlap = 0;          // EXPERIMENT CEED_MI355X_ASM_OVERLAP=1: k_assemble on a second stream beside the fused kernel (ungated: timing only)
+  bool gated_assembly = true;   // restriction transpose beside the fused kernel (k_assemble_gated + k_assemble_tail); CEED_MI355X_ASSEMBLE=serial: k_assemble after it
+  int gated_waves = 4;          // persistent assembler waves per CU (CEED_MI355X_ASM_WAVES)
+  int gated_spins = 1 << 19;    // the gated kernel's bounded wait for one bucket, in ~2 us polls (CEED_MI355X_ASM_SPINS)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double *d_scalar = nullptr;   // device scalar for reductions
   double *h_scalar = nullptr;   // pinned host landing slot for it (pageable targets make the runtime stage + pin per copy)
   // hipGraph capture (CeedXGraphBeginCapture): device work is recorded on `capture_stream`
@@ -116,6 +129,25 @@ struct CsrMap {
   }
 };
 
+// The transpose map re-ordered for the gated assembly (kernels.hpp, GatedAsmArgs): rows by (chunk, bucket of the last
+// contributor), cut rows last; built for one group size E (elements per wave of the pencil kernel) on the host.
+struct GatedMap {
+  bool built = false;
+  int E = 0, skipP = 0, nb = 0, bucket_shift = 0, nitems = 0, nrows_local = 0, nrows = 0, nskipped = 0;
+  int evec_stride = 0;   // doubles per element block of the E-vector: whole 128-byte lines
+  bool full_cover = false;
+  int item_begin[9] = {0};
+  std::vector<uint32_t> h_node_off;   // re-ordered (for the per-operator Dirichlet flags)
+  uint32_t *d_rowptr = nullptr, *d_cols = nullptr, *d_node_off = nullptr, *d_item_row = nullptr, *d_item_bucket = nullptr,
+           *d_bucket_groups = nullptr, *d_bucket_items = nullptr;
+  unsigned *d_ctrl = nullptr;
+  void release() {
+    for (uint32_t *p : {d_rowptr, d_cols, d_node_off, d_item_row, d_item_bucket, d_bucket_groups, d_bucket_items}) if (p) (void)hipFree(p);
+    if (d_ctrl) (void)hipFree(d_ctrl);
+    d_rowptr = d_cols = d_node_off = d_item_row = d_item_bucket = d_bucket_groups = d_bucket_items = nullptr; d_ctrl = nullptr; built = false;
+  }
+};
+
 struct CeedElemRestriction_private {
   Ceed ceed = nullptr;
   int refcount = 1;
@@ -128,6 +160,7 @@ struct CeedElemRestriction_private {
   // (E-vector positions e*elemsize + n, in element order) -- built on first use
   CsrMap csr;   // default map (nodes in ascending offset order)
   CsrMap csr_shell;        // the same without the element-interior nodes (FusedGradArgs::direct)
+  GatedMap gated;          // the map of the fused residual / Jacobian apply, re-ordered for the gated assembly
   int interior_private = 0;  // 0: not checked yet; 1: every element-interior node has one contributor; -1: not so
 };
 
@@ -174,6 +207,7 @@ struct CeedOperator_private {
   unsigned char *d_node_flags = nullptr;      // per node of the restriction's transpose map
   unsigned char *d_node_flags_ovl = nullptr;  // per node of the operator's own (priority-first) map
   unsigned char *d_node_flags_shell = nullptr;  // per node of the restriction's shell map (direct-store mode)
+  unsigned char *d_node_flags_gated = nullptr;  // per row of the restriction's gated map
   std::vector<unsigned char> h_mask;      // copy of the output mask (node flags are derived lazily)
   int mask_mode = 0;
   // optional fine-side scale for transfers
@@ -233,11 +267,22 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   c->even_odd = c->fused_variant == 1 && !(eo && !strcmp(eo, "0"));
   const char *di = getenv("CEED_MI355X_DIRECT");
   c->direct_interior = c->fused_variant == 1 && !c->atomic_scatter && !(di && !strcmp(di, "0"));
+  const char *sd = getenv("CEED_MI355X_SCHED");
+  c->dynamic_sched = c->fused_variant == 1 && sd && !strcmp(sd, "dynamic");
+  const char *ao = getenv("CEED_MI355X_ASM_OVERLAP");
+  c->asm_overlap = ao ? atoi(ao) : 0;
+  const char *ga = getenv("CEED_MI355X_ASSEMBLE");
+  c->gated_assembly = c->fused_variant == 1 && !c->atomic_scatter && !(ga && !strcmp(ga, "serial"));
+  const char *gw = getenv("CEED_MI355X_ASM_WAVES");
+  if (gw && atoi(gw) > 0) c->gated_waves = atoi(gw);
+  const char *gs = getenv("CEED_MI355X_ASM_SPINS");
+  if (gs && atoi(gs) > 0) c->gated_spins = atoi(gs);
   *ceed = c;
   return 0;
 }
 static void ceed_ref(Ceed c) { c->refcount++; }
-static void ceed_unref(Ceed c) { if (--c->refcount == 0) { if (c->capture_stream) (void)hipStreamDestroy(c->capture_stream); if (c->evec) (void)hipFree(c->evec); if (c->d_scalar) (void)hipFree(c->d_scalar); if (c->h_scalar) (void)hipHostFree(c->h_scalar); delete c; } }
+static void ceed_free_parked(Ceed c) { for (double *p : c->evec_parked) (void)hipFree(p); c->evec_parked.clear(); }
+static void ceed_unref(Ceed c) { if (--c->refcount == 0) { if (c->capture_stream) (void)hipStreamDestroy(c->capture_stream); if (c->evec) (void)hipFree(c->evec); ceed_free_parked(c); if (c->queue) (void)hipFree(c->queue); if (c->side_stream) (void)hipStreamDestroy(c->side_stream); if (c->ev_fork) (void)hipEventDestroy(c->ev_fork); if (c->ev_join) (void)hipEventDestroy(c->ev_join); if (c->d_scalar) (void)hipFree(c->d_scalar); if (c->h_scalar) (void)hipHostFree(c->h_scalar); delete c; } }
 extern "C" int CeedDestroy(Ceed *ceed) {
   if (!ceed || !*ceed) return 0;
   ceed_unref(*ceed);
@@ -275,6 +320,7 @@ extern "C" int CeedXGraphEndCapture(Ceed ceed, CeedXGraph *graph) {
   e = hipGraphInstantiate(&G->exec, g, nullptr, nullptr, 0);
   if (e != hipSuccess) { (void)hipGraphDestroy(g); delete G; return ceed_error("hipGraphInstantiate: %s", hipGetErrorString(e)); }
   ceed_ref(ceed);
+  ceed->live_graphs++;
   *graph = G;
   return 0;
 }
@@ -289,6 +335,7 @@ extern "C" int CeedXGraphDestroy(CeedXGraph *graph) {
   (void)hipStreamSynchronize(G->ceed->stream);
   if (G->exec) (void)hipGraphExecDestroy(G->exec);
   if (G->graph) (void)hipGraphDestroy(G->graph);
+  if (--G->ceed->live_graphs == 0 && !G->ceed->capturing) ceed_free_parked(G->ceed);   // the stream was drained above
   ceed_unref(G->ceed);
   delete G;
   *graph = nullptr;
@@ -514,6 +561,7 @@ extern "C" int CeedElemRestrictionDestroy(CeedElemRestriction *rstr) {
   if (r->d_offsets) (void)hipFree(r->d_offsets);
   r->csr.release();
   r->csr_shell.release();
+  r->gated.release();
   ceed_unref(r->ceed);
   delete r;
   return 0;
@@ -733,7 +781,8 @@ static void op_free_flags(CeedOperator o) {
   if (o->d_node_flags) (void)hipFree(o->d_node_flags);
   if (o->d_node_flags_ovl) (void)hipFree(o->d_node_flags_ovl);
   if (o->d_node_flags_shell) (void)hipFree(o->d_node_flags_shell);
-  o->d_node_flags = o->d_node_flags_ovl = o->d_node_flags_shell = nullptr;
+  if (o->d_node_flags_gated) (void)hipFree(o->d_node_flags_gated);
+  o->d_node_flags = o->d_node_flags_ovl = o->d_node_flags_shell = o->d_node_flags_gated = nullptr;
   o->h_mask.clear();
   o->mask_mode = 0;
 }
@@ -768,6 +817,9 @@ extern "C" int CeedOperatorDestroy(CeedOperator *op) {
 // stores them itself (FusedGradArgs::direct); the caller has checked rstr_interior_private().
 static int build_csr(CeedElemRestriction r, CsrMap &M, const unsigned char *prio, int skipP = 0) {
   if (M.built) return 0;
+  if (r->ceed->capturing)
+    return ceed_error("first apply of an operator during graph capture: its restriction's transpose map is built on the host; "
+                      "apply the operator once before recording");
   const size_t n = r->h_offsets.size();
   std::vector<uint32_t> cnt((size_t)r->lsize + 1, 0u);
   for (size_t i = 0; i < n; i++) cnt[(size_t)r->h_offsets[i]]++;
@@ -825,9 +877,91 @@ static bool rstr_interior_private(CeedElemRestriction r, int P) {
   r->interior_private = 1;
   return true;
 }
+// Re-order the transpose map `M` (shell or full) of restriction r for the gated assembly with groups of E elements.
+static int build_gated(CeedElemRestriction r, const CsrMap &M, int E, int skipP, GatedMap &G) {
+  if (G.built && G.E == E && G.skipP == skipP) return 0;
+  if (r->ceed->capturing)
+    return ceed_error("first apply of an operator during graph capture: its restriction's transpose map is built on the host; "
+                      "apply the operator once before recording");
+  G.release();
+  G.E = E; G.skipP = skipP; G.nskipped = M.nskipped; G.full_cover = M.full_cover;
+  const int per_elem = skipP > 0 ? element_shell_size(skipP) : r->elemsize;
+  G.evec_stride = ((3 * per_elem * 8 + 127) / 128) * 128 / 8;
+  if ((size_t)r->nelem * (size_t)G.evec_stride > 0xFFFFFFFFull) return ceed_error("E-vector of %d elements exceeds the 32-bit index of the gated transpose map", r->nelem);
+  const int ngroups = (r->nelem + E - 1) / E, chunk = (ngroups + 7) / 8;
+  G.bucket_shift = 5;   // 32 groups per bucket
+  const int BG = 1 << G.bucket_shift;
+  G.nb = std::max(1, (chunk + BG - 1) / BG);
+  // download-free: the host copies of rowptr / cols are rebuilt from the restriction (same counting sort as build_csr)
+  const int nn = M.nnodes;
+  std::vector<uint32_t> rowptr((size_t)nn + 1), cols;
+  {
+    HIPCHK(hipMemcpy(rowptr.data(), M.d_rowptr, sizeof(uint32_t) * ((size_t)nn + 1), hipMemcpyDeviceToHost));
+    cols.resize(rowptr[nn] ? rowptr[nn] : 1);
+    HIPCHK(hipMemcpy(cols.data(), M.d_cols, sizeof(uint32_t) * rowptr[nn], hipMemcpyDeviceToHost));
+  }
+  // key of a row: chunk * nb + bucket of its last contributor, or the cut key 8 * nb
+  const uint32_t cutkey = 8u * (uint32_t)G.nb;
+  std::vector<uint32_t> key((size_t)nn), cnt((size_t)cutkey + 2, 0u);
+  for (int i = 0; i < nn; i++) {
+    const uint32_t efirst = cols[rowptr[i]] / (uint32_t)per_elem, elast = cols[rowptr[i + 1] - 1] / (uint32_t)per_elem;   // element order
+    const uint32_t gf = efirst / (uint32_t)E, gl = elast / (uint32_t)E, cf = gf / (uint32_t)chunk, cl = gl / (uint32_t)chunk;
+    key[i] = cf == cl ? cl * (uint32_t)G.nb + ((gl - cl * (uint32_t)chunk) >> G.bucket_shift) : cutkey;
+    cnt[key[i] + 1]++;
+  }
+  for (size_t k = 0; k + 1 < cnt.size(); k++) cnt[k + 1] += cnt[k];   // cnt[k] = first new row of key k
+  std::vector<uint32_t> order((size_t)nn), cursor(cnt.begin(), cnt.end() - 1);
+  for (int i = 0; i < nn; i++) order[cursor[key[i]]++] = (uint32_t)i;    // stable: ascending node offset within a bucket
+  std::vector<uint32_t> rp2((size_t)nn + 1, 0u), cols2(cols.size()), no2((size_t)(nn ? nn : 1));
+  G.h_node_off.resize((size_t)nn);
+  for (int j = 0; j < nn; j++) {
+    const uint32_t i = order[j];
+    const uint32_t len = rowptr[i + 1] - rowptr[i];
+    for (uint32_t k = 0; k < len; k++) {   // position e * per_elem + rank  ->  double index in the line-padded E-vector
+      const uint32_t pos = cols[rowptr[i] + k];
+      cols2[rp2[j] + k] = (pos / (uint32_t)per_elem) * (uint32_t)G.evec_stride + (pos % (uint32_t)per_elem) * 3u;
+    }
+    rp2[j + 1] = rp2[j] + len;
+    no2[j] = G.h_node_off[j] = M.h_node_off[i];
+  }
+  G.nrows = nn; G.nrows_local = (int)cnt[cutkey];
+  // items: pieces of <= GATED_ITEM_ROWS rows of one bucket, per chunk in bucket order
+  std::vector<uint32_t> item_row, item_bucket, bgroups((size_t)cutkey, 0u), bitems((size_t)cutkey, 0u);
+  for (int c = 0; c < 8; c++) {
+    G.item_begin[c] = (int)item_bucket.size();
+    const int cg = std::max(0, std::min(ngroups, (c + 1) * chunk) - c * chunk);   // groups of this chunk
+    for (int b = 0; b < G.nb; b++) {
+      bgroups[(size_t)c * G.nb + b] = (uint32_t)std::max(0, std::min(BG, cg - b * BG));
+      const uint32_t k = (uint32_t)c * (uint32_t)G.nb + (uint32_t)b;
+      for (uint32_t r0 = cnt[k]; r0 < cnt[k + 1]; r0 += GATED_ITEM_ROWS) { item_row.push_back(r0); item_bucket.push_back((uint32_t)b); }
+      bitems[(size_t)c * G.nb + b] = (uint32_t)((int)item_bucket.size() - G.item_begin[c]);   // items waiting for bucket <= b
+    }
+  }
+  G.item_begin[8] = (int)item_bucket.size();
+  G.nitems = (int)item_bucket.size();
+  // an item ends where the next begins -- also across bucket and chunk boundaries, since rows are contiguous in key order
+  item_row.push_back((uint32_t)G.nrows_local);
+  if (item_bucket.empty()) item_bucket.push_back(0u);
+  auto up = [](uint32_t **dst, const std::vector<uint32_t> &v) -> int {
+    HIPCHK(hipMalloc((void **)dst, sizeof(uint32_t) * (v.size() ? v.size() : 1)));
+    if (!v.empty()) HIPCHK(hipMemcpy(*dst, v.data(), sizeof(uint32_t) * v.size(), hipMemcpyHostToDevice));
+    return 0;
+  };
+  CHK(up(&G.d_rowptr, rp2)); CHK(up(&G.d_cols, cols2)); CHK(up(&G.d_node_off, no2)); CHK(up(&G.d_item_row, item_row));
+  CHK(up(&G.d_item_bucket, item_bucket)); CHK(up(&G.d_bucket_groups, bgroups)); CHK(up(&G.d_bucket_items, bitems));
+  const size_t nctrl = (size_t)GatedCtrl::size(G.nb, G.nitems);
+  HIPCHK(hipMalloc((void **)&G.d_ctrl, sizeof(unsigned) * nctrl));
+  HIPCHK(hipMemset(G.d_ctrl, 0, sizeof(unsigned) * nctrl));
+  G.built = true;
+  return 0;
+}
 static int ceed_need_evec(Ceed c, size_t len) {
   if (c->evec_len >= len) return 0;
-  if (c->evec) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->evec)); c->evec = nullptr; c->evec_len = 0; }
+  if (c->evec) {
+    if (c->capturing || c->live_graphs > 0) c->evec_parked.push_back(c->evec);   // recorded nodes still point at it
+    else { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->evec)); }
+    c->evec = nullptr; c->evec_len = 0;
+  }
   HIPCHK(hipMalloc((void **)&c->evec, sizeof(double) * len));
   c->evec_len = len;
   return 0;
@@ -1104,8 +1238,9 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
       HIPCHK(hipMalloc((void **)flagsp, fl.size() ? fl.size() : 1));
       HIPCHK(hipMemcpy(*flagsp, fl.data(), fl.size(), hipMemcpyHostToDevice));
     }
-    CHK(ceed_need_evec(op->ceed, (size_t)r->nelem * r->ncomp * r->elemsize));
+    CHK(ceed_need_evec(op->ceed, (size_t)r->nelem * (((size_t)3 * r->elemsize * 8 + 127) / 128 * 16)));   // line-padded blocks at most
     a.evec = op->ceed->evec;
+    a.evec_stride = 3 * (direct ? element_shell_size(ai.basis->P1d) : r->elemsize);
     row0 = 0; nrows = M->nnodes;
     if (split) {
       if (phase == 0) { a.nelem = op->ovl_lead; nrows = M->nprio; }
@@ -1117,14 +1252,68 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
   }
   {
     TimerScope ts(op, s);
+    Ceed c = op->ceed;
+    // gated assembly: whole applies in overwrite mode through the pencil kernel
+    const bool gated = c->gated_assembly && use_evec && !add && !split && a.variant == 1;
+    GatedAsmArgs ga{};
+    if (gated) {
+      GatedMap &G = r->gated;
+      CHK(build_gated(r, *M, pencil_group_elems(ai.basis->Q1d), direct ? ai.basis->P1d : 0, G));
+      if (!op->d_node_flags_gated && !op->h_mask.empty()) {
+        std::vector<unsigned char> fl((size_t)G.nrows, 0);
+        for (int i = 0; i < G.nrows; i++)
+          for (int cc = 0; cc < r->ncomp && cc < 3; cc++)
+            if (op->h_mask[(size_t)G.h_node_off[i] + (size_t)cc * r->compstride]) fl[i] |= (unsigned char)(1u << cc);
+        HIPCHK(hipMalloc((void **)&op->d_node_flags_gated, fl.size() ? fl.size() : 1));
+        HIPCHK(hipMemcpy(op->d_node_flags_gated, fl.data(), fl.size(), hipMemcpyHostToDevice));
+      }
+      a.queue = G.d_ctrl + GatedCtrl::QUEUE; a.done = G.d_ctrl + GatedCtrl::DONE; a.nb = G.nb; a.bucket_shift = G.bucket_shift;
+      a.evec_stride = G.evec_stride;
+      if (getenv("CEED_MI355X_GATED_DEBUG") && (atoi(getenv("CEED_MI355X_GATED_DEBUG")) & 4)) a.done = nullptr;
+      if (getenv("CEED_MI355X_GATED_DEBUG") && (atoi(getenv("CEED_MI355X_GATED_DEBUG")) & 8)) a.queue = nullptr;
+      ga.rowptr = G.d_rowptr; ga.cols = G.d_cols; ga.node_off = G.d_node_off;
+      ga.flags = (op->mask_mode & 2) ? op->d_node_flags_gated : nullptr;
+      ga.evec = a.evec; ga.y = py; ga.ctrl = G.d_ctrl; ga.item_row = G.d_item_row; ga.item_bucket = G.d_item_bucket;
+      ga.bucket_groups = G.d_bucket_groups; ga.bucket_items = G.d_bucket_items;
+      for (int i = 0; i < 9; i++) ga.item_begin[i] = G.item_begin[i];
+      ga.nb = G.nb; ga.nitems = G.nitems; ga.nrows_local = G.nrows_local; ga.nrows = G.nrows;
+      ga.max_spins = c->gated_spins;
+      ga.dbg = getenv("CEED_MI355X_GATED_KDBG") ? atoi(getenv("CEED_MI355X_GATED_KDBG")) : 0;
+    } else if (c->dynamic_sched && a.variant == 1) {
+      if (!c->queue) HIPCHK(hipMalloc((void **)&c->queue, sizeof(unsigned) * 8 * QUEUE_STRIDE));
+      CHK(dev_zero(c, (double *)c->queue, 8 * QUEUE_STRIDE / 2));
+      a.queue = c->queue;
+    }
+    const bool side = (gated || c->asm_overlap) && use_evec;
+    if (side) {   // fork: the assembly runs on a second stream beside the fused kernel (also while a graph is recorded)
+      if (!c->side_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+      }
+      HIPCHK(hipEventRecord(c->ev_fork, s));
+      HIPCHK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+    }
     hipError_t e = launch_fused_grad(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, a, s, kname);
     if (e == hipErrorInvalidValue && !**kname)
       return ceed_error("no fused kernel instantiated for P=%d Q=%d QFunction %s", ai.basis->P1d, ai.basis->Q1d, qf->name.c_str());
     HIPCHK(e);
-    if (use_evec) {  // timed together with the fused kernel: the two launches ARE the operator apply
+    if (gated) {
+      // launched AFTER the fused kernel, which never waits for it: whatever the queues do, the fused kernel completes;
+      // the gated kernel's waits are bounded and the tail kernel finishes whatever it left
+      static const int dbg = getenv("CEED_MI355X_GATED_DEBUG") ? atoi(getenv("CEED_MI355X_GATED_DEBUG")) : 0;   // bring-up only
+      if (!(dbg & 1)) HIPCHK(launch_assemble_gated(ga, c->gated_waves, (dbg & 16) ? s : c->side_stream));   // 16: after the fused kernel (its own rate)
+      HIPCHK(hipEventRecord(c->ev_join, c->side_stream));
+      HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+      if (!(dbg & 2)) HIPCHK(launch_assemble_tail(ga, s));
+    } else if (use_evec) {  // timed together with the fused kernel: the launches ARE the operator apply
       const unsigned char *fl = (op->mask_mode & 2) ? (split ? op->d_node_flags_ovl : (direct ? op->d_node_flags_shell : op->d_node_flags)) : nullptr;
       HIPCHK(launch_assemble(M->d_rowptr + row0, M->d_cols, M->d_node_off + row0, fl ? fl + row0 : nullptr, a.evec, py,
-                             nrows, r->elemsize, add ? 1 : 0, s));
+                             nrows, r->elemsize, add ? 1 : 0, side ? c->side_stream : s));
+      if (side) {
+        HIPCHK(hipEventRecord(c->ev_join, c->side_stream));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+      }
     }
   }
   op->launches++;
@@ -1404,6 +1593,23 @@ extern "C" int CeedXOperatorApplyPhase(CeedOperator op, CeedVector in, CeedVecto
   const char *kname = "";
   CHK(apply_fused_grad(op, in, out, false, phase, &kname));
   op->kernel_name = kname;
+  return 0;
+}
+
+// Gated assembly of the operator's active restriction: out[0] = items of the transpose map, out[1] = rows in them,
+// out[2] = cut rows, out[3] = items the tail kernel had to sum (the gated kernel had not), out[4] = applies -- [3], [4]
+// since the last call.  Diagnostic only (placement and co-residency decide [3], never the result).
+extern "C" int CeedXOperatorGetGatedStats(CeedOperator op, long long out[5]) {
+  for (int i = 0; i < 5; i++) out[i] = 0;
+  if (op->composite || op->plan != PLAN_FUSED_GRAD) return 0;
+  GatedMap &G = op->in[op->i_active].rstr->gated;
+  if (!G.built) return 0;
+  unsigned st[4] = {0, 0, 0, 0};
+  HIPCHK(hipStreamSynchronize(op->ceed->stream));
+  unsigned *p = G.d_ctrl + GatedCtrl::stats(G.nb, G.nitems);
+  HIPCHK(hipMemcpy(st, p, sizeof st, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(p, 0, sizeof st));
+  out[0] = G.nitems; out[1] = G.nrows_local; out[2] = G.nrows - G.nrows_local; out[3] = st[0]; out[4] = st[1];
   return 0;
 }
 

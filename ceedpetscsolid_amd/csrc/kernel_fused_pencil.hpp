@@ -34,10 +34,7 @@ namespace cps {
 
 template <int P, int Q> struct PencilGeom {
   static constexpr int Q3 = Q * Q * Q, P3 = P * P * P;
-#ifndef CPS_PENCIL_E5
-#define CPS_PENCIL_E5 2
-#endif
-  static constexpr int E = Q <= 2 ? 8 : (Q <= 4 ? 4 : (Q == 5 ? CPS_PENCIL_E5 : 1));  // elements per wave
+  static constexpr int E = pencil_group_elems(Q);                            // elements per wave
   static constexpr int SJ = Q, SK = Q * Q, SC = Q3;                         // strides in doubles
   static constexpr int ARR = 3 * SC;                                        // one 3-component array
   static constexpr int PAD = Q == 5 ? 5 : 1;                                // tools/pencil_layout_search.py
@@ -257,14 +254,58 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
   constexpr bool geo = GEO;   // recompute the geometric factors per point instead of reading qdata (FusedGradArgs::geo set)
   const int lane = threadIdx.x;
 
-  // ---- work list of this wave (XCD-aware, as in the row kernel) ---------------------------------
+  // ---- work list of this wave -----------------------------------------------------------------------
+  // The groups are cut into 8 contiguous chunks, one per XCD (neighbouring elements share their nodes through one L2).
+  // Static schedule (a.queue == null): block b serves chunk b % 8 (blocks b and b + 8 share an XCD under the round-robin
+  // placement), group = chunk begin + wave rank + k * waves per chunk.  Dynamic schedule (a.queue): the wave reads the XCD
+  // it really runs on (HW_REG_XCC_ID) and takes that chunk's groups in order from a ticket counter (one returning
+  // atomic per group, issued a whole group ahead of its use); a wave whose chunk has run dry goes on with the
+  // following chunks (work stealing, tail balance), so every group is taken whatever the placement.
   const int ngroups = (a.nelem + E - 1) / E;
-  const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1;
-  const int xcd = blockIdx.x % nxcd, wrank = blockIdx.x / nxcd, wper = gridDim.x / nxcd;
-  const int chunk = (ngroups + nxcd - 1) / nxcd;
-  const int gbeg = xcd * chunk, gend = min(ngroups, gbeg + chunk);
-  int grp = gbeg + wrank;
-  if (grp >= gend) return;
+  const bool dyn = a.queue != nullptr;
+  const int nxcd = (dyn || gridDim.x % 8 == 0) ? 8 : 1;
+  const int wrank = blockIdx.x / nxcd, wper = gridDim.x / nxcd;
+  const int gend = dyn ? 0 : min(ngroups, (int)(blockIdx.x % nxcd + 1) * ((ngroups + nxcd - 1) / nxcd));   // static schedule only
+  // dynamic schedule: all the wave keeps is  home XCD | chunk it takes from << 4 | chunks it has moved on << 8  (everything
+  // else is re-derived from the launch arguments where it is used: the scalar register file is full, see the table passes)
+  int xs = 0;
+  if (dyn) { xs = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); xs |= xs << 4; }   // hwreg(HW_REG_XCC_ID, 0, 4)
+  auto chunk_groups = [&]() { return (((kargs_fresh<true>()->nelem + E - 1) / E) + 7) >> 3; };   // groups per chunk (uniform)
+  // next group of this wave, or -1: ticket of the current chunk; on exhaustion move on to the next chunk (at most 8 tries)
+  auto take = [&]() -> int {
+    for (;;) {
+      const kargs_t ka = kargs_fresh<true>();
+      const int ng = (ka->nelem + E - 1) / E, ch = (ng + 7) >> 3, x = (xs >> 4) & 7;
+      unsigned t = 0;
+      if (lane == 0) t = atomicAdd(ka->queue + x * QUEUE_STRIDE, 1u);
+      const int g = x * ch + (int)__builtin_amdgcn_readfirstlane(t);
+      if (g < min(ng, (x + 1) * ch)) return g;
+      const int st = (xs >> 8) + 1;
+      if (st >= 8) return -1;
+      xs = (xs & 15) | (((x + 1) & 7) << 4) | (st << 8);
+    }
+  };
+  // Completion signal of the gated assembly (FusedGradArgs::done): one add to the counter of group g's bucket -- in its
+  // upper half if the group was taken from another XCD's chunk -- once the group's stores have been acknowledged
+  // (s_waitcnt vmcnt(0): L1 is write-through, the acknowledgement comes from the XCD's L2).  Issued for the PREVIOUS group
+  // just before the physics of the current one, where every older memory operation has landed anyway (the physics needs
+  // the prefetched state), so the wait costs nothing; once more after the loop.
+  auto signal_done = [&](int g) {
+    const kargs_t ka = kargs_fresh<true>();
+    unsigned *dn = ka->done;
+    if (dn && g >= 0) {
+      const int ch = chunk_groups();
+      int c = 0;
+#pragma unroll
+      for (int i = 1; i < 8; i++) c += (g >= i * ch) ? 1 : 0;
+      const int sig = c * ka->nb + ((g - c * ch) >> ka->bucket_shift);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) atomicAdd(dn + sig, c == (xs & 15) ? 1u : GatedCtrl::FOREIGN);
+    }
+  };
+  int grp, g_q1 = -1, g_prev = -1;   // current group; dynamic: the group after it (taken one group ahead), the one before it
+  if (dyn) { grp = take(); if (grp < 0) return; g_q1 = take(); }
+  else { grp = (int)(blockIdx.x % nxcd) * ((ngroups + nxcd - 1) / nxcd) + wrank; if (grp >= gend) return; }
 
   // ---- loop-invariant lane -> work maps -----------------------------------------------------
   // pencil passes: task t = lane + 64 r over (element, component, b, a), a fastest; address of the
@@ -311,15 +352,15 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
   }
   uint32_t nd_interior = 0;  // bit r: this lane's node of round r is interior to its element (direct store to y)
   uint32_t ev_idx[(RN + 1) / 2] = {};  // E-vector entry (in doubles) of this lane's node within the group's block, 16 bits each
-  static_assert(E * P3 * 3 < 65536, "16-bit E-vector entry index");
+  static_assert(E * (P3 * 3 + 15) < 65536, "16-bit E-vector entry index");
 #pragma unroll
   for (int r = 0; r < RN; r++) {
     const int t = lane + 64 * r, el = t / P3, n = t % P3;
     aNd[r] = lds0 + (el * SE + (n / (P * P)) * SK + ((n / P) % P) * SJ + n % P);
     if (a.direct && node_is_element_interior(n, P)) nd_interior |= 1u << r;
-    ev_idx[r / 2] |= (a.direct ? (uint32_t)((el * element_shell_size(P) + node_shell_rank(n, P)) * 3) : (uint32_t)(min(t, E * P3 - 1) * 3)) << (16 * (r % 2));
+    // [element][shell rank or node][3], the element blocks a.evec_stride doubles apart (whole cache lines for the gated assembly)
+    ev_idx[r / 2] |= (uint32_t)(min(el, E - 1) * a.evec_stride + (a.direct ? node_shell_rank(n, P) : n) * 3) << (16 * (r % 2));
   }
-  const int ev_per_elem = 3 * (a.direct ? element_shell_size(P) : P3);
   // element-in-group of owner slot t, recomputed where needed (a few compares) instead of held in
   // registers through the physics
   auto el_of = [&](int t, int n3) {
@@ -388,9 +429,10 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
   for (int t = 0; t < NSET; t++) load_point(qd[t], st[t], grp, t);
 
   for (;;) {
-    const int grp_nx = grp + wper;
-    const bool more = grp_nx < gend;  // wave-uniform
+    const int grp_nx = dyn ? g_q1 : grp + wper;
+    const bool more = dyn ? grp_nx >= 0 : grp_nx < gend;  // wave-uniform
     const int g_nx = more ? grp_nx : grp;
+    if (dyn && more) g_q1 = take();   // the group after the next: its ticket returns under this group's work
     load_offsets(g_nx, off_nx);
     constexpr int RG = (E * GEO_NCOEF + 63) / 64;
     double gcoef[RG];    // this group's element-map coefficients, lane + 64 i; into LDS right before the physics
@@ -475,6 +517,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
         if (lane + 64 * i < E * GEO_NCOEF)
           *(ldsp_t)((volatile __attribute__((address_space(3))) char *)lds0 + oGC + (lane + 64 * i) * 8) = gcoef[i];
     }
+    if (dyn) { signal_done(g_prev); g_prev = -1; }
     // ---- physics: point owners, one round at a time; ug[d*3+c] from (BX, A, BZ), dv back in place ----
 #pragma unroll
     for (int r = 0; r < RQ; r++) {
@@ -647,7 +690,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
             yb[base] = (fl & 1u) ? 0. : v[r][0]; (yb + 1)[base] = (fl & 2u) ? 0. : v[r][1]; (yb + 2)[base] = (fl & 4u) ? 0. : v[r][2];
           }
           if (ka->evec && !interior) {
-            double *eb = ka->evec + (size_t)(ka->elem_begin + grp * E) * ev_per_elem;
+            double *eb = ka->evec + (size_t)(ka->elem_begin + grp * E) * ka->evec_stride;
             const uint32_t ve = (r % 2) ? (ev_idx[r / 2] >> 16) : (ev_idx[r / 2] & 0xFFFFu);
 #ifndef CPS_ABLATE_STORE
             eb[ve] = v[r][0]; (eb + 1)[ve] = v[r][1]; (eb + 2)[ve] = v[r][2];
@@ -664,11 +707,13 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
         }
       }
     }
+    g_prev = grp;
     if (!more) break;
     grp = grp_nx;
 #pragma unroll
     for (int r = 0; r < RN; r++) off[r] = off_nx[r];
   }
+  if (dyn) signal_done(g_prev);
 }
 
 template <int P, int Q> constexpr int pencil_waves_per_cu() {

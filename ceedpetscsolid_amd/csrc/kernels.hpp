@@ -26,6 +26,7 @@ enum QFKind : int {
 };
 
 constexpr int MAXN1D = 8;  // largest P or Q supported by the kernel tables
+constexpr int QUEUE_STRIDE = 32;  // uints between the per-XCD ticket counters of the dynamic schedule (one 128-B line each)
 constexpr int EO_TAB = 36;  // doubles per even-odd table (see FusedGradArgs::eo)
 
 // 1-D tables handed to kernels by value: they live in the kernarg segment; the pencil kernel reads them from
@@ -57,6 +58,8 @@ struct FusedGradArgs {
   unsigned long long *stamps;  // diagnostic builds only (-DCPS_STAMPS): 8 s_memtime stamps per wave
   double *evec;                // if set: element results go here ([elem][P^3][3], plain coalesced stores)
                                // and launch_assemble() sums them into y; else f64 atomics straight into y
+  int evec_stride;            // doubles between the E-vector blocks of consecutive elements: 3 * nodes per block, or that
+                               // rounded up to whole 128-byte lines (gated assembly: a line then belongs to ONE element)
   int variant;                // host-side dispatch only: 0 = row kernel (kernel_fused_grad.hpp),
                                // 1 = pencil kernel (kernel_fused_pencil.hpp)
   const double *geo;          // pencil kernel: if set, [nelem][GEO_NCOEF] trilinear-map coefficients of the elements
@@ -70,6 +73,13 @@ struct FusedGradArgs {
   // middle column at 32 + r (r < (N+1)/2, j < K/2); built and checked by the host (eo_ok).
   double eo[6][EO_TAB];
   int eo_ok;
+  unsigned *queue;            // pencil kernel: if set, per-XCD ticket counters (8 x QUEUE_STRIDE, zero at launch) -> groups are
+                               // taken dynamically by the XCD a wave really runs on (see the kernel's work list)
+  unsigned *done;             // with queue: completion counters for the gated assembly (GatedCtrl layout): a wave that has
+                               // finished a group -- its E-vector stores acknowledged by L2 -- adds 1 to the counter of the
+                               // group's bucket, done[chunk * nb + ((group - chunk begin) >> bucket_shift)]; a group taken from
+                               // another XCD's chunk adds GatedCtrl::FOREIGN instead (its stores sit in another L2)
+  int nb, bucket_shift;       // buckets per chunk, log2(groups per bucket)
   int direct;                 // pencil kernel + evec: results at ELEMENT-INTERIOR nodes (0 < i,j,k < P-1; one contributor,
                                // verified on the host) are stored straight into y and skip the E-vector round trip; the
                                // E-vector then is [elem][shell node][3] and the transpose map handed to launch_assemble()
@@ -148,6 +158,52 @@ hipError_t launch_setup_geo(int Q, const BasisTables &t, const SetupGeoArgs &a, 
                             const char **name);
 hipError_t launch_diag(int P, int Q, int qf, const BasisTables &t, const DiagArgs &a, hipStream_t s,
                        const char **name);
+
+// ---- gated assembly (the restriction transpose under the fused kernel) ------------------------------------------------
+// The pencil kernel's element groups are cut into 8 chunks (one per XCD) and each chunk into buckets of 2^bucket_shift
+// groups.  The rows of the transpose map are re-ordered by (chunk, bucket of the row's LAST contributor); rows whose
+// contributors lie in two chunks are the CUT rows at the end.  k_assemble_gated runs BESIDE the fused kernel on a second
+// stream: its waves read the XCD they run on.  ONE wave per XCD (the gatekeeper: first ticket) watches the chunk's bucket
+// counters, advances the completion frontier and publishes the number of items that may be summed in the chunk's READY
+// word; the others take that chunk's items (<= GATED_ITEM_ROWS rows of one bucket) in order, wait until READY has passed
+// their item and sum its rows.  (Every waiting wave polling the counters itself -- words the fused kernel's atomics
+// hit -- more than doubled the fused kernel's time; READY is written by one wave and only read by the rest.)  Producer and consumer share one
+// L2, so the E-vector entries are read with L1-bypassing loads and no cache maintenance.  k_assemble_tail then sums,
+// after both, the cut rows and every item the gated kernel did not finish (buckets with groups stolen by another XCD,
+// waves that never became resident) and resets the control block.  Correctness never depends on co-residency or on
+// the placement of workgroups: only the speed does.
+constexpr int GATED_ITEM_ROWS = 256;
+struct GatedCtrl {   // uint32 offsets into the control block (zero before the first launch; the tail kernel re-zeroes it)
+  static constexpr int QUEUE = 0, AHEAD = 8 * QUEUE_STRIDE, READY = 16 * QUEUE_STRIDE, DONE = 24 * QUEUE_STRIDE;
+  static constexpr unsigned STOP = 0x80000000u;   // READY word: the gatekeeper has given up (foreign groups ahead, time-out)
+  static constexpr unsigned FOREIGN = 0x10000u;   // a group run by another XCD counts in the upper half of its bucket's counter
+  static constexpr int item_done(int nb) { return DONE + 8 * nb; }
+  static constexpr int stats(int nb, int nitems) { return DONE + 8 * nb + nitems; }   // [0] items the tail kernel had to sum, [1] applies
+  static constexpr int size(int nb, int nitems) { return DONE + 8 * nb + nitems + 4; }
+};
+struct GatedAsmArgs {
+  const uint32_t *rowptr, *cols, *node_off;  // re-ordered transpose map; cols = DOUBLE index of a contributor's first component in the E-vector
+  const unsigned char *flags;                // per re-ordered row, or null
+  const double *evec;
+  double *y;
+  unsigned *ctrl;                            // GatedCtrl
+  const uint32_t *item_row;                  // [nitems + 1] first row of every item (items of chunk c: item_begin[c] .. item_begin[c+1])
+  const uint32_t *item_bucket;               // [nitems] bucket (within its chunk) an item waits for
+  const uint32_t *bucket_groups;             // [8 * nb] groups in every bucket
+  const uint32_t *bucket_items;              // [8 * nb] items of the chunk that wait for this bucket or an earlier one
+  int item_begin[9];
+  int nb, nitems, nrows_local, nrows;        // rows [nrows_local, nrows) are the cut rows
+  int max_spins;                             // bound of the gated kernel's wait for one bucket (then the tail kernel takes over)
+  int dbg;                                   // bring-up switches (CEED_MI355X_GATED_KDBG): 1 L1-bypassing E-vector loads, 2 no frontier wait, 4 static items
+};
+hipError_t launch_assemble_gated(const GatedAsmArgs &a, int waves_per_cu, hipStream_t s);
+hipError_t launch_assemble_tail(const GatedAsmArgs &a, hipStream_t s);
+// elements per wave (= per group) of the pencil kernel, PencilGeom<P, Q>::E: 3 Q^2 pencils per element and pass against 64
+// lanes and the 9 Q^3-double LDS slab per element
+#ifndef CPS_PENCIL_E5
+#define CPS_PENCIL_E5 2
+#endif
+constexpr int pencil_group_elems(int Q) { return Q <= 2 ? 8 : (Q <= 4 ? 4 : (Q == 5 ? CPS_PENCIL_E5 : 1)); }
 
 // Deterministic, atomic-free E^T: y[node_off[r] + c] (+)= sum over the node's contributors, in element
 // order, of E[3 * cols[k] + c] (cols[k] = e * P3 + n).  `flags` (one byte per node, bit c = component c constrained) may be null.

@@ -366,6 +366,155 @@ __global__ void k_assemble(const uint32_t *rowptr, const uint32_t *cols, const u
     dst[0] = a0; dst[1] = a1; dst[2] = a2;
   }
 }
+// ---- gated assembly (kernels.hpp, GatedAsmArgs) -------------------------------------------------------------------------
+// A row of the re-ordered transpose map (columns = double index of the contributor in the E-vector).
+// The E-vector values were written during this launch by other CUs of the same XCD, whose stores this CU's L1 never sees.
+// Plain loads are sound all the same: an element's E-vector block is whole 128-byte lines (FusedGradArgs::evec_stride), every
+// line is written by ONE wave before that wave signals its group, and a row is read only after all its contributors'
+// groups have been seen complete -- so no line of a block can have entered this CU's L1 (empty at kernel start) before
+// its final bytes had reached the XCD's L2.  BYPASS (A/B only): L1-bypassing loads (global_load ... sc1), which the
+// measurements price at 1.5x the kernel's time (8-byte sc1 loads, each of a node's three fetched from L2 separately).
+template <bool BYPASS>
+CPS_DEV void assemble_row(const GatedAsmArgs &a, int r) {
+  const uint32_t k0 = a.rowptr[r], k1 = a.rowptr[r + 1];
+  double a0 = 0., a1 = 0., a2 = 0.;
+  for (uint32_t k = k0; k < k1; k += 4) {   // as k_assemble: four contributors per trip, summed in element order
+    uint32_t c[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) c[j] = a.cols[k + j < k1 ? k + j : k1 - 1];
+    double v[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const double *p = a.evec + c[j];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        if constexpr (BYPASS) v[j][d] = __hip_atomic_load(p + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else v[j][d] = p[d];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (k + j < k1) { a0 += v[j][0]; a1 += v[j][1]; a2 += v[j][2]; }
+  }
+  const unsigned fl = a.flags ? a.flags[r] : 0u;
+  double *dst = a.y + (a.node_off[r] & OFF_MASK);
+  dst[0] = (fl & 1u) ? 0. : a0; dst[1] = (fl & 2u) ? 0. : a1; dst[2] = (fl & 4u) ? 0. : a2;
+}
+// Persistent single-wave workgroups beside the fused kernel.  Every wait is bounded: a wave that gives up (or never runs)
+// leaves its items to k_assemble_tail.
+__global__ __launch_bounds__(64) void k_assemble_gated(const GatedAsmArgs a) {
+  const int lane = threadIdx.x;
+  const int xcd = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);   // hwreg(HW_REG_XCC_ID, 0, 4): the chunk this wave may read
+  unsigned *ahead = a.ctrl + GatedCtrl::AHEAD + xcd * QUEUE_STRIDE, *ready = a.ctrl + GatedCtrl::READY + xcd * QUEUE_STRIDE;
+  unsigned *item_done = a.ctrl + GatedCtrl::item_done(a.nb);
+  const int ibeg = a.item_begin[xcd], iend = a.item_begin[xcd + 1];
+  if (ibeg >= iend) return;
+  // The control flow is kept wave-uniform and every loop is bounded.
+  auto peek = [](const unsigned *p) { return (unsigned)__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
+  auto ticket = [&]() { unsigned t = 0; if (lane == 0) t = atomicAdd(ahead, 1u); return (int)__builtin_amdgcn_readfirstlane(t); };
+  int tk = ticket();
+  if (tk == 0) {
+    // ---- gatekeeper of this XCD's chunk: frontier f = buckets [0, f) complete, every group of them run by this XCD.  One
+    // probe looks at 64 buckets, one per lane (L1-bypassing loads), and moves the frontier by the run of complete ones.
+    const unsigned *done = a.ctrl + GatedCtrl::DONE + xcd * a.nb;
+    const uint32_t *bgroups = a.bucket_groups + xcd * a.nb, *bitems = a.bucket_items + xcd * a.nb;
+    unsigned f = 0, pub = 0;
+    for (int spins = 0; f < (unsigned)a.nb;) {
+      const unsigned fb = f + (unsigned)lane;
+      const bool in = fb < (unsigned)a.nb;
+      const unsigned d = in ? __hip_atomic_load(done + fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      const unsigned long long clean = __ballot(in && d == bgroups[in ? fb : 0u]), taint = __ballot(in && d >= GatedCtrl::FOREIGN);
+      const int run = clean == ~0ull ? 64 : __builtin_ctzll(~clean);   // complete buckets from f on
+      if (run > 0) {
+        f += (unsigned)run;
+        pub = (unsigned)__builtin_amdgcn_readfirstlane(bitems[f - 1]);
+        if (lane == 0) *(volatile unsigned *)ready = pub;   // plain store: it stays in this XCD's L2, where the readers look
+        spins = 0;
+        continue;
+      }
+      if ((taint & 1ull) || ++spins > a.max_spins) {   // groups of bucket f ran on another XCD, or nothing moves: the tail kernel's
+        if (lane == 0) *(volatile unsigned *)ready = pub | GatedCtrl::STOP;
+        return;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+    return;
+  }
+  for (int n = ibeg; n < iend; n++) {   // at most the chunk's items
+    const int it = ibeg + tk - 1;
+    if (it >= iend) break;
+    if (a.dbg & 4) tk += (int)gridDim.x / 8;   // bring-up: static striding (assumes an even spread of the waves over the XCDs)
+    else tk = ticket();   // the next item's ticket returns under this item's work (an item taken and then abandoned is the tail kernel's)
+    // wait until the gatekeeper has published this item (READY: written by one wave, read here past L1)
+    bool ok = true;
+    for (int spins = 0; !(a.dbg & 2);) {
+      const unsigned r = peek(ready);
+      if ((r & ~GatedCtrl::STOP) > (unsigned)(it - ibeg)) break;
+      if ((r & GatedCtrl::STOP) || ++spins > a.max_spins) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(64);                                       // ~1.7 us
+      if (a.dbg & 16) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+    }
+    if (!ok) break;   // this item and the chunk's later ones stay undone
+    if (a.dbg & 8) continue;   // bring-up: waiting only, the rows are left to the tail kernel
+    const int r0 = (int)a.item_row[it], r1 = (int)a.item_row[it + 1];
+    if (a.dbg & 1) { for (int r = r0 + lane; r < r1; r += 64) assemble_row<true>(a, r); }
+    else { for (int r = r0 + lane; r < r1; r += 64) assemble_row<false>(a, r); }
+    if (lane == 0) item_done[it] = 1u;
+  }
+}
+// After the fused and the gated kernel: block j < ceil(nitems / TAIL_ITEMS) looks at TAIL_ITEMS items and sums those the gated
+// kernel did not; the blocks behind sum the cut rows; the control block is zeroed for the next apply.
+constexpr int TAIL_ITEMS = 1;   // (16 per block made the tail 3x slower: the undone items sit together at the end of a chunk and were then summed one after the other)
+__global__ __launch_bounds__(GATED_ITEM_ROWS) void k_assemble_tail(const GatedAsmArgs a) {
+  unsigned *item_done = a.ctrl + GatedCtrl::item_done(a.nb);
+  const int j = blockIdx.x, nib = (a.nitems + TAIL_ITEMS - 1) / TAIL_ITEMS;
+  if (j == 0) {
+    for (int i = threadIdx.x; i < GatedCtrl::item_done(a.nb); i += blockDim.x) a.ctrl[i] = 0u;
+    if (threadIdx.x == 0) atomicAdd(a.ctrl + GatedCtrl::stats(a.nb, a.nitems) + 1, 1u);
+  }
+  if (j < nib) {
+    const int i0 = j * TAIL_ITEMS;
+    unsigned undone = 0;   // bit k: item i0 + k was left by the gated kernel (uniform over the block)
+#pragma unroll
+    for (int k = 0; k < TAIL_ITEMS; k++)
+      if (i0 + k < a.nitems && item_done[i0 + k] == 0u) undone |= 1u << k;
+    __syncthreads();
+    if ((int)threadIdx.x < TAIL_ITEMS && i0 + (int)threadIdx.x < a.nitems) item_done[i0 + threadIdx.x] = 0u;
+    while (undone) {
+      const int k = __builtin_ctz(undone);
+      undone &= undone - 1u;
+      const int r = (int)a.item_row[i0 + k] + threadIdx.x;
+      if (r < (int)a.item_row[i0 + k + 1]) assemble_row<false>(a, r);
+      if (threadIdx.x == 0) atomicAdd(a.ctrl + GatedCtrl::stats(a.nb, a.nitems), 1u);
+    }
+  } else {
+    const int r = a.nrows_local + (j - nib) * GATED_ITEM_ROWS + threadIdx.x;
+    if (r < a.nrows) assemble_row<false>(a, r);
+  }
+}
+hipError_t launch_assemble_gated(const GatedAsmArgs &a, int waves_per_cu, hipStream_t s) {
+  if (a.nitems <= 0) return hipSuccess;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    ncu = prop.multiProcessorCount;
+  }
+  int grid = ncu * (waves_per_cu > 0 ? waves_per_cu : 4);
+  if (grid > a.nitems + 8) grid = a.nitems + 8;   // one gatekeeper per XCD on top of the workers
+  if (grid < 8) grid = 8;   // one wave per XCD at least (placement permitting; the tail kernel covers the rest)
+  hipLaunchKernelGGL(k_assemble_gated, dim3(grid), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_assemble_tail(const GatedAsmArgs &a, hipStream_t s) {
+  const int ncut = a.nrows - a.nrows_local;
+  int grid = (a.nitems + TAIL_ITEMS - 1) / TAIL_ITEMS + (ncut + GATED_ITEM_ROWS - 1) / GATED_ITEM_ROWS;
+  if (grid < 1) grid = 1;   // block 0 zeroes the control block (the fused kernel's ticket counters live there)
+  hipLaunchKernelGGL(k_assemble_tail, dim3(grid), dim3(GATED_ITEM_ROWS), 0, s, a);
+  return hipGetLastError();
+}
+
 __global__ void k_dot(const double *x, const double *y, const double *w, size_t n, double *result) {
   double s = 0.;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)

@@ -483,7 +483,8 @@ class NewtonPMG:
                 st.history.append((inc, it + 1, k, lam, rnorm))
                 if self.verbose:
                     print(f"   newton {it + 1:2d}: ksp its {k:3d}  lambda {lam:.4f}  |R| = {rnorm:.6e}")
-            else:
+            # decided on the residual itself: a step that meets the tolerance in the LAST allowed iteration has converged
+            if not (rnorm <= self.snes_rtol * rnorm0 or rnorm < 1e-50):
                 st.converged = False
             st.increments = inc
             if not np.isfinite(rnorm) or not st.converged:

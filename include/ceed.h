@@ -310,5 +310,10 @@ CEED_EXTERN int CeedXCsrDestroy(CeedXCsr *csr);
 CEED_EXTERN int CeedXOperatorSetTiming(CeedOperator op, int enable);
 CEED_EXTERN int CeedXOperatorGetTiming(CeedOperator op, double *ms,
                                        int64_t *launches);
+/* Diagnostic: the gated assembly of a residual / Jacobian operator (the      */
+/* restriction transpose run beside the fused kernel).  out[0] items of the    */
+/* transpose map, out[1] rows in them, out[2] cut rows, out[3] items summed by */
+/* the tail kernel since the last call, out[4] applies since the last call.    */
+CEED_EXTERN int CeedXOperatorGetGatedStats(CeedOperator op, long long out[5]);
 
 #endif /* CEED_MI355X_CEED_H */

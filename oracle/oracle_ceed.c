@@ -1111,6 +1111,7 @@ int CeedXVectorDot(CeedVector x, CeedVector y, CeedVector weight, double *result
 }
 int CeedXOperatorSetTiming(CeedOperator op, int enable) { (void)op; (void)enable; return 0; }
 int CeedXOperatorGetTiming(CeedOperator op, double *ms, int64_t *launches) { (void)op; *ms = 0; *launches = 0; return 0; }
+int CeedXOperatorGetGatedStats(CeedOperator op, long long out[5]) { (void)op; for (int i = 0; i < 5; i++) out[i] = 0; return 0; }
 
 /* ---- assembled sparse operator (include/ceed.h, CeedXCsr*): plain CSR on the host ------------ */
 struct CeedXCsr_private {

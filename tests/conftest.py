@@ -20,6 +20,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Build the checker now, before any fixture can initialise the GPU: a process that has made a HIP call must not
+    # start child processes on the GPU pool (the `gpu` fixture may be instantiated before `oracle_lib`).
+    _ensure_oracle()
 
 
 def _ensure_oracle():

@@ -319,6 +319,82 @@ def test_apply_is_bitwise_reproducible(gpu):
     assert np.array_equal(Y.to_numpy(), r0)
 
 
+@pytest.mark.parametrize("mk,degree,problem", [
+    (lambda: hollow_cylinder_mesh(4, 24, 16), 4, "hyperFS"),    # 1 536 elements: 96 groups per XCD chunk, three buckets each
+    (lambda: hollow_cylinder_mesh(10, 40, 20), 4, "hyperFS"),   # 8 000 elements
+    (lambda: distorted_box(12, 12, 12), 2, "hyperSS"),          # Q = 3: four elements per group
+    (lambda: distorted_box(9, 7, 5), 1, "linElas"),             # Q = 2: eight elements per group, ragged last group
+    (lambda: distorted_box(7, 6, 6), 6, "hyperFS"),             # Q = 7: one element per group
+], ids=["cyl1536 p4", "cyl8000 p4", "box p2", "box p1", "box p6"])
+def test_gated_assembly_equals_serial_assembly_bitwise(product_lib, mk, degree, problem):
+    """The restriction transpose beside the fused kernel (k_assemble_gated + k_assemble_tail, default) against the same
+    sums formed after it (CEED_MI355X_ASSEMBLE=serial): same E-vector values, same element order, so the results are
+    BITWISE equal.  The inputs alternate between applies, so an E-vector entry read before its producer's store had
+    reached the XCD's L2 (or from a stale L1 line) would show as the previous apply's value."""
+    mesh = mk()
+    gated = cd.Ceed(product_lib, "/gpu/hip/mi355x")
+    serial = _ceed_with_env(product_lib, "CEED_MI355X_ASSEMBLE", "serial")
+    probs = [SolidProblem(c, mesh, degree, problem, nu=0.3, E=1.0, bc_sides=[sorted(mesh.side_sets)[0]], multigrid="none") for c in (gated, serial)]
+    n = probs[0].lsize()
+    rng = np.random.default_rng(11)
+    vecs = [(c.vector(n), c.vector(n)) for c in (gated, serial)]
+    u0 = probs[0].smooth_state(0.1)
+    for (X, Y), p in zip(vecs, probs):
+        X.set_array(u0); p.form_residual(X, Y)
+    assert np.array_equal(vecs[0][1].to_numpy(), vecs[1][1].to_numpy())
+    for it in range(12):
+        x = rng.uniform(-1, 1, n) * (10.0 ** rng.integers(-3, 4))
+        outs = []
+        for (X, Y), p in zip(vecs, probs):
+            X.set_array(x)
+            p.apply_jacobian(p.fine, X, Y)
+            if it % 3 == 2:   # back-to-back applies without a host round trip in between
+                p.apply_jacobian(p.fine, X, Y); p.apply_jacobian(p.fine, X, Y)
+            outs.append(Y.to_numpy())
+        assert np.array_equal(outs[0], outs[1]), f"apply {it}"
+    assert probs[0].levels[probs[0].fine].opJacob.kernel_name == probs[1].levels[probs[1].fine].opJacob.kernel_name
+
+
+def test_recorded_graph_survives_growth_of_the_scratch(product_lib):
+    """A recorded graph has the E-vector scratch pointer of its capture time in its kernel nodes.  Applying a LARGER
+    operator on the same Ceed afterwards (a second problem, a finer level) grows the scratch: the old buffer must stay
+    alive for the graph's replays (ceed_need_evec parks it), and growth DURING a capture must not break the capture."""
+    ceed = cd.Ceed(product_lib, "/gpu/hip/mi355x")      # a Ceed of its own: its scratch starts empty
+    small = SolidProblem(ceed, distorted_box(2, 2, 2), 2, "hyperFS", nu=0.3, E=1.0, bc_sides=[1], multigrid="none")
+    n = small.lsize()
+    X, Y, Yg = ceed.vector(n), ceed.vector(n), ceed.vector(n)
+    X.set_array(small.smooth_state(0.1)); small.form_residual(X, Y)
+    X.set_array(np.random.default_rng(5).uniform(-1, 1, n))
+    small.apply_jacobian(small.fine, X, Y)
+    eager = Y.to_numpy()
+    g = ceed.capture(lambda: small.apply_jacobian(small.fine, X, Yg))
+    big = SolidProblem(ceed, distorted_box(4, 4, 3), 4, "hyperFS", nu=0.3, E=1.0, bc_sides=[1], multigrid="none")
+    nb = big.lsize()
+    Xb, Yb, Yb2 = ceed.vector(nb), ceed.vector(nb), ceed.vector(nb)
+    Xb.set_array(big.smooth_state(0.1)); big.form_residual(Xb, Yb)      # first apply of the larger restriction: the scratch grows
+    Xb.set_array(np.random.default_rng(6).uniform(-1, 1, nb))
+    big.apply_jacobian(big.fine, Xb, Yb)
+    for _ in range(2):
+        Yg.set_value(-3.0)
+        g.launch()
+        assert np.array_equal(Yg.to_numpy(), eager)
+    # a COLD operator cannot be recorded (its transpose map is built on the host at the first apply): a clear error, and
+    # the Ceed, the older graph and the parked scratch stay usable
+    cold = SolidProblem(ceed, distorted_box(5, 4, 4), 4, "hyperFS", nu=0.3, E=1.0, bc_sides=[1], multigrid="none")
+    nh = cold.lsize()
+    Xh, Yh = ceed.vector(nh), ceed.vector(nh)
+    Xh.set_array(cold.smooth_state(0.1)); Xh.device_pointer(); Yh.set_value(0.0)
+    with pytest.raises(cd.CeedError, match="once before recording"):
+        ceed.capture(lambda: cold.form_residual(Xh, Yh))
+    cold.form_residual(Xh, Yh)                                          # eagerly: the scratch grows again
+    g2 = ceed.capture(lambda: big.apply_jacobian(big.fine, Xb, Yb2))    # a second, larger recording beside the first
+    Yb2.set_value(-1.0); Yg.set_value(-1.0)
+    g2.launch(); g.launch()
+    assert np.array_equal(Yb2.to_numpy(), Yb.to_numpy())
+    assert np.array_equal(Yg.to_numpy(), eager)
+    g.destroy(); g2.destroy()
+
+
 def test_apply_add_and_empty_vectors(gpu):
     """CeedOperatorApplyAdd accumulates (y += J x); zero-length vectors are legal objects."""
     import ctypes as C

@@ -39,6 +39,25 @@ def test_solver_converges_on_oracle(oracle, problem, incs):
         assert st.newton_its == 1                                   # linear problem: one Newton step
 
 
+def test_convergence_in_the_last_allowed_newton_iteration(oracle):
+    """A step that meets snes_rtol in iteration snes_maxit has converged (the tolerance test sits at the top of the
+    loop, so the flag is decided on the residual afterwards); one iteration fewer has not."""
+    mesh = hollow_cylinder_mesh(1, 6, 2, z0=-1.0, z1=1.0)
+    p = SolidProblem(oracle, mesh, 2, "hyperFS", nu=0.3, E=10.0, bc_sides=[998, 999])
+    ref = NewtonPMG(p, clamp=CLAMP)
+    st = ref.solve(2)
+    per_inc = [sum(1 for h in st.history if h[0] == inc) for inc in (1, 2)]
+    need = max(per_inc)
+    assert st.converged and need >= 2
+    s = NewtonPMG(p, clamp=CLAMP, snes_maxit=need)
+    st2 = s.solve(2)
+    assert st2.converged and st2.increments == 2 and st2.newton_its == st.newton_its
+    assert np.array_equal(s.U.to_numpy(), ref.U.to_numpy())
+    s = NewtonPMG(p, clamp=CLAMP, snes_maxit=need - 1)
+    st3 = s.solve(2)
+    assert not st3.converged
+
+
 @pytest.mark.gpu
 def test_device_solve_matches_oracle_solve(oracle, gpu):
     mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_672e_4ss_us.npz"))
