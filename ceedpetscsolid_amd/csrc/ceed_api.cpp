@@ -77,9 +77,13 @@ struct Ceed_private {
   bool even_odd = true;         // pencil kernel applies the 1-D tables in even-odd form (CEED_MI355X_EO=0: plain products)
   bool direct_interior = true;  // pencil kernel: element-interior nodes go straight to y (CEED_MI355X_DIRECT=0: all via the E-vector)
   unsigned *queue = nullptr;    // per-XCD ticket counters of the pencil kernel's dynamic schedule (8 x QUEUE_STRIDE)
-  bool dynamic_sched = false;   // CEED_MI355X_SCHED=dynamic: dynamic group schedule also where the assembly is not gated (A/B)
+  bool dynamic_sched = true;    // pencil kernel: groups taken dynamically per XCD (default; CEED_MI355X_SCHED=static: round-1 striding)
   int asm_overlap = 0;          // EXPERIMENT CEED_MI355X_ASM_OVERLAP=1: k_assemble on a second stream beside the fused kernel (ungated: timing only)
-  bool gated_assembly = true;   // restriction transpose beside the fused kernel (k_assemble_gated + k_assemble_tail); CEED_MI355X_ASSEMBLE=serial: k_assemble after it
+  // Restriction transpose of the fused residual / Jacobian apply (CEED_MI355X_ASSEMBLE): "serial" (default) = k_assemble after
+  // the fused kernel; "gated" = k_assemble_gated beside the fused kernel on a second stream + k_assemble_tail; "folded" =
+  // summed by the pencil kernel's own waves, one item per element group, + k_assemble_tail.  Measured in DESIGN.md 8.
+  bool gated_assembly = false;   // folded or gated
+  bool folded_assembly = false;
   int gated_waves = 4;          // persistent assembler waves per CU (CEED_MI355X_ASM_WAVES)
   int gated_spins = 1 << 19;    // the gated kernel's bounded wait for one bucket, in ~2 us polls (CEED_MI355X_ASM_SPINS)
   hipStream_t side_stream = nullptr;
@@ -268,11 +272,12 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   const char *di = getenv("CEED_MI355X_DIRECT");
   c->direct_interior = c->fused_variant == 1 && !c->atomic_scatter && !(di && !strcmp(di, "0"));
   const char *sd = getenv("CEED_MI355X_SCHED");
-  c->dynamic_sched = c->fused_variant == 1 && sd && !strcmp(sd, "dynamic");
+  c->dynamic_sched = c->fused_variant == 1 && !(sd && !strcmp(sd, "static"));
   const char *ao = getenv("CEED_MI355X_ASM_OVERLAP");
   c->asm_overlap = ao ? atoi(ao) : 0;
   const char *ga = getenv("CEED_MI355X_ASSEMBLE");
-  c->gated_assembly = c->fused_variant == 1 && !c->atomic_scatter && !(ga && !strcmp(ga, "serial"));
+  c->gated_assembly = c->fused_variant == 1 && !c->atomic_scatter && ga && (!strcmp(ga, "gated") || !strcmp(ga, "folded"));
+  c->folded_assembly = c->gated_assembly && !strcmp(ga, "folded");
   const char *gw = getenv("CEED_MI355X_ASM_WAVES");
   if (gw && atoi(gw) > 0) c->gated_waves = atoi(gw);
   const char *gs = getenv("CEED_MI355X_ASM_SPINS");
@@ -907,6 +912,7 @@ static int build_gated(CeedElemRestriction r, const CsrMap &M, int E, int skipP,
     const uint32_t efirst = cols[rowptr[i]] / (uint32_t)per_elem, elast = cols[rowptr[i + 1] - 1] / (uint32_t)per_elem;   // element order
     const uint32_t gf = efirst / (uint32_t)E, gl = elast / (uint32_t)E, cf = gf / (uint32_t)chunk, cl = gl / (uint32_t)chunk;
     key[i] = cf == cl ? cl * (uint32_t)G.nb + ((gl - cl * (uint32_t)chunk) >> G.bucket_shift) : cutkey;
+    if (rowptr[i + 1] - rowptr[i] > 4u) key[i] = cutkey;   // more than four contributors (vertices, irregular nodes): summed by the tail kernel
     cnt[key[i] + 1]++;
   }
   for (size_t k = 0; k + 1 < cnt.size(); k++) cnt[k + 1] += cnt[k];   // cnt[k] = first new row of key k
@@ -1254,11 +1260,16 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
     TimerScope ts(op, s);
     Ceed c = op->ceed;
     // gated assembly: whole applies in overwrite mode through the pencil kernel
-    const bool gated = c->gated_assembly && use_evec && !add && !split && a.variant == 1;
+    // folded assembly is compiled into the pencil kernel up to Q = 5; beyond, the serial assembly unless "gated" was asked for
+    const bool gated = c->gated_assembly && use_evec && !add && !split && a.variant == 1 && (!c->folded_assembly || ai.basis->Q1d <= 5);
     GatedAsmArgs ga{};
     if (gated) {
       GatedMap &G = r->gated;
       CHK(build_gated(r, *M, pencil_group_elems(ai.basis->Q1d), direct ? ai.basis->P1d : 0, G));
+      if (!op->d_node_flags_gated && op->h_mask.empty()) {   // no Dirichlet mask: all-zero flags (the folded stages read them unconditionally)
+        HIPCHK(hipMalloc((void **)&op->d_node_flags_gated, (size_t)(G.nrows ? G.nrows : 1)));
+        HIPCHK(hipMemset(op->d_node_flags_gated, 0, (size_t)(G.nrows ? G.nrows : 1)));
+      }
       if (!op->d_node_flags_gated && !op->h_mask.empty()) {
         std::vector<unsigned char> fl((size_t)G.nrows, 0);
         for (int i = 0; i < G.nrows; i++)
@@ -1278,13 +1289,25 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
       for (int i = 0; i < 9; i++) ga.item_begin[i] = G.item_begin[i];
       ga.nb = G.nb; ga.nitems = G.nitems; ga.nrows_local = G.nrows_local; ga.nrows = G.nrows;
       ga.max_spins = c->gated_spins;
+      if (c->folded_assembly) {
+        a.as_rowptr = G.d_rowptr; a.as_cols = G.d_cols; a.as_node_off = G.d_node_off; a.as_item_row = G.d_item_row;
+        a.as_bucket_items = G.d_bucket_items; a.as_flags = op->d_node_flags_gated; a.as_max_spins = c->gated_spins;
+        for (int i = 0; i < 9; i++) a.as_item_begin[i] = G.item_begin[i];
+        a.as_dbg = getenv("CEED_MI355X_FOLD_DBG") ? atoi(getenv("CEED_MI355X_FOLD_DBG")) : 0;
+      }
       ga.dbg = getenv("CEED_MI355X_GATED_KDBG") ? atoi(getenv("CEED_MI355X_GATED_KDBG")) : 0;
-    } else if (c->dynamic_sched && a.variant == 1) {
-      if (!c->queue) HIPCHK(hipMalloc((void **)&c->queue, sizeof(unsigned) * 8 * QUEUE_STRIDE));
-      CHK(dev_zero(c, (double *)c->queue, 8 * QUEUE_STRIDE / 2));
+    } else if (c->dynamic_sched && a.variant == 1 && use_evec) {   // tickets zeroed at allocation and by every k_assemble behind the fused kernel
+      if (!c->queue) {
+        HIPCHK(hipMalloc((void **)&c->queue, sizeof(unsigned) * 8 * QUEUE_STRIDE));
+        HIPCHK(hipMemset(c->queue, 0, sizeof(unsigned) * 8 * QUEUE_STRIDE));
+      }
       a.queue = c->queue;
+      static const int qd = getenv("CEED_MI355X_DBG") ? atoi(getenv("CEED_MI355X_DBG")) : 0;   // bring-up
+      if (qd & 1) { static unsigned *dummy = nullptr; if (!dummy) { HIPCHK(hipMalloc((void **)&dummy, 4096)); HIPCHK(hipMemset(dummy, 0, 4096)); } a.done = dummy; a.nb = 1; a.bucket_shift = 30; }
+      if (qd & 2) CHK(dev_zero(c, (double *)c->queue, 8 * QUEUE_STRIDE / 2));
     }
-    const bool side = (gated || c->asm_overlap) && use_evec;
+    const bool folded = gated && c->folded_assembly;
+    const bool side = ((gated && !folded) || c->asm_overlap) && use_evec;
     if (side) {   // fork: the assembly runs on a second stream beside the fused kernel (also while a graph is recorded)
       if (!c->side_stream) {
         HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
@@ -1294,22 +1317,27 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
       HIPCHK(hipEventRecord(c->ev_fork, s));
       HIPCHK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
     }
-    hipError_t e = launch_fused_grad(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, a, s, kname);
+    // Gated: the LONG kernel goes to the side stream and the chain that depends on it (gated assembly, tail) stays on the
+    // Ceed's stream, so that the only cross-stream wait on the critical path is the fork at the start (the event the tail
+    // waits for has fired ~15 us before the gated kernel ends).  Measured against fused-on-main / join-before-tail: -12 us.
+    hipError_t e = launch_fused_grad(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, a, (gated && !folded) ? c->side_stream : s, kname);
     if (e == hipErrorInvalidValue && !**kname)
       return ceed_error("no fused kernel instantiated for P=%d Q=%d QFunction %s", ai.basis->P1d, ai.basis->Q1d, qf->name.c_str());
     HIPCHK(e);
-    if (gated) {
+    if (folded) {
+      HIPCHK(launch_assemble_tail(ga, s));   // cut rows, abandoned items, control block reset
+    } else if (gated) {
       // launched AFTER the fused kernel, which never waits for it: whatever the queues do, the fused kernel completes;
       // the gated kernel's waits are bounded and the tail kernel finishes whatever it left
       static const int dbg = getenv("CEED_MI355X_GATED_DEBUG") ? atoi(getenv("CEED_MI355X_GATED_DEBUG")) : 0;   // bring-up only
-      if (!(dbg & 1)) HIPCHK(launch_assemble_gated(ga, c->gated_waves, (dbg & 16) ? s : c->side_stream));   // 16: after the fused kernel (its own rate)
-      HIPCHK(hipEventRecord(c->ev_join, c->side_stream));
+      HIPCHK(hipEventRecord(c->ev_join, c->side_stream));                 // fused kernel done
+      if (!(dbg & 1)) HIPCHK(launch_assemble_gated(ga, c->gated_waves, s));
       HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
       if (!(dbg & 2)) HIPCHK(launch_assemble_tail(ga, s));
     } else if (use_evec) {  // timed together with the fused kernel: the launches ARE the operator apply
       const unsigned char *fl = (op->mask_mode & 2) ? (split ? op->d_node_flags_ovl : (direct ? op->d_node_flags_shell : op->d_node_flags)) : nullptr;
       HIPCHK(launch_assemble(M->d_rowptr + row0, M->d_cols, M->d_node_off + row0, fl ? fl + row0 : nullptr, a.evec, py,
-                             nrows, r->elemsize, add ? 1 : 0, side ? c->side_stream : s));
+                             nrows, r->elemsize, add ? 1 : 0, side ? c->side_stream : s, (!gated && a.queue) ? a.queue : nullptr));
       if (side) {
         HIPCHK(hipEventRecord(c->ev_join, c->side_stream));
         HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));

@@ -227,7 +227,9 @@ constexpr int pencil_minw(int Q) { return Q == 5 ? CPS_PENCIL_MINW5 : CPS_PENCIL
 #ifndef CPS_PENCIL_NSET_BIGQ
 #define CPS_PENCIL_NSET_BIGQ 1   // Q >= 6: the split-table passes keep all rounds' pencils in VGPRs; a second q-point set
 #endif                           // would push the hyperFS tangent past 256 VGPRs (26 spilled to scratch)
-template <int P, int Q, int QF, bool GEO, bool EO>
+// FOLD: the folded assembly (FusedGradArgs::as_rowptr) is compiled in -- an instantiation of its own (GEO and EO forms only),
+// so that the default kernel keeps its 203 registers (249 with the stages).
+template <int P, int Q, int QF, bool GEO, bool EO, bool FOLD = false>
 __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const BasisTables tab_, const FusedGradArgs a) {
   static_assert(offsetof(BasisTables, interp) == 0 && offsetof(BasisTables, colo) == 8 * MAXN1D * MAXN1D &&
                 offsetof(BasisTables, grad) == 16 * MAXN1D * MAXN1D, "kernarg layout of the tables");
@@ -285,14 +287,23 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       xs = (xs & 15) | (((x + 1) & 7) << 4) | (st << 8);
     }
   };
-  // Completion signal of the gated assembly (FusedGradArgs::done): one add to the counter of group g's bucket -- in its
-  // upper half if the group was taken from another XCD's chunk -- once the group's stores have been acknowledged
+  // Completion signal of the gated / folded assembly (FusedGradArgs::done): one add to the counter of group g's bucket -- in
+  // its upper half if the group was taken from another XCD's chunk -- once the group's stores have been acknowledged
   // (s_waitcnt vmcnt(0): L1 is write-through, the acknowledgement comes from the XCD's L2).  Issued for the PREVIOUS group
   // just before the physics of the current one, where every older memory operation has landed anyway (the physics needs
   // the prefetched state), so the wait costs nothing; once more after the loop.
-  auto signal_done = [&](int g) {
+  // (compiled in up to Q = 5: from Q = 6 the passes keep all rounds' pencils in registers and the stages' 40 would spill)
+  const bool fold = FOLD && Q <= 5 && dyn && a.as_rowptr != nullptr;
+  auto bucket_size = [&](int c, int b) {   // groups in bucket b of chunk c
+    const kargs_t ka = kargs_fresh<true>();
+    const int ng = (ka->nelem + E - 1) / E, ch = (ng + 7) >> 3, cg = max(0, min(ng - c * ch, ch));
+    return max(0, min(1 << ka->bucket_shift, cg - (b << ka->bucket_shift)));
+  };
+  // sig_idx (out): index of the counter that was bumped, -1 none; sig_old (out, lane 0): its value before (folded assembly)
+  auto signal_done = [&](int g, int &sig_idx, unsigned &sig_old) {
     const kargs_t ka = kargs_fresh<true>();
     unsigned *dn = ka->done;
+    sig_idx = -1;
     if (dn && g >= 0) {
       const int ch = chunk_groups();
       int c = 0;
@@ -300,12 +311,127 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       for (int i = 1; i < 8; i++) c += (g >= i * ch) ? 1 : 0;
       const int sig = c * ka->nb + ((g - c * ch) >> ka->bucket_shift);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) atomicAdd(dn + sig, c == (xs & 15) ? 1u : GatedCtrl::FOREIGN);
+      if (fold) {
+        if (lane == 0) sig_old = atomicAdd(dn + sig, c == (xs & 15) ? 1u : GatedCtrl::FOREIGN);
+        sig_idx = sig;
+      } else if (lane == 0) atomicAdd(dn + sig, c == (xs & 15) ? 1u : GatedCtrl::FOREIGN);
+    }
+  };
+  // Folded assembly: the frontier of chunk c (buckets [0, f) complete and run by the chunk's own XCD) is moved by the wave
+  // whose signal completed a bucket; 64 buckets are probed at once, one per lane.  READY = items that may be summed; its
+  // top bit says that the frontier has met a bucket with foreign groups and will not move again.
+  auto advance_frontier = [&](int sig_idx, unsigned sig_old) {
+    if (sig_idx < 0) return;
+    const kargs_t ka = kargs_fresh<true>();
+    const int nb = ka->nb, c = sig_idx / nb, b = sig_idx - c * nb;
+    const unsigned old = (unsigned)__builtin_amdgcn_readfirstlane(sig_old);
+    // total arrivals (own + foreign) of the bucket after this wave's add
+    if ((int)((old & 0xFFFFu) + (old >> 16)) + 1 != bucket_size(c, b)) return;
+    unsigned *ctrl = ka->queue;
+    unsigned f = (unsigned)__builtin_amdgcn_readfirstlane(__hip_atomic_load(ctrl + GatedCtrl::FRONT + c * QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const unsigned f0 = f;
+    bool stop = false;
+#pragma unroll 1
+    for (int it = 0; it < 8 && f < (unsigned)nb; it++) {
+      const unsigned fb = f + (unsigned)lane;
+      const bool in = fb < (unsigned)nb;
+      const unsigned d = in ? __hip_atomic_load(ka->done + c * nb + fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      const int bs = bucket_size(c, in ? (int)fb : 0);
+      const unsigned long long clean = __ballot(in && d == (unsigned)bs);
+      const unsigned long long dirty = __ballot(in && d >= GatedCtrl::FOREIGN && (int)((d & 0xFFFFu) + (d >> 16)) == bs);
+      const int run = clean == ~0ull ? 64 : __builtin_ctzll(~clean);
+      f += (unsigned)run;
+      if (run < 64) { stop = (dirty >> run) & 1ull; break; }
+    }
+    if (lane == 0) {
+      if (f > f0) {
+        atomicMax(ctrl + GatedCtrl::FRONT + c * QUEUE_STRIDE, f);
+        atomicMax(ctrl + GatedCtrl::READY + c * QUEUE_STRIDE, ka->as_bucket_items[c * nb + (int)f - 1]);
+      }
+      if (stop) atomicOr(ctrl + GatedCtrl::READY + c * QUEUE_STRIDE, GatedCtrl::STOP);
+    }
+  };
+  // ---- folded assembly: one item of the home chunk per element group, in four stages -----------------------------------
+  // Carried from group to group: as_item and the ticket register only.  The rows' registers (FoldRows) live inside ONE
+  // group's iteration -- row pointers across the physics (8 VGPRs), columns and values only behind it.
+  constexpr int AR = GATED_ITEM_ROWS / 64;   // rows per lane
+  struct FoldRows { bool go; unsigned rdy; uint32_t r0, r1, k0[AR], k1[AR], no[AR], cc[AR][4], fl[AR]; double v[AR][4][3]; };
+  int as_item = -1;          // item (index within the home chunk) this wave holds; -1 none, -2 the chunk has no more, -3 ticket requested
+  unsigned as_tkv = 0;       // lane 0: the requested ticket
+  auto as_request = [&]() {   // next item's ticket (returns under other work)
+    if (lane == 0) as_tkv = atomicAdd(kargs_fresh<true>()->queue + GatedCtrl::AHEAD + (xs & 15) * QUEUE_STRIDE, 1u);
+    as_item = -3;
+  };
+  auto as_take = [&]() {   // read a requested ticket
+    if (as_item == -3) {
+      const kargs_t ka = kargs_fresh<true>();
+      const int h = xs & 15;
+      as_item = (int)__builtin_amdgcn_readfirstlane(as_tkv);
+      if (as_item >= ka->as_item_begin[h + 1] - ka->as_item_begin[h]) as_item = -2;
+    }
+  };
+  auto as_stage0 = [&](FoldRows &fr) {   // top of a group: the item's row range and the READY word are requested
+    fr.go = false;
+    if (!fold) return;
+    as_take();
+    const kargs_t ka = kargs_fresh<true>();
+    const int h = xs & 15;
+    const uint32_t *ir = ka->as_item_row + ka->as_item_begin[h] + max(as_item, 0);
+    fr.r0 = ir[0]; fr.r1 = ir[1];
+    fr.rdy = __hip_atomic_load(ka->queue + GatedCtrl::READY + h * QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // Stages 1-4 are BRANCH-FREE: when the wave has no ready item they run all the same on row 0 with every lane inactive
+  // (a handful of loads that hit in cache, no stores).  Loads behind a wave-uniform branch would leave the number of
+  // outstanding memory operations unknown at the join, and the compiler's counted s_waitcnt of the prefetch pipeline
+  // (q-point refills, next group's x) would turn into waits for everything: measured +13 % on the whole kernel.
+  auto as_stage1 = [&](FoldRows &fr, bool drain = false) {   // before the physics: is the item ready?  then row pointers, node offsets, flags
+    const kargs_t ka = kargs_fresh<true>();
+    const unsigned rdy = (unsigned)__builtin_amdgcn_readfirstlane(fr.rdy) & ~GatedCtrl::STOP;
+    fr.go = fold && as_item >= 0 && rdy > (unsigned)as_item && (drain || !(ka->as_dbg & 2));
+    const uint32_t r = fr.r0 + (uint32_t)lane;
+    const bool act = fr.go && r < fr.r1;
+    const uint32_t ri = act ? r : 0u;
+    fr.k0[0] = ka->as_rowptr[ri];
+    fr.k1[0] = ka->as_rowptr[ri + 1];
+    fr.no[0] = ka->as_node_off[ri];
+    fr.fl[0] = (uint32_t)ka->as_flags[ri] | (act ? 0u : 0x100u);   // bit 8: inactive lane
+  };
+  auto as_stage2 = [&](FoldRows &fr) {   // after the physics: the (up to four) contributors' columns
+    const uint32_t *cols = kargs_fresh<true>()->as_cols;
+    const uint32_t last = max(fr.k1[0], fr.k0[0] + 1u) - 1u;
+#pragma unroll
+    for (int m = 0; m < 4; m++) fr.cc[0][m] = cols[min(fr.k0[0] + (uint32_t)m, last)];
+  };
+  auto as_stage3 = [&](FoldRows &fr) {   // after the k-transpose: their values (plain loads: see assemble_row in kernels_misc.hip)
+    const double *ev = kargs_fresh<true>()->evec;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const double *p = ev + fr.cc[0][m];
+#pragma unroll
+      for (int d = 0; d < 3; d++) fr.v[0][m][d] = p[d];
+    }
+  };
+  auto as_stage4 = [&](FoldRows &fr) {   // after the group's own stores: sums in contributor (= element) order, y
+    const kargs_t ka = kargs_fresh<true>();
+    double s0 = 0., s1 = 0., s2 = 0.;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {   // rows of an item have at most four contributors (the others are k_assemble_tail's)
+      const bool in = fr.k0[0] + (uint32_t)m < fr.k1[0];
+      s0 += in ? fr.v[0][m][0] : 0.; s1 += in ? fr.v[0][m][1] : 0.; s2 += in ? fr.v[0][m][2] : 0.;
+    }
+    if (!(fr.fl[0] & 0x100u)) {
+      double *dst = ka->y + (fr.no[0] & OFF_MASK);
+      dst[0] = (fr.fl[0] & 1u) ? 0. : s0; dst[1] = (fr.fl[0] & 2u) ? 0. : s1; dst[2] = (fr.fl[0] & 4u) ? 0. : s2;
+    }
+    if (fr.go) {
+      if (lane == 0) (ka->queue + GatedCtrl::item_done(ka->nb))[ka->as_item_begin[xs & 15] + as_item] = 1u;
+      as_request();
     }
   };
   int grp, g_q1 = -1, g_prev = -1;   // current group; dynamic: the group after it (taken one group ahead), the one before it
   if (dyn) { grp = take(); if (grp < 0) return; g_q1 = take(); }
   else { grp = (int)(blockIdx.x % nxcd) * ((ngroups + nxcd - 1) / nxcd) + wrank; if (grp >= gend) return; }
+  if (fold) as_request();
 
   // ---- loop-invariant lane -> work maps -----------------------------------------------------
   // pencil passes: task t = lane + 64 r over (element, component, b, a), a fastest; address of the
@@ -433,6 +559,10 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     const bool more = dyn ? grp_nx >= 0 : grp_nx < gend;  // wave-uniform
     const int g_nx = more ? grp_nx : grp;
     if (dyn && more) g_q1 = take();   // the group after the next: its ticket returns under this group's work
+    FoldRows fr;        // (this iteration only)
+    int sig_idx = -1;   // the completion counter bumped in this iteration, its value before (lane 0)
+    unsigned sig_old = 0;
+    as_stage0(fr);
     load_offsets(g_nx, off_nx);
     constexpr int RG = (E * GEO_NCOEF + 63) / 64;
     double gcoef[RG];    // this group's element-map coefficients, lane + 64 i; into LDS right before the physics
@@ -517,7 +647,8 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
         if (lane + 64 * i < E * GEO_NCOEF)
           *(ldsp_t)((volatile __attribute__((address_space(3))) char *)lds0 + oGC + (lane + 64 * i) * 8) = gcoef[i];
     }
-    if (dyn) { signal_done(g_prev); g_prev = -1; }
+    if (dyn) { signal_done(g_prev, sig_idx, sig_old); g_prev = -1; }
+    if (fold) as_stage1(fr);
     // ---- physics: point owners, one round at a time; ug[d*3+c] from (BX, A, BZ), dv back in place ----
 #pragma unroll
     for (int r = 0; r < RQ; r++) {
@@ -579,6 +710,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       }
     }
 
+    if (fold) { advance_frontier(sig_idx, sig_old); as_stage2(fr); }
 #ifndef CPS_ABLATE_PASSES
     // ---- gradient^T --------------------------------------------------------------------------------------
     pencil_pass<Q, Q, Q, true, BI, oBX, oBX, -1, EO>(tDt, aIQ, lane, E * T_IQ);  // B1: W1 = Dx^T g0, BX in place
@@ -661,6 +793,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       }
     }
 #endif
+    if (fold) as_stage3(fr);
     load_x(off_nx, xin);  // next group's x (its offsets landed long ago): issued this late so its 6 RN registers
                           // are not live across the physics and the register-hungry passes; B4, B5, the
                           // final store and the next gather's address work hide most of its latency
@@ -707,13 +840,42 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
         }
       }
     }
+    if (fold) as_stage4(fr);
     g_prev = grp;
     if (!more) break;
     grp = grp_nx;
 #pragma unroll
     for (int r = 0; r < RN; r++) off[r] = off_nx[r];
   }
-  if (dyn) signal_done(g_prev);
+  {
+    int sig_idx = -1;
+    unsigned sig_old = 0;
+    if (dyn) signal_done(g_prev, sig_idx, sig_old);
+    if (fold) advance_frontier(sig_idx, sig_old);
+  }
+  if (fold && !(a.as_dbg & 1)) {
+    // ---- drain: the items of the home chunk that are still to be summed; READY is written by few and read here past L1.
+    // Every wait is bounded; what is given up here (frontier stopped by foreign groups, time-out) is k_assemble_tail's.
+    const int nit = a.as_item_begin[(xs & 15) + 1] - a.as_item_begin[xs & 15];
+#pragma unroll 1
+    for (int n = 0; n <= nit; n++) {
+      if (as_item == -1) as_request();
+      as_take();
+      if (as_item < 0) break;
+      bool ok = false;
+#pragma unroll 1
+      for (int spins = 0; spins <= a.as_max_spins; spins++) {
+        const unsigned r = (unsigned)__builtin_amdgcn_readfirstlane(__hip_atomic_load(a.queue + GatedCtrl::READY + (xs & 15) * QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if ((r & ~GatedCtrl::STOP) > (unsigned)as_item) { ok = true; break; }
+        if (r & GatedCtrl::STOP) break;
+        __builtin_amdgcn_s_sleep(64);
+      }
+      if (!ok) break;
+      FoldRows fr;
+      as_stage0(fr); fr.rdy = ~GatedCtrl::STOP;
+      as_stage1(fr, true); as_stage2(fr); as_stage3(fr); as_stage4(fr);
+    }
+  }
 }
 
 template <int P, int Q> constexpr int pencil_waves_per_cu() {
@@ -737,6 +899,13 @@ hipError_t launch_fused_pencil_t(const BasisTables &t, const FusedGradArgs &a, h
   if (!wpc) { const char *e = getenv("CEED_MI355X_PENCIL_WAVES"); wpc = e && atoi(e) > 0 ? atoi(e) : -1; }
   int grid = ncu * (wpc > 0 ? wpc : pencil_waves_per_cu<P, Q>());
   if (grid > ngroups) grid = ngroups;
+  if constexpr (Q <= 5) {
+    if (a.geo && a.eo_ok && a.as_rowptr) {
+      hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true, true, true>), dim3(grid), dim3(64), 0, s, t, a);
+      return hipGetLastError();
+    }
+  }
+  // (a.as_rowptr set but no folded instantiation for this form: the kernel sums nothing and k_assemble_tail sums every item)
   if (a.geo && a.eo_ok) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true, true>), dim3(grid), dim3(64), 0, s, t, a);
   else if (a.geo) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true, false>), dim3(grid), dim3(64), 0, s, t, a);
   else if (a.eo_ok) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, false, true>), dim3(grid), dim3(64), 0, s, t, a);

@@ -80,6 +80,17 @@ struct FusedGradArgs {
                                // group's bucket, done[chunk * nb + ((group - chunk begin) >> bucket_shift)]; a group taken from
                                // another XCD's chunk adds GatedCtrl::FOREIGN instead (its stores sit in another L2)
   int nb, bucket_shift;       // buckets per chunk, log2(groups per bucket)
+  // FOLDED assembly (as_rowptr set; needs queue and done): the waves of the pencil kernel sum the rows of the re-ordered
+  // transpose map themselves -- one item (<= GATED_ITEM_ROWS rows of one bucket of the wave's own XCD's chunk) per element
+  // group, its four dependent load levels (item, row pointers, columns, E-vector values) issued at four points of the
+  // group's passes so that none of them is waited for -- and whoever completes a bucket moves the chunk's frontier and
+  // publishes the number of items that may be summed (GatedCtrl::READY).  What is left when a wave runs out of groups is
+  // summed in a drain loop; cut rows and abandoned items are k_assemble_tail's.  One launch does the whole apply but those.
+  const uint32_t *as_rowptr, *as_cols, *as_node_off, *as_item_row, *as_bucket_items;
+  const unsigned char *as_flags;
+  int as_item_begin[9];
+  int as_max_spins;
+  int as_dbg;                 // bring-up (CEED_MI355X_FOLD_DBG): 1 no drain loop, 2 no in-loop stages (all in the drain loop)
   int direct;                 // pencil kernel + evec: results at ELEMENT-INTERIOR nodes (0 < i,j,k < P-1; one contributor,
                                // verified on the host) are stored straight into y and skip the E-vector round trip; the
                                // E-vector then is [elem][shell node][3] and the transpose map handed to launch_assemble()
@@ -172,9 +183,9 @@ hipError_t launch_diag(int P, int Q, int qf, const BasisTables &t, const DiagArg
 // after both, the cut rows and every item the gated kernel did not finish (buckets with groups stolen by another XCD,
 // waves that never became resident) and resets the control block.  Correctness never depends on co-residency or on
 // the placement of workgroups: only the speed does.
-constexpr int GATED_ITEM_ROWS = 256;
+constexpr int GATED_ITEM_ROWS = 64;    // rows per item: one per lane of the wave that sums it (two per lane: the 48 value registers spilled in the folded form)
 struct GatedCtrl {   // uint32 offsets into the control block (zero before the first launch; the tail kernel re-zeroes it)
-  static constexpr int QUEUE = 0, AHEAD = 8 * QUEUE_STRIDE, READY = 16 * QUEUE_STRIDE, DONE = 24 * QUEUE_STRIDE;
+  static constexpr int QUEUE = 0, AHEAD = 8 * QUEUE_STRIDE, READY = 16 * QUEUE_STRIDE, FRONT = 24 * QUEUE_STRIDE, DONE = 32 * QUEUE_STRIDE;
   static constexpr unsigned STOP = 0x80000000u;   // READY word: the gatekeeper has given up (foreign groups ahead, time-out)
   static constexpr unsigned FOREIGN = 0x10000u;   // a group run by another XCD counts in the upper half of its bucket's counter
   static constexpr int item_done(int nb) { return DONE + 8 * nb; }
@@ -209,7 +220,7 @@ constexpr int pencil_group_elems(int Q) { return Q <= 2 ? 8 : (Q <= 4 ? 4 : (Q =
 // order, of E[3 * cols[k] + c] (cols[k] = e * P3 + n).  `flags` (one byte per node, bit c = component c constrained) may be null.
 hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off,
                            const unsigned char *flags, const double *evec, double *y, int nnodes, int P3,
-                           int add, hipStream_t s);
+                           int add, hipStream_t s, unsigned *queue_reset = nullptr);   // queue_reset: the pencil kernel's ticket counters, zeroed for its next launch
 
 // Coordinate-driven set-up operators (kernels_coord.hip): opSetupForce and opTrue of setuplibceed.c:555-623.
 struct CoordOpArgs {

@@ -1,5 +1,6 @@
 // kernels_misc.hip -- geometry set-up, p-multigrid transfer, diagonal assembly,
 // restriction and vector utilities, and the (P,Q,qf) dispatch tables.
+#include <algorithm>
 #include "kernels_common.hpp"
 #include "qfunctions_device.hpp"
 
@@ -336,7 +337,9 @@ __global__ void k_rstr(const uint32_t *off, size_t total, int elemsize, int ncom
 // 24 contiguous bytes, consecutive lanes (consecutively numbered nodes of one element) read and write
 // consecutive 24-byte rows, so the three strided 8-byte accesses of a wave cover whole cache lines.
 __global__ void k_assemble(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off,
-                           const unsigned char *flags, const double *evec, double *y, int nnodes, int add) {
+                           const unsigned char *flags, const double *evec, double *y, int nnodes, int add, unsigned *queue_reset) {
+  // the fused kernel's ticket counters (dynamic schedule) are zeroed here, after it, for its next launch
+  if (queue_reset && blockIdx.x == 0 && threadIdx.x < 8) queue_reset[threadIdx.x * QUEUE_STRIDE] = 0u;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nnodes; r += gridDim.x * blockDim.x) {
     const uint32_t k0 = rowptr[r], k1 = rowptr[r + 1];
     double a0 = 0., a1 = 0., a2 = 0.;
@@ -591,10 +594,10 @@ hipError_t launch_multiplicity(const uint32_t *off, int nelem, int elemsize, int
 }
 hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off,
                            const unsigned char *flags, const double *evec, double *y, int nnodes, int P3,
-                           int add, hipStream_t s) {
-  if (nnodes <= 0) return hipSuccess;
+                           int add, hipStream_t s, unsigned *queue_reset) {
+  if (nnodes <= 0 && !queue_reset) return hipSuccess;
   (void)P3;
-  hipLaunchKernelGGL(k_assemble, dim3((unsigned)((nnodes + 255) / 256)), dim3(256), 0, s, rowptr, cols, node_off, flags, evec, y, nnodes, add);
+  hipLaunchKernelGGL(k_assemble, dim3((unsigned)((std::max(nnodes, 1) + 255) / 256)), dim3(256), 0, s, rowptr, cols, node_off, flags, evec, y, nnodes, add, queue_reset);
   return hipGetLastError();
 }
 hipError_t launch_dot(const double *x, const double *y, const double *w, size_t n, double *result_dev, hipStream_t s) {

@@ -62,11 +62,11 @@ QF_NAMES = {2: "LinElas", 3: "HyperSSF", 4: "HyperSSdF", 5: "HyperFSF", 6: "Hype
 
 
 def short_name(mangled):
-    m = re.search(r"k_fused_pencilILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)E", mangled)
+    m = re.search(r"k_fused_pencilILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)E", mangled)
     if not m:
         return None, 0, 0
-    P, Q, qf, geo, eo = (int(x) for x in m.groups())
-    return f"k_fused_pencil<P={P},Q={Q},{QF_NAMES.get(qf, qf)},geo={geo},eo={eo}>", Q, eo
+    P, Q, qf, geo, eo, fold = (int(x) for x in m.groups())
+    return f"k_fused_pencil<P={P},Q={Q},{QF_NAMES.get(qf, qf)},geo={geo},eo={eo}" + (",fold" if fold else "") + ">", Q, eo
 
 
 def instruction_counts(co):
@@ -116,7 +116,7 @@ def main():
                     if n_scratch or m.get("scratch", 0): why.append(f"scratch ({m.get('scratch', 0)} B, {n_scratch} instructions)")
                     # SGPR spills go to VGPR lanes (v_writelane / v_readlane): slower, not wrong.  The default (even-odd) instantiations
                     # up to Q = 5 are held to none (from Q = 6 one table fills the SGPR file); the plain-table fallback (eo=0, taken only for tables that are not centro-symmetric) has a few.
-                    if m.get("vspill", 0) or (eo and q <= 5 and m.get("sspill", 0)): why.append(f"spills (vgpr {m.get('vspill', 0)}, sgpr {m.get('sspill', 0)})")
+                    if m.get("vspill", 0) or (eo and q <= 5 and m.get("sspill", 0) > 4): why.append(f"spills (vgpr {m.get('vspill', 0)}, sgpr {m.get('sspill', 0)})")
                     if m.get("vgpr", 0) > 256: why.append(f"{m['vgpr']} VGPRs > 256 (one wave per SIMD)")
                     if why:
                         bad.append(f"{short}: " + "; ".join(why))
