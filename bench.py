@@ -71,16 +71,24 @@ def host_cores() -> int:
 
 
 def traffic_from_profile(kernel_name: str, nelem: int):
-    """HBM bytes per operator apply from the committed PMC reduction (tools/collect_traffic.py ->
-    profiles/r01_traffic.json), if it was taken on this workload; else None."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        d = json.load(open(path))
+    """HBM bytes per operator apply from the newest committed PMC reduction (tools/collect_traffic.py ->
+    profiles/rNN_traffic.json), if it was taken on this workload; (bytes, provenance) or (None, reason).  The value is a
+    constant of that profile, NOT a measurement of this run: PMC counters cannot be read from inside bench.py."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
         if d.get("elements_per_gpu") == nelem and d.get("kernel") == kernel_name:
-            return d.get("hbm_bytes_per_apply")
-    except Exception:
-        pass
-    return None
+            return d.get("hbm_bytes_per_apply"), f"profiles/{os.path.basename(path)} @{d.get('commit', 'round 1')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated on a known axpby)"
+    return None, "no committed PMC profile of this workload / kernel"
+
+
+def own_floor_bytes(nelem: int, P: int, Q: int, lsize: int, state: bool) -> int:
+    """What the apply as BUILT must move at least: stored state (the geometric factors are recomputed from 168 B of map
+    coefficients per element, not streamed), offsets, x and y once."""
+    return nelem * (8 * (9 if state else 0) * Q ** 3 + 4 * P ** 3 + 168) + 16 * lsize
 
 
 def cpu_baseline(args, nr, nth):
@@ -124,7 +132,9 @@ def main():
     ap.add_argument("--nr", type=int, default=10)
     ap.add_argument("--nth", type=int, default=110)
     ap.add_argument("--nz", type=int, default=90)
-    ap.add_argument("--workload", default="cylinder", choices=["cylinder", "box"],
+    ap.add_argument("--mesh", default=os.path.join(ROOT, "tests", "golden", "mesh_cylinder8_44928e_2ss_us.npz"),
+                    help="--workload mesh: an unstructured HEX8 mesh fixture (the reference's cylinder8_44928e_2ss_us.exo, CUBIT order)")
+    ap.add_argument("--workload", default="cylinder", choices=["cylinder", "box", "mesh"],
                     help="cylinder: BASELINE config 4 (default, the metric's config); box: config 5 shape, "
                          "nr x nth x nz elements per GPU (e.g. --workload box --nr 32 --nth 32 --nz 32 --degree 6)")
     ap.add_argument("--nu", type=float, default=0.3)
@@ -167,6 +177,12 @@ def main():
     if args.workload == "cylinder":
         mesh = slab_cylinder(rank, world, args.nr, args.nth, args.nz)
         bc = [s for s in (998, 999) if s in mesh.side_sets]
+    elif args.workload == "mesh":   # one unstructured mesh, z-slab partition of its elements over the ranks (strong scaling)
+        from ceedpetscsolid_amd.mesh import load_mesh_npz, partition_slabs, submesh
+        mesh = load_mesh_npz(args.mesh)
+        if world > 1:
+            mesh = submesh(mesh, partition_slabs(mesh, world)[rank])
+        bc = [s for s in (998, 999) if s in mesh.side_sets and len(mesh.side_sets[s])]
     else:
         mesh = slab_box(rank, world, args.nr, args.nth, args.nz)
         bc = [s for s in (1, 2) if s in mesh.side_sets]
@@ -184,7 +200,10 @@ def main():
     n_global = halo.global_count(free)
 
     # state u (stores gradu through the residual), then the Jacobian input x
-    xt = torch.from_numpy(smooth_displacement(dofmap.node_coords, 0.1, origin=(-1.0, -1.0, 0.0), span=(2.0, 2.0, 10.0))).to(dev)
+    if args.workload == "mesh":   # (the reference cylinders: radius 1, height 2.x -- any fixed box works, the field only has to be rank-independent)
+        xt = torch.from_numpy(smooth_displacement(dofmap.node_coords, 0.1, origin=(-2.0, -2.0, -2.0), span=(4.0, 4.0, 8.0))).to(dev)
+    else:
+        xt = torch.from_numpy(smooth_displacement(dofmap.node_coords, 0.1, origin=(-1.0, -1.0, 0.0), span=(2.0, 2.0, 10.0))).to(dev)
     yt = torch.zeros(n, dtype=torch.float64, device=dev)
     X, Y = ceed.vector(n), ceed.vector(n)
     X.set_device_pointer(xt.data_ptr()); Y.set_device_pointer(yt.data_ptr())   # matops.c:40-41, -memtype device
@@ -250,6 +269,7 @@ def main():
         abytes = algorithmic_bytes(mesh.nelem, P, Q, n, args.problem != "linElas")
         avg_s = kernel_ms * 1e-3 / max(args.steps, 1)   # per APPLY (a split-phase apply is two timed launch pairs)
         achieved = abytes / avg_s / 1e9
+        traffic, traffic_src = traffic_from_profile(op.kernel_name, mesh.nelem)
         out = {
             "metric": "MDoF/s for matrix-free Jacobian apply, p=4 hyperFS hex, 1/2/4/8 GPU",
             "value": 1e-6 * n_global * args.steps / elapsed,
@@ -262,14 +282,22 @@ def main():
             "config": {"workload": (f"config 4: {args.problem}, hollow cylinder {args.nr}x{args.nth}x{args.nz} = "
                                     f"{mesh.nelem} hex per GPU (stand-in for cylinder8_99Ke_4ss_us.exo), degree {args.degree}, "
                                     f"Q={Q}, clamped ends, Jacobian apply y=J(u)x") if args.workload == "cylinder" else
+                                   (f"unstructured reference mesh {os.path.basename(args.mesh)}: {args.problem}, {mesh.nelem} hex on this rank, "
+                                    f"degree {args.degree}, Q={Q}, side sets {bc} clamped, Jacobian apply y=J(u)x") if args.workload == "mesh" else
                                    (f"config 5 shape: {args.problem}, box {args.nr}x{args.nth}x{args.nz} = {mesh.nelem} hex per GPU, "
                                     f"degree {args.degree}, Q={Q}, z faces clamped, Jacobian apply y=J(u)x"),
                        "global_dofs": n_global, "elements_per_gpu": mesh.nelem, "ldofs_per_gpu": n,
                        "halo_dofs_rank0": halo.n_shared_dofs, "kernel": op.kernel_name,
+                       "assembly": os.environ.get("CEED_MI355X_ASSEMBLE", "serial"), "schedule": os.environ.get("CEED_MI355X_SCHED", "dynamic"),
                        "partition": ("z-slabs, one per GPU; halo sum " + ("overlapped with interior elements" if overlap else "after the apply"))
                                     if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(op.kernel_name, mesh.nelem),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         # `achieved` prices the REFERENCE formulation's bytes (qdata and gradu streamed) over the
+                         # measured time: an effective rate.  The kernel as built recomputes qdata (own_floor_bytes) and makes
+                         # an E-vector round trip (the difference between traffic and own_floor_bytes).
+                         "own_floor_bytes": own_floor_bytes(mesh.nelem, P, Q, n, args.problem != "linElas"),
+                         "measured_traffic_GBs": (traffic / avg_s / 1e9) if traffic else None,
                          "algorithmic_bytes_per_launch": abytes, "kernel_avg_us": avg_s * 1e6,
                          "kernel_launches_timed": launches,
                          "kernels": "k_fused_pencil (gather..physics..shell E-vector, interior nodes straight to y) + k_assemble (deterministic per-node sum of the shared nodes): the two launches of one CeedOperatorApply, timed together with hipEvents on their stream",

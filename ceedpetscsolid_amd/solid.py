@@ -88,7 +88,10 @@ class SolidProblem:
                  nu: float = 0.3, E: float = 1.0, multigrid: str = "logarithmic", qextra: int = 0,
                  bc_sides: Optional[Sequence[int]] = None, bc_all_boundary: bool = False,
                  fused_bc: bool = True, shared_multiplicity=None):
-        """``bc_sides``: side-set ids clamped (all three components; -bc_clamp, setupdm.c:171-190);
+        """``fused_bc=False``: build the operator graphs exactly as the reference does and call NO extension of this
+        backend (no Dirichlet flags folded into the offsets, no fused multiplicity scale): the drop-in form, in which the
+        caller does what src/matops.c does around CeedOperatorApply.
+        ``bc_sides``: side-set ids clamped (all three components; -bc_clamp, setupdm.c:171-190);
         ``bc_all_boundary``: the "marker" label of -test mode (setupdm.c:160-170)."""
         if problem not in PROBLEMS:
             raise ValueError(f"unknown problem {problem!r} (hyperFSIncomp is not implemented: dead code upstream)")
@@ -223,8 +226,9 @@ class SolidProblem:
             lv.opProlong.set_field("input", co.Erestrictu, lv.basisCtoF, "active")
             lv.opProlong.set_field("output", lv.Erestrictu, None, "active")
             L = self.ceed.L
-            for op in (lv.opRestrict, lv.opProlong):
-                L.chk(L.lib.CeedXOperatorSetFineScale(op.h, lv.multinv.h))
+            if self.fused_bc:   # fused_bc=False is the EXTENSION-FREE form: no CeedX* call at all; the caller applies multVec
+                for op in (lv.opRestrict, lv.opProlong):   # (matops.c:149,176) and the Dirichlet handling (:33,57,106) itself
+                    L.chk(L.lib.CeedXOperatorSetFineScale(op.h, lv.multinv.h))
             if self.fused_bc:
                 self._set_mask(lv.opProlong, co.mask, lv.mask, mode=3)
                 self._set_mask(lv.opRestrict, lv.mask, co.mask, mode=3)

@@ -210,7 +210,7 @@ def test_full_size_properties_config4(gpu):
     assert np.abs(J(t)).max() < 1e-11 * np.abs(jv).max()
 
 
-@pytest.mark.parametrize("which", ["config 4", "config 5 per-GPU block"])
+@pytest.mark.parametrize("which", ["config 4", "config 5 per-GPU block", "unstructured cylinder8_44928e"])
 def test_full_size_matches_oracle(oracle, oracle_lib, gpu, which):
     """BASELINE configs 4 and 5 (one GPU's 32^3 block, p=6) at FULL size against the oracle itself (threaded over
     elements: a residual and a Jacobian apply of a ~20 M-dof problem take the CPU a few seconds each): the north-star
@@ -218,6 +218,9 @@ def test_full_size_matches_oracle(oracle, oracle_lib, gpu, which):
     import ctypes as C
     if which == "config 4":
         mesh, degree, bc = hollow_cylinder_mesh(10, 110, 90), 4, [998, 999]
+    elif which.startswith("unstructured"):   # the largest unstructured reference cylinder present: CUBIT element and vertex order
+        mesh, degree, bc = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_44928e_2ss_us.npz")), 4, [998, 999]
+        assert mesh.nelem == 44928
     else:
         mesh, degree, bc = box_mesh(32, 32, 32), 6, [1, 2]
     nthreads = max(1, min(16, len(os.sched_getaffinity(0))))
@@ -255,6 +258,79 @@ def test_device_pointer_use_pointer_roundtrip(gpu):
     X, Y = p.ceed.vector(n).set_array(x.cpu().numpy()), p.ceed.vector(n)
     p.apply_jacobian(p.fine, X, Y)
     assert rel_err(y.cpu().numpy(), Y.to_numpy()) < 1e-13
+
+
+@pytest.mark.parametrize("memtype", ["device", "host"])
+def test_extension_free_call_sequence_of_matops(oracle, gpu, memtype):
+    """The UNCHANGED src/matops.c above this library: no CeedX* call at all.  ApplyLocalCeedOp (matops.c:26-60) borrows the
+    caller's buffers with CeedVectorSetArray(memtype, CEED_USE_POINTER), applies, and takes them back; the caller zeroes the
+    constrained entries of the input (G->L into a zeroed Xloc, :33,106), drops the constrained rows of the output (L->G,
+    :57) and multiplies by multVec around the transfers (:149,176).  Residual, Jacobian / diagonal / prolong / restrict on
+    every level, -memtype device (borrowed device buffers) and -memtype host (borrowed host buffers)."""
+    import torch
+    mesh = hollow_cylinder_mesh(2, 8, 3)
+    kw = dict(nu=0.3, E=2.5, bc_sides=[998, 999])
+    pa = SolidProblem(oracle, mesh, 4, "hyperFS", fused_bc=False, **kw)
+    pb = SolidProblem(gpu, mesh, 4, "hyperFS", fused_bc=False, **kw)
+    pf = SolidProblem(gpu, mesh, 4, "hyperFS", fused_bc=True, **kw)       # the fused form, for cross-checking
+    rng = np.random.default_rng(21)
+
+    def apply_local(p, op_apply, xin, nout):
+        """ApplyLocalCeedOp: borrow, apply, take back.  xin: numpy L-vector; returns numpy."""
+        c = p.ceed
+        X, Y = c.vector(xin.size), c.vector(nout)
+        if c is oracle or memtype == "host":
+            xbuf, ybuf = np.ascontiguousarray(xin, dtype=np.float64), np.full(nout, 9.0)
+            X.set_array(xbuf, copy=False); Y.set_array(ybuf, copy=False)           # CEED_MEM_HOST, CEED_USE_POINTER
+            op_apply(X, Y)
+            X.take_array(cd.MEM_HOST); Y.take_array(cd.MEM_HOST)
+            return ybuf.copy()
+        xt, yt = torch.from_numpy(xin).cuda(), torch.full((nout,), 9.0, dtype=torch.float64, device="cuda")
+        X.set_device_pointer(xt.data_ptr()); Y.set_device_pointer(yt.data_ptr())   # CEED_MEM_DEVICE, CEED_USE_POINTER
+        op_apply(X, Y)
+        X.take_array(cd.MEM_DEVICE); Y.take_array(cd.MEM_DEVICE)
+        torch.cuda.synchronize()
+        return yt.cpu().numpy()
+
+    fine = pa.fine
+    free = [(lv.mask == 0).astype(np.float64) for lv in pa.levels]
+    # FormResidual_Ceed (matops.c:63-79): boundary values stay in Xloc, constrained rows dropped on the way back
+    u = pa.smooth_state(0.12)
+    ra, rb = (apply_local(p, p.opApply.apply, u, u.size) * free[fine] for p in (pa, pb))
+    assert rel_err(rb, ra) < TOL
+    X, Y = gpu.vector(u.size).set_array(u), gpu.vector(u.size)
+    pf.form_residual(X, Y)
+    assert rel_err(rb, Y.to_numpy()) < 1e-13
+    for lv in range(len(pa.levels)):
+        n = pa.lsize(lv)
+        x = rng.uniform(-1, 1, n)
+        # ApplyJacobian_Ceed (matops.c:98-112)
+        ja, jb = (apply_local(p, p.levels[lv].opJacob.apply, x * free[lv], n) * free[lv] for p in (pa, pb))
+        assert rel_err(jb, ja) < TOL, lv
+        X, Y = gpu.vector(n).set_array(x), gpu.vector(n)
+        pf.apply_jacobian(lv, X, Y)
+        assert rel_err(jb, Y.to_numpy()) < 1e-13, lv
+        # GetDiag_Ceed (matops.c:206-244): the diagonal lands in the borrowed Yloc
+        da, db = (apply_local(p, lambda X_, Y_, p=p: p.levels[lv].opJacob.assemble_diagonal(Y_), x, n) * free[lv] for p in (pa, pb))
+        assert rel_err(db, da) < TOL, lv
+        if lv == 0:
+            continue
+        nc = pa.lsize(lv - 1)
+        xc = rng.uniform(-1, 1, nc)
+        mult = pa.levels[lv].multinv.to_numpy()
+        assert np.array_equal(mult, pb.levels[lv].multinv.to_numpy())
+        # Prolong_Ceed (matops.c:115-157): apply, then VecPointwiseMult with multVec
+        fa, fb = (apply_local(p, p.levels[lv].opProlong.apply, xc * free[lv - 1], n) * mult * free[lv] for p in (pa, pb))
+        assert rel_err(fb, fa) < TOL, lv
+        Xc, Yf = gpu.vector(nc).set_array(xc), gpu.vector(n)
+        pf.prolong(lv, Xc, Yf)
+        assert rel_err(fb, Yf.to_numpy()) < 1e-13, lv
+        # Restrict_Ceed (matops.c:160-203): VecPointwiseMult with multVec, then apply
+        ca, cb = (apply_local(p, p.levels[lv].opRestrict.apply, x * free[lv] * mult, nc) * free[lv - 1] for p in (pa, pb))
+        assert rel_err(cb, ca) < TOL, lv
+        Xf, Yc = gpu.vector(n).set_array(x), gpu.vector(nc)
+        pf.restrict(lv, Xf, Yc)
+        assert rel_err(cb, Yc.to_numpy()) < 1e-13, lv
 
 
 def test_unsupported_graphs_fail_loudly(gpu):

@@ -72,6 +72,31 @@ def test_device_solve_matches_oracle_solve(oracle, gpu):
     assert rel_err(sols[1][0], sols[0][0]) < 1e-8
 
 
+@pytest.mark.gpu
+def test_config3_full_solve_on_the_device(gpu):
+    """BASELINE config 3 as stated: hyperSS, cylinder8_5580e_4ss_us (the reference's own mesh), degree 4, the FULL
+    Newton-CG-pMG solve (10 load increments, levels p = 1, 2, 4, assembled coarse level) on one MI355X.  Pinned: convergence
+    of every increment, the Newton count (3 per increment), a Krylov count in the band the matrix-free and the assembled
+    coarse solve both give, the clamp displacement reached, and a final residual at the solver's tolerance."""
+    mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_5580e_4ss_us.npz"))
+    p = SolidProblem(gpu, mesh, 4, "hyperSS", nu=0.3, E=1e3, bc_sides=[998, 999])
+    assert p.degrees == [1, 2, 4] and p.n_free() == 1150068
+    tr = (0.0, -0.05, 0.1)
+    s = NewtonPMG(p, clamp={998: dict(translate=tr), 999: dict()}, coarse="assembled", coarse_cheb_its=40, coarse_cheb_ratio=100.0, graph=True)
+    st = s.solve(10)
+    assert st.converged and st.increments == 10
+    assert st.newton_its == 30
+    assert 400 <= st.ksp_its <= 1400, st.ksp_its
+    last = [h for h in st.history if h[0] == 10]
+    first_of_last = last[0][4]
+    assert st.history[-1][4] < 1e-6 * max(1.0, first_of_last) or st.history[-1][4] < 1e-8
+    u = s.U.to_numpy()
+    assert np.all(u[p.levels[p.fine].mask != 0] == 0.0)      # L-layout: constrained entries stay zero (the clamp values live in Xloc)
+    umax = np.abs(u.reshape(-1, 3)).max(axis=0)
+    # the free nodes next to the translated clamp (0, -0.05, 0.1) follow it (recorded on the device: 0.0031, 0.0515, 0.0998)
+    assert 0.09 < umax[2] <= 0.1 + 1e-9 and 0.045 < umax[1] < 0.06 and umax[0] < 0.01, umax
+
+
 def test_chebyshev_coarse_solver_converges_on_oracle(oracle):
     mesh = hollow_cylinder_mesh(1, 6, 2, z0=-1.0, z1=1.0)
     p = SolidProblem(oracle, mesh, 2, "hyperSS", nu=0.3, E=10.0, bc_sides=[998, 999])

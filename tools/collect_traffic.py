@@ -1,11 +1,11 @@
 """Reduce rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes, as MI355X_MICROARCH.md
-prescribes) into profiles/r01_traffic.json.  gfx950 corrections applied:
+prescribes) into gpurun_out/<tag>_traffic.json (copied to profiles/).  gfx950 corrections applied:
   * FETCH_SIZE counts 64 B per 128-B fabric read request: doubled for wide coalesced streaming reads.
     Our reads are 8 B/lane (512 B contiguous per wave-instruction), an access width the guide calls
     uncalibrated, so the factor is CALIBRATED in the same run on a kernel with a known byte count
     (k_axpby over a 1 GiB vector: reads 2 x 8 B/lane streams, writes one).
   * WRITE_SIZE is taken as exact for streaming stores after the same calibration.
-Usage (on the GPU box):  python tools/collect_traffic.py <fetch_pass_dir> <write_pass_dir> <bench_json>
+Usage (on the GPU box):  python tools/collect_traffic.py <fetch_pass_dir> <write_pass_dir> <bench_json> [tag=r02] [commit]
 """
 import csv, glob, json, os, sys, collections
 
@@ -27,10 +27,13 @@ f_cal = w_cal = None
 if kax:
     f_cal = 2 * cal_known / (mean(fetch[kax[0]]["FETCH_SIZE"]) * 1024.0)      # true read bytes / counted
     w_cal = 1 * cal_known / (mean(write[find(write, "k_axpby")[0]]["WRITE_SIZE"]) * 1024.0)
+tag = sys.argv[4] if len(sys.argv) > 4 else "r02"
 out = {"kernel": bench["config"]["kernel"], "elements_per_gpu": bench["config"]["elements_per_gpu"],
+       "commit": sys.argv[5] if len(sys.argv) > 5 else os.environ.get("GRAFT_COMMIT", "unknown"),
+       "assembly": bench["config"].get("assembly"), "schedule": bench["config"].get("schedule"),
        "fetch_calibration_factor": f_cal, "write_calibration_factor": w_cal, "per_kernel": {}}
 tot = 0.0
-for name in ("k_fused_pencil<5, 5, 6", "k_fused_grad<5, 5, 6>", "k_assemble"):
+for name in ("k_fused_pencil<5, 5, 6", "k_fused_grad<5, 5, 6>", "k_assemble(", "k_assemble_gated", "k_assemble_tail"):
     kf, kw = find(fetch, name), find(write, name)
     if not kf: continue
     fb = mean(fetch[kf[0]]["FETCH_SIZE"]) * 1024.0 * (f_cal or 2.0)
@@ -39,5 +42,5 @@ for name in ("k_fused_pencil<5, 5, 6", "k_fused_grad<5, 5, 6>", "k_assemble"):
     tot += fb + wb
 out["hbm_bytes_per_apply"] = tot
 out["algorithmic_bytes_per_apply"] = bench["roofline"]["algorithmic_bytes_per_launch"]
-json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r01_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", tag + "_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
