@@ -8,9 +8,10 @@ replaces DMLocalToGlobal(ADD_VALUES).  Inputs are resident in HBM before the tim
 
 Workload (config.workload): BASELINE config 4 -- hyperFS, degree 4, ~99k-element hollow
 cylinder (R 0.5-1, height 10; structured stand-in for the absent cylinder8_99Ke_4ss_us.exo,
-same geometry and side-set ids), clamped at both ends.  N > 1 is WEAK scaling: every rank
-owns one such 99 000-element z-slab of a cylinder N slabs tall; ranks exchange the slab
-interfaces over RCCL (torch.distributed "nccl").
+same geometry and side-set ids), clamped at both ends.  N > 1 is STRONG scaling, as the config is
+stated: that ONE cylinder's element layers are partitioned over the N ranks (--scaling weak: one
+such cylinder per rank, round 1's form); ranks exchange the interface dofs over RCCL through the
+library's own CeedXHalo* (--halo torch: torch.distributed point-to-point).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -35,7 +36,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from ceedpetscsolid_amd import ceed as cd  # noqa: E402
-from ceedpetscsolid_amd.halo import HaloExchange, interface_elements, slab_box, slab_cylinder  # noqa: E402
+from ceedpetscsolid_amd.halo import (HaloExchange, RcclHalo, interface_elements, part_box, part_cylinder, slab_box,  # noqa: E402
+                                     slab_cylinder)
 from ceedpetscsolid_amd.mesh import reorder_elements_first  # noqa: E402
 from ceedpetscsolid_amd.harness import SolidApp  # noqa: E402
 from ceedpetscsolid_amd.solid import SolidProblem, smooth_displacement  # noqa: E402
@@ -137,6 +139,12 @@ def main():
     ap.add_argument("--workload", default="cylinder", choices=["cylinder", "box", "mesh"],
                     help="cylinder: BASELINE config 4 (default, the metric's config); box: config 5 shape, "
                          "nr x nth x nz elements per GPU (e.g. --workload box --nr 32 --nth 32 --nz 32 --degree 6)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = ONE mesh of the stated size partitioned over the ranks, as BASELINE configs 4 / 5 are "
+                         "stated (setupdm.c:57-64: DMPlexDistribute of one mesh); weak = one such mesh PER rank (round 1's form)")
+    ap.add_argument("--halo", default="rccl", choices=["rccl", "torch"],
+                    help="N > 1 on the nccl backend: rccl = the library's own exchange (CeedXHalo*: pack kernel, ncclSend/ncclRecv group on "
+                         "its stream, unpack-add kernel); torch = torch.distributed point-to-point + index ops (also the gloo rehearsal)")
     ap.add_argument("--nu", type=float, default=0.3)
     ap.add_argument("--E", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -174,8 +182,9 @@ def main():
     ceed.set_stream(stream.cuda_stream)
 
     # ---- workload ---------------------------------------------------------
+    strong = args.scaling == "strong"
     if args.workload == "cylinder":
-        mesh = slab_cylinder(rank, world, args.nr, args.nth, args.nz)
+        mesh = part_cylinder(rank, world, args.nr, args.nth, args.nz) if strong else slab_cylinder(rank, world, args.nr, args.nth, args.nz)
         bc = [s for s in (998, 999) if s in mesh.side_sets]
     elif args.workload == "mesh":   # one unstructured mesh, z-slab partition of its elements over the ranks (strong scaling)
         from ceedpetscsolid_amd.mesh import load_mesh_npz, partition_slabs, submesh
@@ -184,7 +193,7 @@ def main():
             mesh = submesh(mesh, partition_slabs(mesh, world)[rank])
         bc = [s for s in (998, 999) if s in mesh.side_sets and len(mesh.side_sets[s])]
     else:
-        mesh = slab_box(rank, world, args.nr, args.nth, args.nz)
+        mesh = part_box(rank, world, args.nr, args.nth, args.nz) if strong else slab_box(rank, world, args.nr, args.nth, args.nz)
         bc = [s for s in (1, 2) if s in mesh.side_sets]
     lead = interface_elements(mesh)                    # collective; all False on one rank
     overlap = world > 1 and not args.no_overlap and lead.any() and not lead.all()
@@ -196,6 +205,9 @@ def main():
     dofmap, mask = prob.dofmaps[prob.fine], prob.masks[prob.fine]
     n = prob.lsize()
     halo = HaloExchange(mesh, dofmap, device=dev)
+    # the exchange itself: behind the C ABI over RCCL on a GPU node; the torch path on gloo (single-GPU rehearsal) or on request
+    use_rccl = world > 1 and args.halo == "rccl" and dist.get_backend() == "nccl"
+    chalo = RcclHalo(ceed, halo) if use_rccl else None
     free = (mask == 0).astype(np.float64)
     n_global = halo.global_count(free)
 
@@ -216,12 +228,12 @@ def main():
     def step():
         if overlap:   # interface elements -> start the RCCL exchange -> interior elements under it -> add
             op.apply_phase(X, Y, 0)
-            halo.start(yt)
+            chalo.start(Y) if chalo else halo.start(yt)
             op.apply_phase(X, Y, 1)
-            halo.finish(yt)
+            chalo.finish(Y) if chalo else halo.finish(yt)
         else:
             prob.apply_jacobian(prob.fine, X, Y)   # ApplyJacobian_Ceed: k_fused_pencil + k_assemble on `stream`
-            halo.add(yt)                            # interface sum (no-op at N = 1)
+            chalo.add(Y) if chalo else halo.add(yt)   # interface sum (no-op at N = 1)
 
     if args.calibrate_traffic:   # known traffic for tools/collect_traffic.py: reads 2 GiB, writes 1 GiB
         import ctypes as C
@@ -260,6 +272,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the exchange alone (outside the timed region): mean of 20 back-to-back interface sums
+    halo_us = None
+    if world > 1:
+        ykeep = yt.clone()
+        torch.cuda.synchronize(); dist.barrier()
+        th = time.perf_counter()
+        for _ in range(20):
+            chalo.add(Y) if chalo else halo.add(yt)
+        torch.cuda.synchronize()
+        halo_us = 1e6 * (time.perf_counter() - th) / 20
+        yt.copy_(ykeep)
     # sanity on the result of the last step (cheap, outside the timed region)
     ynorm = float(torch.linalg.vector_norm(yt).item())
     assert np.isfinite(ynorm) and ynorm > 0.0
@@ -277,7 +300,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "prewarm_ms": args.prewarm_ms, "prewarm_steps": prewarm_steps,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"config 4: {args.problem}, hollow cylinder {args.nr}x{args.nth}x{args.nz} = "
                                     f"{mesh.nelem} hex per GPU (stand-in for cylinder8_99Ke_4ss_us.exo), degree {args.degree}, "
@@ -289,8 +312,11 @@ def main():
                        "global_dofs": n_global, "elements_per_gpu": mesh.nelem, "ldofs_per_gpu": n,
                        "halo_dofs_rank0": halo.n_shared_dofs, "kernel": op.kernel_name,
                        "assembly": os.environ.get("CEED_MI355X_ASSEMBLE", "serial"), "schedule": os.environ.get("CEED_MI355X_SCHED", "dynamic"),
-                       "partition": ("z-slabs, one per GPU; halo sum " + ("overlapped with interior elements" if overlap else "after the apply"))
-                                    if world > 1 else "single GPU"},
+                       "partition": ((("z-layers of ONE mesh" if args.workload != "box" else "blocks %dx%dx%d of ONE box" % __import__("ceedpetscsolid_amd.halo", fromlist=["block_grid"]).block_grid(world)) if strong else "one such mesh per GPU (z-slabs)")
+                                     + "; halo sum " + ("overlapped with interior elements" if overlap else "after the apply")
+                                     + (" through CeedXHalo* (RCCL group of ncclSend/ncclRecv, pack / unpack-add kernels)" if use_rccl else " through torch.distributed P2P"))
+                                    if world > 1 else "single GPU",
+                       "halo_exchange_us_alone": halo_us, "multi_gpu_measured": (None if world == 1 else "this run")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          # `achieved` prices the REFERENCE formulation's bytes (qdata and gradu streamed) over the

@@ -64,6 +64,7 @@ class CeedLib:
         "CeedXSetErrorReturn", "CeedXLastError", "CeedXSetStream", "CeedXSynchronize",
         "CeedXOperatorGetKernelName", "CeedXOperatorSetDirichletMask",
         "CeedXOperatorSetTiming", "CeedXOperatorGetTiming", "CeedXOperatorSetDirichletMaskMode", "CeedXOperatorGetGatedStats",
+        "CeedXCommGetUniqueId", "CeedXCommInit", "CeedXCommDestroy", "CeedXHaloCreate", "CeedXHaloStart", "CeedXHaloFinish", "CeedXHaloDestroy",
         "CeedXOperatorSetFineScale", "CeedXOperatorSetOverlapSplit", "CeedXOperatorApplyPhase",
         "CeedXVectorPointwiseMult", "CeedXVectorAXPBY", "CeedXVectorDot", "CeedXVectorChebyshevUpdate",
         "CeedXGraphBeginCapture", "CeedXGraphEndCapture", "CeedXGraphLaunch", "CeedXGraphDestroy",

@@ -16,6 +16,7 @@
 // There is NO host fallback: a graph outside these families, a QFunction without
 // a device functor, or a missing GPU is a loud error.
 #include <ceed.h>
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -88,6 +89,10 @@ struct Ceed_private {
   int gated_spins = 1 << 19;    // the gated kernel's bounded wait for one bucket, in ~2 us polls (CEED_MI355X_ASM_SPINS)
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // RCCL communicator of the halo exchange (CeedXCommInit) and the stream its sends / receives run on
+  void *comm = nullptr;
+  int comm_rank = 0, comm_size = 1;
+  hipStream_t comm_stream = nullptr;
   double *d_scalar = nullptr;   // device scalar for reductions
   double *h_scalar = nullptr;   // pinned host landing slot for it (pageable targets make the runtime stage + pin per copy)
   // hipGraph capture (CeedXGraphBeginCapture): device work is recorded on `capture_stream`
@@ -286,8 +291,9 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   return 0;
 }
 static void ceed_ref(Ceed c) { c->refcount++; }
+static int (*g_rccl_destroy)(void *) = nullptr;   // set when RCCL is bound (CeedXCommInit)
 static void ceed_free_parked(Ceed c) { for (double *p : c->evec_parked) (void)hipFree(p); c->evec_parked.clear(); }
-static void ceed_unref(Ceed c) { if (--c->refcount == 0) { if (c->capture_stream) (void)hipStreamDestroy(c->capture_stream); if (c->evec) (void)hipFree(c->evec); ceed_free_parked(c); if (c->queue) (void)hipFree(c->queue); if (c->side_stream) (void)hipStreamDestroy(c->side_stream); if (c->ev_fork) (void)hipEventDestroy(c->ev_fork); if (c->ev_join) (void)hipEventDestroy(c->ev_join); if (c->d_scalar) (void)hipFree(c->d_scalar); if (c->h_scalar) (void)hipHostFree(c->h_scalar); delete c; } }
+static void ceed_unref(Ceed c) { if (--c->refcount == 0) { if (c->capture_stream) (void)hipStreamDestroy(c->capture_stream); if (c->evec) (void)hipFree(c->evec); ceed_free_parked(c); if (c->queue) (void)hipFree(c->queue); if (c->side_stream) (void)hipStreamDestroy(c->side_stream); if (c->comm && g_rccl_destroy) g_rccl_destroy(c->comm); if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream); if (c->ev_fork) (void)hipEventDestroy(c->ev_fork); if (c->ev_join) (void)hipEventDestroy(c->ev_join); if (c->d_scalar) (void)hipFree(c->d_scalar); if (c->h_scalar) (void)hipHostFree(c->h_scalar); delete c; } }
 extern "C" int CeedDestroy(Ceed *ceed) {
   if (!ceed || !*ceed) return 0;
   ceed_unref(*ceed);
@@ -1682,6 +1688,160 @@ extern "C" int CeedXVectorDot(CeedVector x, CeedVector y, CeedVector weight, dou
   HIPCHK(hipMemcpyAsync(x->ceed->h_scalar, dres, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   *result = *x->ceed->h_scalar;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Halo exchange over RCCL (the L-vector interface sum of src/matops.c:57 across the GPUs of one node)
+// ---------------------------------------------------------------------------
+// RCCL is bound at first use with dlopen: a C host gets /opt/rocm's librccl, a Python host the copy torch has already
+// loaded (one RCCL per process, like the HIP runtime: see ceed.py).  No link-time dependency for single-GPU users.
+namespace {
+typedef struct { char internal[128]; } rccl_unique_id;
+struct Rccl {
+  void *h = nullptr;
+  int (*GetUniqueId)(rccl_unique_id *) = nullptr;
+  int (*CommInitRank)(void **, int, rccl_unique_id, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+const int RCCL_FLOAT64 = 8;   // ncclFloat64 (rccl.h)
+int rccl_load() {
+  if (g_rccl.h) return 0;
+  const char *names[] = {"librccl.so.1", "librccl.so"};
+  for (int pass = 0; pass < 2 && !g_rccl.h; pass++)      // an already loaded copy first (RTLD_NOLOAD)
+    for (const char *n : names)
+      if (!g_rccl.h) g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+  if (!g_rccl.h) return ceed_error("the halo exchange needs RCCL (librccl.so.1): %s", dlerror());
+  auto sym = [](const char *n) { return dlsym(g_rccl.h, n); };
+  g_rccl.GetUniqueId = (int (*)(rccl_unique_id *))sym("ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void **, int, rccl_unique_id, int))sym("ncclCommInitRank");
+  g_rccl.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
+  g_rccl_destroy = g_rccl.CommDestroy;
+  g_rccl.GroupStart = (int (*)())sym("ncclGroupStart");
+  g_rccl.GroupEnd = (int (*)())sym("ncclGroupEnd");
+  g_rccl.Send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))sym("ncclSend");
+  g_rccl.Recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))sym("ncclRecv");
+  g_rccl.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Send ||
+      !g_rccl.Recv || !g_rccl.GetErrorString) { g_rccl.h = nullptr; return ceed_error("librccl lacks a point-to-point entry point"); }
+  return 0;
+}
+}  // namespace
+#define RCCLCHK(x) do { int r_ = (x); if (r_ != 0) return ceed_error("%s failed: %s", #x, g_rccl.GetErrorString(r_)); } while (0)
+
+extern "C" int CeedXCommGetUniqueId(Ceed, char id[128]) {
+  CHK(rccl_load());
+  rccl_unique_id u;
+  RCCLCHK(g_rccl.GetUniqueId(&u));
+  memcpy(id, u.internal, 128);
+  return 0;
+}
+extern "C" int CeedXCommInit(Ceed ceed, int nranks, int rank, const char id[128]) {
+  if (ceed->comm) return ceed_error("this Ceed already has a communicator");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return ceed_error("CeedXCommInit: rank %d of %d", rank, nranks);
+  CHK(rccl_load());
+  rccl_unique_id u;
+  memcpy(u.internal, id, 128);
+  HIPCHK(hipSetDevice(ceed->device));
+  RCCLCHK(g_rccl.CommInitRank(&ceed->comm, nranks, u, rank));
+  ceed->comm_rank = rank; ceed->comm_size = nranks;
+  if (!ceed->comm_stream) HIPCHK(hipStreamCreateWithFlags(&ceed->comm_stream, hipStreamNonBlocking));
+  return 0;
+}
+extern "C" int CeedXCommDestroy(Ceed ceed) {
+  if (ceed->comm) { (void)hipStreamSynchronize(ceed->comm_stream); (void)g_rccl.CommDestroy(ceed->comm); ceed->comm = nullptr; }
+  return 0;
+}
+
+struct HaloNeighbour { int rank = 0, n = 0; uint32_t *d_idx = nullptr; double *send = nullptr, *recv = nullptr; };
+struct CeedXHalo_private {
+  Ceed ceed = nullptr;
+  std::vector<HaloNeighbour> nb;
+  hipEvent_t packed = nullptr, arrived = nullptr;
+  bool in_flight = false;
+  CeedInt lsize_min = 0;
+};
+// Neighbour lists: `index[k]` holds the `count[k]` L-vector entries shared with rank `neigh_rank[k]`, in an order both
+// sides agree on (halo.py sorts them by partition-independent node keys).  Entries are unique within one list.
+extern "C" int CeedXHaloCreate(Ceed ceed, CeedInt nneigh, const int *neigh_rank, const CeedInt *count,
+                               const CeedInt *const *index, CeedXHalo *halo) {
+  if (nneigh > 0 && !ceed->comm) return ceed_error("CeedXHaloCreate: call CeedXCommInit first");
+  CeedXHalo H = new CeedXHalo_private;
+  H->ceed = ceed; ceed_ref(ceed);
+  for (int k = 0; k < nneigh; k++) {
+    if (neigh_rank[k] < 0 || neigh_rank[k] >= ceed->comm_size || count[k] < 0) return ceed_error("CeedXHaloCreate: bad neighbour %d", k);
+    HaloNeighbour nb;
+    nb.rank = neigh_rank[k]; nb.n = count[k];
+    std::vector<uint32_t> idx((size_t)nb.n);
+    for (int i = 0; i < nb.n; i++) {
+      if (index[k][i] < 0) return ceed_error("CeedXHaloCreate: negative index");
+      idx[i] = (uint32_t)index[k][i];
+      H->lsize_min = std::max(H->lsize_min, index[k][i] + 1);
+    }
+    HIPCHK(hipMalloc((void **)&nb.d_idx, sizeof(uint32_t) * (idx.size() ? idx.size() : 1)));
+    HIPCHK(hipMemcpy(nb.d_idx, idx.data(), sizeof(uint32_t) * idx.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&nb.send, sizeof(double) * (nb.n ? nb.n : 1)));
+    HIPCHK(hipMalloc((void **)&nb.recv, sizeof(double) * (nb.n ? nb.n : 1)));
+    H->nb.push_back(nb);
+  }
+  HIPCHK(hipEventCreateWithFlags(&H->packed, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&H->arrived, hipEventDisableTiming));
+  *halo = H;
+  return 0;
+}
+// Start: pack on the Ceed's stream, then all sends and receives of this rank as ONE RCCL group on the communicator's
+// stream -- the Ceed's stream is free for the interior elements meanwhile (CeedXOperatorApplyPhase 1).
+extern "C" int CeedXHaloStart(CeedXHalo H, CeedVector y) {
+  if (H->in_flight) return ceed_error("CeedXHaloStart: an exchange is already in flight");
+  if (H->nb.empty()) return 0;
+  Ceed c = H->ceed;
+  if (c->capturing) return ceed_error("CeedXHaloStart during graph capture");
+  if (y->length < H->lsize_min) return ceed_error("CeedXHaloStart: vector shorter than the halo's indices");
+  double *py;
+  CHK(vec_dev(y, false, &py));
+  for (HaloNeighbour &nb : H->nb) HIPCHK(launch_halo_pack(nb.d_idx, nb.n, py, nb.send, c->stream));
+  HIPCHK(hipEventRecord(H->packed, c->stream));
+  HIPCHK(hipStreamWaitEvent(c->comm_stream, H->packed, 0));
+  RCCLCHK(g_rccl.GroupStart());
+  for (HaloNeighbour &nb : H->nb) {
+    RCCLCHK(g_rccl.Send(nb.send, (size_t)nb.n, RCCL_FLOAT64, nb.rank, c->comm, c->comm_stream));
+    RCCLCHK(g_rccl.Recv(nb.recv, (size_t)nb.n, RCCL_FLOAT64, nb.rank, c->comm, c->comm_stream));
+  }
+  RCCLCHK(g_rccl.GroupEnd());
+  HIPCHK(hipEventRecord(H->arrived, c->comm_stream));
+  H->in_flight = true;
+  return 0;
+}
+// Finish: the Ceed's stream waits for the arrivals and adds them, neighbour by neighbour in list order (a node shared by
+// three ranks gets its two additions in the same order every time: the sum is reproducible).
+extern "C" int CeedXHaloFinish(CeedXHalo H, CeedVector y) {
+  if (H->nb.empty()) return 0;
+  if (!H->in_flight) return ceed_error("CeedXHaloFinish without CeedXHaloStart");
+  Ceed c = H->ceed;
+  double *py;
+  CHK(vec_dev(y, true, &py));
+  HIPCHK(hipStreamWaitEvent(c->stream, H->arrived, 0));
+  for (HaloNeighbour &nb : H->nb) HIPCHK(launch_halo_unpack_add(nb.d_idx, nb.n, nb.recv, py, c->stream));
+  H->in_flight = false;
+  return 0;
+}
+extern "C" int CeedXHaloDestroy(CeedXHalo *halo) {
+  if (!halo || !*halo) return 0;
+  CeedXHalo H = *halo;
+  (void)hipStreamSynchronize(H->ceed->stream);
+  if (H->ceed->comm_stream) (void)hipStreamSynchronize(H->ceed->comm_stream);
+  for (HaloNeighbour &nb : H->nb) { (void)hipFree(nb.d_idx); (void)hipFree(nb.send); (void)hipFree(nb.recv); }
+  if (H->packed) (void)hipEventDestroy(H->packed);
+  if (H->arrived) (void)hipEventDestroy(H->arrived);
+  ceed_unref(H->ceed);
+  delete H;
+  *halo = nullptr;
   return 0;
 }
 

@@ -251,6 +251,11 @@ struct EnergyOpArgs {
 };
 hipError_t launch_energy_op(const EnergyOpArgs &a, hipStream_t s);
 
+// Interface-dof halo exchange (CeedXHalo*, the L-vector sum of src/matops.c:57 across GPUs): pack the entries shared with
+// one neighbour into its send buffer; add a neighbour's received entries (indices unique per neighbour: no atomics).
+hipError_t launch_halo_pack(const uint32_t *idx, int n, const double *y, double *buf, hipStream_t s);
+hipError_t launch_halo_unpack_add(const uint32_t *idx, int n, const double *buf, double *y, hipStream_t s);
+
 // Assembled coarse-level operator (kernels_csr.hip).
 hipError_t launch_csr_sum(const uint32_t *slotptr, const uint32_t *perm, const double *coo, double *vals, int nnz,
                           const uint32_t *unit_diag_slot, int n_unit, hipStream_t s);

@@ -518,6 +518,23 @@ hipError_t launch_assemble_tail(const GatedAsmArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
+__global__ void k_halo_pack(const uint32_t *idx, int n, const double *y, double *buf) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) buf[i] = y[idx[i]];
+}
+__global__ void k_halo_unpack_add(const uint32_t *idx, int n, const double *buf, double *y) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[idx[i]] += buf[i];
+}
+hipError_t launch_halo_pack(const uint32_t *idx, int n, const double *y, double *buf, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)std::min((n + 255) / 256, 2048)), dim3(256), 0, s, idx, n, y, buf);
+  return hipGetLastError();
+}
+hipError_t launch_halo_unpack_add(const uint32_t *idx, int n, const double *buf, double *y, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_halo_unpack_add, dim3((unsigned)std::min((n + 255) / 256, 2048)), dim3(256), 0, s, idx, n, buf, y);
+  return hipGetLastError();
+}
+
 __global__ void k_dot(const double *x, const double *y, const double *w, size_t n, double *result) {
   double s = 0.;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)

@@ -141,6 +141,49 @@ class HaloExchange:
         return float(s.item())
 
 
+class RcclHalo:
+    """The same exchange behind the C ABI (include/ceed.h, CeedXHalo*): RCCL sends / receives issued by the library on a
+    stream of its own, hand-written pack and unpack-add kernels, no framework ops on the path.  Built from a
+    HaloExchange's neighbour lists; the communicator is bootstrapped like any NCCL communicator (rank 0's unique id,
+    distributed here with torch.distributed -- an MPI_Bcast in the reference's world)."""
+
+    def __init__(self, ceed, halo: "HaloExchange"):
+        import ctypes as C
+        self.ceed, self.L = ceed, ceed.L
+        self.h = C.c_void_p()
+        self.world = halo.world
+        lib = self.L.lib
+        if halo.world > 1 and not getattr(ceed, "_comm_ready", False):
+            ident = [None]
+            if halo.rank == 0:
+                buf = C.create_string_buffer(128)
+                self.L.chk(lib.CeedXCommGetUniqueId(ceed.h, buf))
+                ident = [buf.raw]
+            dist.broadcast_object_list(ident, src=0, group=halo.group)
+            self.L.chk(lib.CeedXCommInit(ceed.h, C.c_int(halo.world), C.c_int(halo.rank), C.c_char_p(ident[0])))
+            ceed._comm_ready = True
+        nn = len(halo.neigh)
+        ranks = (C.c_int * max(nn, 1))(*[n.rank for n in halo.neigh])
+        counts = (C.c_int * max(nn, 1))(*[int(n.dof_idx.numel()) for n in halo.neigh])
+        self._idx = [np.ascontiguousarray(n.dof_idx.cpu().numpy().astype(np.int32)) for n in halo.neigh]
+        ptrs = (C.POINTER(C.c_int) * max(nn, 1))(*[a.ctypes.data_as(C.POINTER(C.c_int)) for a in self._idx])
+        self.L.chk(lib.CeedXHaloCreate(ceed.h, C.c_int(nn), ranks, counts, ptrs, C.byref(self.h)))
+
+    def start(self, y):
+        self.L.chk(self.L.lib.CeedXHaloStart(self.h, y.h))
+
+    def finish(self, y):
+        self.L.chk(self.L.lib.CeedXHaloFinish(self.h, y.h))
+
+    def add(self, y):
+        self.start(y); self.finish(y)
+
+    def destroy(self):
+        if self.h:
+            self.L.lib.CeedXHaloDestroy(__import__("ctypes").byref(self.h))
+            self.h = None
+
+
 def interface_elements(mesh: HexMesh, group=None) -> np.ndarray:
     """bool per element: True if the element has a vertex that another rank also holds (its nodes may
     need the halo sum).  Collective; uses global vertex ids only."""
@@ -182,6 +225,57 @@ def slab_cylinder(rank: int, world: int, nr: int, nth: int, nz: int, height_per_
     if rank != world - 1:
         m.side_sets.pop(999, None)
     m.name = f"cylslab{rank}of{world}_{nr}x{nth}x{nz}"
+    return m
+
+
+def part_cylinder(rank: int, world: int, nr: int, nth: int, nz: int, height: float = 10.0) -> HexMesh:
+    """STRONG-scaling workload (BASELINE config 4 as stated: ONE ~99k-element cylinder over the GPUs of the node,
+    src/setupdm.c:57-64): rank's share of the nz element layers of one hollow cylinder (R 0.5-1, `height`), layers
+    [rank nz / world, (rank+1) nz / world).  Global vertex ids; side sets 998 / 999 on the bottom / top rank only."""
+    from .mesh import hollow_cylinder_mesh
+    k0, k1 = rank * nz // world, (rank + 1) * nz // world
+    if k1 <= k0:
+        raise ValueError(f"{nz} element layers cannot be split over {world} ranks")
+    dz = height / nz
+    m = hollow_cylinder_mesh(nr, nth, k1 - k0, z0=-0.5 * height + k0 * dz, z1=-0.5 * height + k1 * dz)
+    per_layer = nth * (nr + 1)
+    m.vertex_gid = (np.arange(m.nvert) // per_layer + k0) * per_layer + np.arange(m.nvert) % per_layer
+    if rank != 0:
+        m.side_sets.pop(998, None)
+    if rank != world - 1:
+        m.side_sets.pop(999, None)
+    m.name = f"cylpart{rank}of{world}_{nr}x{nth}x{nz}"
+    return m
+
+
+def block_grid(world: int):
+    """Blocks per direction for `world` ranks: 8 -> 2x2x2 (BASELINE config 5), 4 -> 2x2x1, 2 -> 2x1x1, else slabs in z."""
+    return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world, (1, 1, world))
+
+
+def part_box(rank: int, world: int, nx: int, ny: int, nz: int) -> HexMesh:
+    """STRONG-scaling box workload (BASELINE config 5: -dm_plex_box_faces 64,64,64 over 8 GPUs): rank's block of ONE
+    nx x ny x nz box cut into block_grid(world) blocks (2x2x2 at 8 ranks: a 193^2-node interface per face at p = 6,
+    against 385^2 per side for z-slabs).  Global vertex ids of the whole box; face sets 1 (z-) / 2 (z+) where the block
+    touches them."""
+    from .mesh import box_mesh
+    bx, by, bz = block_grid(world)
+    ix, iy, iz = rank % bx, (rank // bx) % by, rank // (bx * by)
+    rng = lambda n, b, i: (i * n // b, (i + 1) * n // b)
+    (x0, x1), (y0, y1), (z0, z1) = rng(nx, bx, ix), rng(ny, by, iy), rng(nz, bz, iz)
+    h = 1.0 / nx
+    m = box_mesh(x1 - x0, y1 - y0, z1 - z0, lo=(x0 * h, y0 * h, z0 * h), hi=(x1 * h, y1 * h, z1 * h))
+    lx, ly = x1 - x0 + 1, y1 - y0 + 1
+    v = np.arange(m.nvert)
+    i, j, k = v % lx + x0, (v // lx) % ly + y0, v // (lx * ly) + z0
+    m.vertex_gid = (k * (ny + 1) + j) * (nx + 1) + i
+    if z0 != 0:
+        m.side_sets.pop(1, None)
+    if z1 != nz:
+        m.side_sets.pop(2, None)
+    for sid in [s for s in m.side_sets if s not in (1, 2)]:   # lateral faces: interior cuts are not boundaries (and are never clamped here)
+        m.side_sets.pop(sid, None)
+    m.name = f"boxblock{rank}of{world}_{nx}x{ny}x{nz}"
     return m
 
 

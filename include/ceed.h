@@ -310,6 +310,26 @@ CEED_EXTERN int CeedXCsrDestroy(CeedXCsr *csr);
 CEED_EXTERN int CeedXOperatorSetTiming(CeedOperator op, int enable);
 CEED_EXTERN int CeedXOperatorGetTiming(CeedOperator op, double *ms,
                                        int64_t *launches);
+/* Halo exchange between the element partitions of several GPUs: the replacement */
+/* of DMLocalToGlobal(ADD_VALUES) (src/matops.c:57, :33) for L-vectors whose       */
+/* interface entries are replicated.  RCCL point-to-point over xGMI, one group of  */
+/* sends and receives per exchange on a stream of its own; pack and unpack-add are */
+/* kernels of this library.  Bootstrap as with any NCCL communicator: rank 0 calls */
+/* CeedXCommGetUniqueId, the host program distributes the 128 bytes (MPI_Bcast in  */
+/* the reference's world), every rank calls CeedXCommInit.  `index[k]` lists the   */
+/* `count[k]` L-vector entries shared with rank `neigh_rank[k]` in an order both    */
+/* sides agree on.  Start after the interface nodes are complete (e.g. after       */
+/* CeedXOperatorApplyPhase 0), Finish after the interior work has been queued.     */
+typedef struct CeedXHalo_private *CeedXHalo;
+CEED_EXTERN int CeedXCommGetUniqueId(Ceed ceed, char id[128]);
+CEED_EXTERN int CeedXCommInit(Ceed ceed, int nranks, int rank, const char id[128]);
+CEED_EXTERN int CeedXCommDestroy(Ceed ceed);
+CEED_EXTERN int CeedXHaloCreate(Ceed ceed, CeedInt nneigh, const int *neigh_rank,
+                                const CeedInt *count, const CeedInt *const *index,
+                                CeedXHalo *halo);
+CEED_EXTERN int CeedXHaloStart(CeedXHalo halo, CeedVector y);
+CEED_EXTERN int CeedXHaloFinish(CeedXHalo halo, CeedVector y);
+CEED_EXTERN int CeedXHaloDestroy(CeedXHalo *halo);
 /* Diagnostic: the gated assembly of a residual / Jacobian operator (the      */
 /* restriction transpose run beside the fused kernel).  out[0] items of the    */
 /* transpose map, out[1] rows in them, out[2] cut rows, out[3] items summed by */

@@ -1112,6 +1112,21 @@ int CeedXVectorDot(CeedVector x, CeedVector y, CeedVector weight, double *result
 int CeedXOperatorSetTiming(CeedOperator op, int enable) { (void)op; (void)enable; return 0; }
 int CeedXOperatorGetTiming(CeedOperator op, double *ms, int64_t *launches) { (void)op; *ms = 0; *launches = 0; return 0; }
 int CeedXOperatorGetGatedStats(CeedOperator op, long long out[5]) { (void)op; for (int i = 0; i < 5; i++) out[i] = 0; return 0; }
+/* Halo exchange: the oracle is a single-process CPU checker; the multi-rank tests exchange through torch.distributed
+   (ceedpetscsolid_amd/halo.py, gloo).  Only the neighbour-free halo exists here. */
+struct CeedXHalo_private { int nneigh; };
+int CeedXCommGetUniqueId(Ceed ceed, char id[128]) { (void)ceed; (void)id; return oracle_error("no communicator in the CPU oracle"); }
+int CeedXCommInit(Ceed ceed, int nranks, int rank, const char id[128]) { (void)ceed; (void)rank; (void)id; return nranks == 1 ? 0 : oracle_error("no communicator in the CPU oracle"); }
+int CeedXCommDestroy(Ceed ceed) { (void)ceed; return 0; }
+int CeedXHaloCreate(Ceed ceed, CeedInt nneigh, const int *neigh_rank, const CeedInt *count, const CeedInt *const *index, CeedXHalo *halo) {
+  (void)ceed; (void)neigh_rank; (void)count; (void)index;
+  if (nneigh != 0) return oracle_error("the CPU oracle exchanges no halo (use ceedpetscsolid_amd.halo over gloo)");
+  *halo = (CeedXHalo)calloc(1, sizeof(struct CeedXHalo_private));
+  return 0;
+}
+int CeedXHaloStart(CeedXHalo halo, CeedVector y) { (void)halo; (void)y; return 0; }
+int CeedXHaloFinish(CeedXHalo halo, CeedVector y) { (void)halo; (void)y; return 0; }
+int CeedXHaloDestroy(CeedXHalo *halo) { if (halo && *halo) { free(*halo); *halo = NULL; } return 0; }
 
 /* ---- assembled sparse operator (include/ceed.h, CeedXCsr*): plain CSR on the host ------------ */
 struct CeedXCsr_private {

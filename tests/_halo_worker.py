@@ -18,7 +18,7 @@ def coord_field(X, mask):
 
 def run(rank, world, initfile, outdir, mode):
     from ceedpetscsolid_amd import ceed as cd
-    from ceedpetscsolid_amd.halo import HaloExchange, interface_elements, slab_cylinder
+    from ceedpetscsolid_amd.halo import HaloExchange, interface_elements, part_box, part_cylinder, slab_cylinder
     from ceedpetscsolid_amd.mesh import hollow_cylinder_mesh, partition_slabs, reorder_elements_first, submesh
     from ceedpetscsolid_amd.solid import SolidProblem
     dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
@@ -26,12 +26,16 @@ def run(rank, world, initfile, outdir, mode):
     ceed = cd.Ceed(lib, "/cpu/self/oracle")
     if mode == "slab":        # the weak-scaling generator of bench.py
         mesh = slab_cylinder(rank, world, 2, 6, 2, height_per_rank=2.0)
+    elif mode == "strong-cyl":   # bench.py's strong-scaling form of config 4: uneven layers of ONE cylinder
+        mesh = part_cylinder(rank, world, 2, 6, 5)
+    elif mode == "blocks":       # bench.py's strong-scaling form of config 5: blocks of ONE box (edges shared by four ranks)
+        mesh = part_box(rank, world, 4, 4, 2)
     else:                     # generic partition of one global mesh
         full = hollow_cylinder_mesh(2, 6, 2 * world, z0=-world, z1=world)
         mesh = submesh(full, partition_slabs(full, world)[rank])
     lead = interface_elements(mesh)
     mesh = reorder_elements_first(mesh, lead)          # interface-touching elements lead (split-phase apply)
-    bc = [s for s in (998, 999) if s in mesh.side_sets and len(mesh.side_sets[s])]
+    bc = [s for s in ((1, 2) if mode == "blocks" else (998, 999)) if s in mesh.side_sets and len(mesh.side_sets[s])]
     p = SolidProblem(ceed, mesh, 3, "hyperFS", nu=0.3, E=1.0, bc_sides=bc, multigrid="none")
     lv = p.levels[p.fine]
     n = p.lsize()

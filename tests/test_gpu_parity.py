@@ -333,6 +333,44 @@ def test_extension_free_call_sequence_of_matops(oracle, gpu, memtype):
         assert rel_err(cb, Yc.to_numpy()) < 1e-13, lv
 
 
+def test_halo_exchange_through_rccl_on_one_gpu(product_lib):
+    """CeedXHalo* end to end on ONE GPU: a one-rank RCCL communicator whose only neighbour is the rank itself (ncclSend /
+    ncclRecv to self inside one group is legal), so the library's pack kernel, RCCL's send and receive on the
+    communicator's stream, the event hand-over between the two streams and the unpack-add kernel all run:
+    y[idx] += y[idx].  (Two ranks cannot share this box's single GPU under RCCL; the multi-rank logic is covered by the
+    gloo tests of the same neighbour lists.)"""
+    import ctypes as C
+    ceed = cd.Ceed(product_lib, "/gpu/hip/mi355x")
+    L = ceed.L
+    ident = C.create_string_buffer(128)
+    L.chk(L.lib.CeedXCommGetUniqueId(ceed.h, ident))
+    L.chk(L.lib.CeedXCommInit(ceed.h, 1, 0, ident))
+    n = 200_003
+    rng = np.random.default_rng(8)
+    y0 = rng.uniform(-1, 1, n)
+    lists = [np.sort(rng.choice(n, 50_000, replace=False)).astype(np.int32), rng.permutation(n)[:777].astype(np.int32), np.zeros(0, dtype=np.int32)]
+    ranks = (C.c_int * 3)(0, 0, 0)
+    counts = (C.c_int * 3)(*[a.size for a in lists])
+    ptrs = (C.POINTER(C.c_int) * 3)(*[a.ctypes.data_as(C.POINTER(C.c_int)) for a in lists])
+    h = C.c_void_p()
+    L.chk(L.lib.CeedXHaloCreate(ceed.h, 3, ranks, counts, ptrs, C.byref(h)))
+    Y = ceed.vector(n).set_array(y0)
+    want = y0.copy()
+    for rep in range(3):
+        L.chk(L.lib.CeedXHaloStart(h, Y.h))
+        with pytest.raises(cd.CeedError):                     # one exchange in flight at a time
+            L.chk(L.lib.CeedXHaloStart(h, Y.h))
+        L.chk(L.lib.CeedXHaloFinish(h, Y.h))
+        packed = [want[a].copy() for a in lists]              # all lists are packed BEFORE any is added
+        for a, p in zip(lists, packed):
+            want[a] += p
+        assert np.array_equal(Y.to_numpy(), want), rep
+    with pytest.raises(cd.CeedError):
+        L.chk(L.lib.CeedXHaloFinish(h, Y.h))                  # nothing in flight
+    L.chk(L.lib.CeedXHaloDestroy(C.byref(h)))
+    L.chk(L.lib.CeedXCommDestroy(ceed.h))
+
+
 def test_unsupported_graphs_fail_loudly(gpu):
     with pytest.raises(cd.CeedError):
         gpu.qfunction("SomeUserQFunction", source="user.h:SomeUserQFunction")

@@ -54,6 +54,44 @@ def test_two_rank_jacobian_matches_single_rank(oracle, mode, world):
         assert rel_err(got, yref[idx]) < 1e-12
 
 
+@pytest.mark.parametrize("mode,world", [("strong-cyl", 2), ("blocks", 4)], ids=["config 4 form: uneven layers of one cylinder, 2 ranks",
+                                                                              "config 5 form: 2x2x1 blocks of one box, 4 ranks"])
+def test_strong_scaling_partitions_match_single_rank(oracle, mode, world):
+    """The partitions bench.py --scaling strong runs (halo.part_cylinder / part_box: ONE mesh over the ranks, as BASELINE
+    configs 4 and 5 are stated) against the single-rank apply on the whole mesh; the block partition has nodes shared by
+    four ranks (three additions per node, in neighbour order)."""
+    from ceedpetscsolid_amd.mesh import box_mesh
+    with tempfile.TemporaryDirectory() as d:
+        initfile = os.path.join(d, "init")
+        mp.spawn(_halo_worker.run, args=(world, initfile, d, mode), nprocs=world, join=True)
+        parts = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(world)]
+    full, bc = (hollow_cylinder_mesh(2, 6, 5), [998, 999]) if mode == "strong-cyl" else (box_mesh(4, 4, 2, hi=(1.0, 1.0, 0.5)), [1, 2])
+    p = SolidProblem(oracle, full, 3, "hyperFS", nu=0.3, E=1.0, bc_sides=bc, multigrid="none")
+    lv = p.levels[p.fine]
+    n = p.lsize()
+    xyz = lv.dofmap.node_coords
+    u = 0.05 * np.stack([np.sin(xyz[:, 1]) * xyz[:, 2], np.cos(xyz[:, 0]) * 0.5 * xyz[:, 2], np.sin(xyz[:, 0] + xyz[:, 1])], axis=1).reshape(-1)
+    X, Y = oracle.vector(n), oracle.vector(n)
+    X.set_array(u); p.form_residual(X, Y)
+    x = _halo_worker.coord_field(xyz, lv.mask)
+    X.set_array(x); p.apply_jacobian(p.fine, X, Y)
+    yref = Y.to_numpy().reshape(-1, 3)
+    assert sum(int(part["y"].size) for part in parts) > n            # the interfaces are replicated
+    for part in parts:
+        assert part["nglob"] == p.n_free()
+    assert abs(parts[0]["dot"] - x @ Y.to_numpy()) < 1e-12 * abs(x @ Y.to_numpy())
+    kfull = key_bytes(lv.dofmap.node_keys)
+    order = np.argsort(kfull)
+    for part in parts:
+        kp = key_bytes(part["keys"])
+        shared_kind = part["keys"][:, 0] < 3
+        pos = np.searchsorted(kfull[order], kp[shared_kind])
+        idx = order[pos]
+        assert np.array_equal(kfull[idx], kp[shared_kind])
+        # inputs agree (coordinates of shared vertices are computed per block) and so do the summed outputs
+        assert rel_err(part["y"].reshape(-1, 3)[shared_kind], yref[idx]) < 1e-11
+
+
 @pytest.mark.parametrize("coarse", ["chebyshev", "assembled"])
 def test_two_rank_solve_matches_single_rank(oracle, coarse):
     """The whole Newton - PCG - pMG solve on two element partitions (halo sums after every operator, ownership-
