@@ -230,7 +230,10 @@ constexpr int pencil_minw(int Q) { return Q == 5 ? CPS_PENCIL_MINW5 : CPS_PENCIL
 // FOLD: the folded assembly (FusedGradArgs::as_rowptr) is compiled in -- an instantiation of its own (GEO and EO forms only),
 // so that the default kernel keeps its 203 registers (249 with the stages).
 template <int P, int Q, int QF, bool GEO, bool EO, bool FOLD = false>
-__global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const BasisTables tab_, const FusedGradArgs a) {
+#ifndef CPS_WG4
+#define CPS_WG4 0   // experiment (tools/variants): 256-thread workgroups of four waves, two barriers per group (timing of the lockstep)
+#endif
+__global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pencil(const BasisTables tab_, const FusedGradArgs a) {
   static_assert(offsetof(BasisTables, interp) == 0 && offsetof(BasisTables, colo) == 8 * MAXN1D * MAXN1D &&
                 offsetof(BasisTables, grad) == 16 * MAXN1D * MAXN1D, "kernarg layout of the tables");
   (void)tab_;  // first kernel argument: lives at offset 0 of the kernarg segment, read through kt below
@@ -251,10 +254,10 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
   // Q >= 6 one coefficient table alone (2 Q^2 SGPRs) overflows it and the extra scalar-load waits only cost (measured).
   constexpr bool KA = Q <= 5;
 
-  __shared__ __attribute__((aligned(16))) double slab[E * SE + G::GEO];
-  const ldsp_t lds0 = (lds_double *)slab;
+  __shared__ __attribute__((aligned(16))) double slab[(CPS_WG4 ? 4 : 1) * (E * SE + G::GEO)];
+  const ldsp_t lds0 = (lds_double *)slab + (CPS_WG4 ? (threadIdx.x >> 6) * (E * SE + G::GEO) : 0);
   constexpr bool geo = GEO;   // recompute the geometric factors per point instead of reading qdata (FusedGradArgs::geo set)
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
 
   // ---- work list of this wave -----------------------------------------------------------------------
   // The groups are cut into 8 contiguous chunks, one per XCD (neighbouring elements share their nodes through one L2).
@@ -265,8 +268,10 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
   // following chunks (work stealing, tail balance), so every group is taken whatever the placement.
   const int ngroups = (a.nelem + E - 1) / E;
   const bool dyn = a.queue != nullptr;
+  const int vblock = CPS_WG4 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : (int)blockIdx.x, vgrid = CPS_WG4 ? (int)gridDim.x * 4 : (int)gridDim.x;
   const int nxcd = (dyn || gridDim.x % 8 == 0) ? 8 : 1;
-  const int wrank = blockIdx.x / nxcd, wper = gridDim.x / nxcd;
+  // (CPS_WG4: the four waves of a workgroup take four CONSECUTIVE groups of the workgroup's chunk -- one block of 8 elements)
+  const int wrank = CPS_WG4 ? (int)(blockIdx.x / nxcd) * 4 + (int)(threadIdx.x >> 6) : vblock / nxcd, wper = vgrid / nxcd;
   const int gend = dyn ? 0 : min(ngroups, (int)(blockIdx.x % nxcd + 1) * ((ngroups + nxcd - 1) / nxcd));   // static schedule only
   // dynamic schedule: all the wave keeps is  home XCD | chunk it takes from << 4 | chunks it has moved on << 8  (everything
   // else is re-derived from the launch arguments where it is used: the scalar register file is full, see the table passes)
@@ -802,6 +807,9 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     pencil_pass<Q, P, P, true, BJ, oA, oA, +1, EO>(tBt, aJP, lane, E * T_JP);    // B4: along j
     pencil_pass<Q, P, P, true, BI, oA, oA, +1, EO>(tBt, aIP, lane, E * T_IP);    // B5: along i
 #endif
+#if CPS_WG4
+    __syncthreads();
+#endif
     // ---- final: node owners -> E-vector (plain coalesced stores) or f64 atomics ---------------------------
     {
       double v[RN][3];
@@ -840,6 +848,9 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
         }
       }
     }
+#if CPS_WG4
+    __syncthreads();
+#endif
     if (fold) as_stage4(fr);
     g_prev = grp;
     if (!more) break;
@@ -899,17 +910,18 @@ hipError_t launch_fused_pencil_t(const BasisTables &t, const FusedGradArgs &a, h
   if (!wpc) { const char *e = getenv("CEED_MI355X_PENCIL_WAVES"); wpc = e && atoi(e) > 0 ? atoi(e) : -1; }
   int grid = ncu * (wpc > 0 ? wpc : pencil_waves_per_cu<P, Q>());
   if (grid > ngroups) grid = ngroups;
+  if (CPS_WG4) grid = (grid / 32) * 8;   // workgroups of four waves, a multiple of 8
   if constexpr (Q <= 5) {
     if (a.geo && a.eo_ok && a.as_rowptr) {
-      hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true, true, true>), dim3(grid), dim3(64), 0, s, t, a);
+      hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true, true, true>), dim3(grid), dim3(CPS_WG4 ? 256 : 64), 0, s, t, a);
       return hipGetLastError();
     }
   }
   // (a.as_rowptr set but no folded instantiation for this form: the kernel sums nothing and k_assemble_tail sums every item)
-  if (a.geo && a.eo_ok) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true, true>), dim3(grid), dim3(64), 0, s, t, a);
-  else if (a.geo) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true, false>), dim3(grid), dim3(64), 0, s, t, a);
-  else if (a.eo_ok) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, false, true>), dim3(grid), dim3(64), 0, s, t, a);
-  else hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, false, false>), dim3(grid), dim3(64), 0, s, t, a);
+  if (a.geo && a.eo_ok) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true, true>), dim3(grid), dim3(CPS_WG4 ? 256 : 64), 0, s, t, a);
+  else if (a.geo) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true, false>), dim3(grid), dim3(CPS_WG4 ? 256 : 64), 0, s, t, a);
+  else if (a.eo_ok) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, false, true>), dim3(grid), dim3(CPS_WG4 ? 256 : 64), 0, s, t, a);
+  else hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, false, false>), dim3(grid), dim3(CPS_WG4 ? 256 : 64), 0, s, t, a);
   return hipGetLastError();
 }
 
