@@ -93,7 +93,11 @@ def hollow_cylinder_mesh(nr: int, nth: int, nz: int, r_in=0.5, r_out=1.0, z0=-5.
 
 
 def read_exodus(path: str) -> HexMesh:
-    """HEX8 Exodus II (NetCDF classic CDF-2) reader for the reference's ``meshes/*.exo``."""
+    """Exodus II (NetCDF classic CDF-2) reader for the reference's ``meshes/*.exo``: HEX8 blocks, and HEX27 blocks through
+    their eight corner nodes (the first eight of an Exodus HEX27; the mid-edge / mid-face / centre nodes carry no
+    information for an isoparametric trilinear geometry and are dropped).  Boundaries: side sets (``*_ss_*``), or -- the
+    ``*_ns_*`` files, SURVEY App. D -- node sets, turned into side sets: an element face belongs to set ``id`` when
+    all four of its corner nodes do."""
     from scipy.io import netcdf_file
     f = netcdf_file(path, "r", mmap=False)
     v = f.variables
@@ -105,9 +109,9 @@ def read_exodus(path: str) -> HexMesh:
     b = 1
     while f"connect{b}" in v:
         c = np.array(v[f"connect{b}"][:], dtype=np.int64) - 1
-        if c.shape[1] != 8:
-            raise ValueError(f"{path}: block {b} is not HEX8")
-        conn.append(c)
+        if c.shape[1] not in (8, 27):
+            raise ValueError(f"{path}: block {b} is neither HEX8 nor HEX27")
+        conn.append(c[:, :8])
         b += 1
     cells = np.concatenate(conn, axis=0)[:, _EXO_TO_TENSOR]
     ss: Dict[int, np.ndarray] = {}
@@ -117,7 +121,27 @@ def read_exodus(path: str) -> HexMesh:
             el = np.array(v[f"elem_ss{k}"][:], dtype=np.int64) - 1
             sd = np.array(v[f"side_ss{k}"][:], dtype=np.int64)
             ss[int(sid)] = np.stack([el, np.array([_EXO_SIDE_TO_FACE[int(s)] for s in sd])], axis=1)
+    node_sets = {}
+    if "ns_prop1" in v:
+        for k, sid in enumerate(np.array(v["ns_prop1"][:], dtype=np.int64), start=1):
+            node_sets[int(sid)] = np.array(v[f"node_ns{k}"][:], dtype=np.int64) - 1
     f.close()
+    used = np.unique(cells)                       # HEX27: keep the corner vertices only
+    if used.size != coords.shape[0]:
+        renum = np.full(coords.shape[0], -1, dtype=np.int64)
+        renum[used] = np.arange(used.size)
+        cells, coords = renum[cells], coords[used]
+        node_sets = {sid: renum[ns][renum[ns] >= 0] for sid, ns in node_sets.items()}
+    for sid, ns in node_sets.items():
+        inset = np.zeros(coords.shape[0], dtype=bool)
+        inset[ns] = True
+        faces = []
+        for face in range(6):                       # local faces as in box_mesh: 0 x-, 1 x+, 2 y-, 3 y+, 4 z-, 5 z+
+            axis, side = face // 2, face % 2
+            corners = [c for c in range(8) if ((c >> axis) & 1) == side]
+            el = np.nonzero(inset[cells[:, corners]].all(axis=1))[0]
+            faces.append(np.stack([el, np.full(el.size, face)], axis=1))
+        ss.setdefault(sid, np.concatenate(faces, axis=0))
     mesh = HexMesh(coords, cells, ss, name=path.split("/")[-1])
     _fix_orientation(mesh)
     return mesh
