@@ -31,6 +31,7 @@ struct CeedData_private {  // elasticity.h:218-240 (the members the path uses)
   CeedOperator opJacob = nullptr, opProlong = nullptr, opRestrict = nullptr;
   CeedVector xceed = nullptr, yceed = nullptr, multVec = nullptr;
   CeedInt Ulocsz = 0;
+  CeedXHalo halo = nullptr;   // several GPUs: the interface sum of this level's L-vectors (borrowed; SolidAppSetHalo)
 };
 
 struct SolidApp_private {
@@ -233,21 +234,33 @@ extern "C" int SolidAppDestroy(SolidApp *papp) {  // CeedDataDestroy, setuplibce
 extern "C" int ApplyLocalCeedOp(SolidApp, CeedOperator op, CeedVector X, CeedVector Y) {
   return CeedOperatorApply(op, X, Y, CEED_REQUEST_IMMEDIATE);
 }
+// DMLocalToGlobal(ADD_VALUES) (matops.c:57,153,199,238) and the DMGlobalToLocal of the next use, across the GPUs of the
+// node: one neighbour sum on the replicated interface entries (CeedXHalo*, RCCL); nothing to do on one GPU.
+static int LocalToGlobalAdd(SolidApp app, CeedInt level, CeedVector Y) {
+  CeedXHalo h = app->data[level].halo;
+  if (!h) return 0;
+  CHK(CeedXHaloStart(h, Y));
+  return CeedXHaloFinish(h, Y);
+}
 // matops.c:63-79: X carries the boundary values inserted at the current load increment
 extern "C" int FormResidual_Ceed(SolidApp app, CeedVector X, CeedVector Y) {
-  return ApplyLocalCeedOp(app, app->opApply, X, Y);
+  CHK(ApplyLocalCeedOp(app, app->opApply, X, Y));
+  return LocalToGlobalAdd(app, app->numLevels - 1, Y);
 }
 // matops.c:98-112
 extern "C" int ApplyJacobian_Ceed(SolidApp app, CeedInt level, CeedVector X, CeedVector Y) {
-  return ApplyLocalCeedOp(app, app->data[level].opJacob, X, Y);
+  CHK(ApplyLocalCeedOp(app, app->data[level].opJacob, X, Y));
+  return LocalToGlobalAdd(app, level, Y);
 }
 // matops.c:115-157 (level-1 -> level)
 extern "C" int Prolong_Ceed(SolidApp app, CeedInt level, CeedVector Xc, CeedVector Yf) {
-  return CeedOperatorApply(app->data[level].opProlong, Xc, Yf, CEED_REQUEST_IMMEDIATE);
+  CHK(CeedOperatorApply(app->data[level].opProlong, Xc, Yf, CEED_REQUEST_IMMEDIATE));
+  return LocalToGlobalAdd(app, level, Yf);
 }
 // matops.c:160-203 (level -> level-1)
 extern "C" int Restrict_Ceed(SolidApp app, CeedInt level, CeedVector Xf, CeedVector Yc) {
-  return CeedOperatorApply(app->data[level].opRestrict, Xf, Yc, CEED_REQUEST_IMMEDIATE);
+  CHK(CeedOperatorApply(app->data[level].opRestrict, Xf, Yc, CEED_REQUEST_IMMEDIATE));
+  return LocalToGlobalAdd(app, level - 1, Yc);
 }
 // matops.c:206-244, including the context swap for -nu_smoother (:215-217, :231-232)
 extern "C" int GetDiag_Ceed(SolidApp app, CeedInt level, CeedVector D) {
@@ -255,6 +268,13 @@ extern "C" int GetDiag_Ceed(SolidApp app, CeedInt level, CeedVector D) {
   if (app->useSmootherPhys) CHK(CeedQFunctionSetContext(d.qfJacob, &app->physSmoother, sizeof(app->physSmoother)));
   CHK(CeedOperatorLinearAssembleDiagonal(d.opJacob, D, CEED_REQUEST_IMMEDIATE));
   if (app->useSmootherPhys) CHK(CeedQFunctionSetContext(d.qfJacob, &app->phys, sizeof(app->phys)));
+  return LocalToGlobalAdd(app, level, D);
+}
+// Several GPUs: the halo of level `level` (created by the caller with CeedXHaloCreate from the partition's neighbour
+// lists; borrowed, NULL clears).  From then on every matops function above ends with the interface sum.
+extern "C" int SolidAppSetHalo(SolidApp app, CeedInt level, CeedXHalo halo) {
+  if (level < 0 || level >= app->numLevels) return 1;
+  app->data[level].halo = halo;
   return 0;
 }
 extern "C" int SolidAppSetSmootherNu(SolidApp app, double nu_smoother) {

@@ -119,6 +119,12 @@ class SolidApp:
     def get_diag(self, level: int, d: cd.Vector):
         self.ceed.L.chk(self.H.GetDiag_Ceed(self.h, C.c_int32(level), d.h))
 
+    def set_halo(self, level: int, halo):
+        """Attach the interface sum of one level (a halo.RcclHalo or a raw CeedXHalo handle; None clears): every matops
+        function then ends with it, as the reference's end with DMLocalToGlobal(ADD_VALUES)."""
+        h = None if halo is None else getattr(halo, "h", halo)
+        self.ceed.L.chk(self.H.SolidAppSetHalo(self.h, C.c_int32(level), h))
+
     def set_smoother_nu(self, nu: float):
         self.ceed.L.chk(self.H.SolidAppSetSmootherNu(self.h, C.c_double(nu)))
 

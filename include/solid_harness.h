@@ -46,6 +46,10 @@ CEED_EXTERN int GetDiag_Ceed(SolidApp app, CeedInt level, CeedVector D);        
 /* -nu_smoother (matops.c:215-232): Poisson ratio used only while assembling the diagonal; < 0 clears */
 CEED_EXTERN int SolidAppSetSmootherNu(SolidApp app, double nu_smoother);
 
+/* Several GPUs: attach the interface sum of one level (CeedXHalo*, include/ceed.h).  Every function above then ends with
+ * it, as the reference's end with DMLocalToGlobal(ADD_VALUES) (matops.c:57,153,199,238). */
+CEED_EXTERN int SolidAppSetHalo(SolidApp app, CeedInt level, CeedXHalo halo);
+
 /* accessors for tests / drivers */
 CEED_EXTERN int SolidAppGetVectors(SolidApp app, CeedVector *qdata, CeedVector *gradu);
 CEED_EXTERN int SolidAppGetLevelOperators(SolidApp app, CeedInt level, CeedOperator *opJacob,

@@ -367,6 +367,27 @@ def test_halo_exchange_through_rccl_on_one_gpu(product_lib):
         assert np.array_equal(Y.to_numpy(), want), rep
     with pytest.raises(cd.CeedError):
         L.chk(L.lib.CeedXHaloFinish(h, Y.h))                  # nothing in flight
+    # the same halo under the C++ harness: ApplyJacobian_Ceed ends with the interface sum (DMLocalToGlobal(ADD_VALUES), matops.c:57)
+    from ceedpetscsolid_amd.harness import SolidApp
+    mesh = distorted_box(3, 3, 2)
+    app = SolidApp(ceed, mesh, 2, "hyperFS", nu=0.3, E=1.0, bc_sides=[1], multigrid="none")
+    nl = app.lsize()
+    X, Y1, Y2 = ceed.vector(nl), ceed.vector(nl), ceed.vector(nl)
+    X.set_array(np.linspace(0.0, 0.05, nl)); app.form_residual(X, Y1)
+    X.set_array(rng.uniform(-1, 1, nl))
+    app.apply_jacobian(app.fine, X, Y1)
+    sub = np.sort(rng.choice(nl, nl // 3, replace=False)).astype(np.int32)
+    hh = C.c_void_p()
+    L.chk(L.lib.CeedXHaloCreate(ceed.h, 1, (C.c_int * 1)(0), (C.c_int * 1)(sub.size), (C.POINTER(C.c_int) * 1)(sub.ctypes.data_as(C.POINTER(C.c_int))), C.byref(hh)))
+    app.set_halo(app.fine, hh)
+    app.apply_jacobian(app.fine, X, Y2)
+    y1, y2 = Y1.to_numpy(), Y2.to_numpy()
+    expect = y1.copy(); expect[sub] += y1[sub]
+    assert np.array_equal(y2, expect)
+    app.set_halo(app.fine, None)
+    app.apply_jacobian(app.fine, X, Y2)
+    assert np.array_equal(Y2.to_numpy(), y1)
+    L.chk(L.lib.CeedXHaloDestroy(C.byref(hh)))
     L.chk(L.lib.CeedXHaloDestroy(C.byref(h)))
     L.chk(L.lib.CeedXCommDestroy(ceed.h))
 
