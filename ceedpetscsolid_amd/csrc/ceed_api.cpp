@@ -144,6 +144,7 @@ struct GatedMap {
   bool built = false;
   int E = 0, skipP = 0, nb = 0, bucket_shift = 0, nitems = 0, nrows_local = 0, nrows = 0, nskipped = 0;
   int evec_stride = 0;   // doubles per element block of the E-vector: whole 128-byte lines
+  int item_rows = 0, max_contrib = 0;   // rows per item; rows with more contributors are cut rows (0: no limit)
   bool full_cover = false;
   int item_begin[9] = {0};
   std::vector<uint32_t> h_node_off;   // re-ordered (for the per-operator Dirichlet flags)
@@ -890,13 +891,13 @@ static bool rstr_interior_private(CeedElemRestriction r, int P) {
   return true;
 }
 // Re-order the transpose map `M` (shell or full) of restriction r for the gated assembly with groups of E elements.
-static int build_gated(CeedElemRestriction r, const CsrMap &M, int E, int skipP, GatedMap &G) {
-  if (G.built && G.E == E && G.skipP == skipP) return 0;
+static int build_gated(CeedElemRestriction r, const CsrMap &M, int E, int skipP, int item_rows, int max_contrib, GatedMap &G) {
+  if (G.built && G.E == E && G.skipP == skipP && G.item_rows == item_rows && G.max_contrib == max_contrib) return 0;
   if (r->ceed->capturing)
     return ceed_error("first apply of an operator during graph capture: its restriction's transpose map is built on the host; "
                       "apply the operator once before recording");
   G.release();
-  G.E = E; G.skipP = skipP; G.nskipped = M.nskipped; G.full_cover = M.full_cover;
+  G.E = E; G.skipP = skipP; G.nskipped = M.nskipped; G.full_cover = M.full_cover; G.item_rows = item_rows; G.max_contrib = max_contrib;
   const int per_elem = skipP > 0 ? element_shell_size(skipP) : r->elemsize;
   G.evec_stride = ((3 * per_elem * 8 + 127) / 128) * 128 / 8;
   if ((size_t)r->nelem * (size_t)G.evec_stride > 0xFFFFFFFFull) return ceed_error("E-vector of %d elements exceeds the 32-bit index of the gated transpose map", r->nelem);
@@ -919,7 +920,7 @@ static int build_gated(CeedElemRestriction r, const CsrMap &M, int E, int skipP,
     const uint32_t efirst = cols[rowptr[i]] / (uint32_t)per_elem, elast = cols[rowptr[i + 1] - 1] / (uint32_t)per_elem;   // element order
     const uint32_t gf = efirst / (uint32_t)E, gl = elast / (uint32_t)E, cf = gf / (uint32_t)chunk, cl = gl / (uint32_t)chunk;
     key[i] = cf == cl ? cl * (uint32_t)G.nb + ((gl - cl * (uint32_t)chunk) >> G.bucket_shift) : cutkey;
-    if (rowptr[i + 1] - rowptr[i] > 4u) key[i] = cutkey;   // more than four contributors (vertices, irregular nodes): summed by the tail kernel
+    if (max_contrib > 0 && rowptr[i + 1] - rowptr[i] > (uint32_t)max_contrib) key[i] = cutkey;   // folded form: more than four contributors (vertices, irregular nodes) are the tail kernel's
     cnt[key[i] + 1]++;
   }
   for (size_t k = 0; k + 1 < cnt.size(); k++) cnt[k + 1] += cnt[k];   // cnt[k] = first new row of key k
@@ -946,7 +947,7 @@ static int build_gated(CeedElemRestriction r, const CsrMap &M, int E, int skipP,
     for (int b = 0; b < G.nb; b++) {
       bgroups[(size_t)c * G.nb + b] = (uint32_t)std::max(0, std::min(BG, cg - b * BG));
       const uint32_t k = (uint32_t)c * (uint32_t)G.nb + (uint32_t)b;
-      for (uint32_t r0 = cnt[k]; r0 < cnt[k + 1]; r0 += GATED_ITEM_ROWS) { item_row.push_back(r0); item_bucket.push_back((uint32_t)b); }
+      for (uint32_t r0 = cnt[k]; r0 < cnt[k + 1]; r0 += (uint32_t)item_rows) { item_row.push_back(r0); item_bucket.push_back((uint32_t)b); }
       bitems[(size_t)c * G.nb + b] = (uint32_t)((int)item_bucket.size() - G.item_begin[c]);   // items waiting for bucket <= b
     }
   }
@@ -1272,7 +1273,8 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
     GatedAsmArgs ga{};
     if (gated) {
       GatedMap &G = r->gated;
-      CHK(build_gated(r, *M, pencil_group_elems(ai.basis->Q1d), direct ? ai.basis->P1d : 0, G));
+      const bool fold_form = c->folded_assembly;
+      CHK(build_gated(r, *M, pencil_group_elems(ai.basis->Q1d), direct ? ai.basis->P1d : 0, fold_form ? GATED_ITEM_ROWS : GATED_ITEM_ROWS_BESIDE, fold_form ? 4 : 0, G));
       if (!op->d_node_flags_gated && op->h_mask.empty()) {   // no Dirichlet mask: all-zero flags (the folded stages read them unconditionally)
         HIPCHK(hipMalloc((void **)&op->d_node_flags_gated, (size_t)(G.nrows ? G.nrows : 1)));
         HIPCHK(hipMemset(op->d_node_flags_gated, 0, (size_t)(G.nrows ? G.nrows : 1)));
@@ -1295,7 +1297,7 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
       ga.bucket_groups = G.d_bucket_groups; ga.bucket_items = G.d_bucket_items;
       for (int i = 0; i < 9; i++) ga.item_begin[i] = G.item_begin[i];
       ga.nb = G.nb; ga.nitems = G.nitems; ga.nrows_local = G.nrows_local; ga.nrows = G.nrows;
-      ga.max_spins = c->gated_spins;
+      ga.max_spins = c->gated_spins; ga.item_rows = G.item_rows;
       if (c->folded_assembly) {
         a.as_rowptr = G.d_rowptr; a.as_cols = G.d_cols; a.as_node_off = G.d_node_off; a.as_item_row = G.d_item_row;
         a.as_bucket_items = G.d_bucket_items; a.as_flags = op->d_node_flags_gated; a.as_max_spins = c->gated_spins;
@@ -1324,10 +1326,10 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
       HIPCHK(hipEventRecord(c->ev_fork, s));
       HIPCHK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
     }
-    // Gated: the LONG kernel goes to the side stream and the chain that depends on it (gated assembly, tail) stays on the
-    // Ceed's stream, so that the only cross-stream wait on the critical path is the fork at the start (the event the tail
-    // waits for has fired ~15 us before the gated kernel ends).  Measured against fused-on-main / join-before-tail: -12 us.
-    hipError_t e = launch_fused_grad(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, a, (gated && !folded) ? c->side_stream : s, kname);
+    // Gated: the fused kernel FIRST and on the Ceed's stream -- its eight waves per CU must be resident before the assembler's
+    // arrive (launched the other way round, the assembler's waves took registers first and the fused kernel ran at
+    // reduced occupancy: 431-508 us instead of 406-416) -- the assembler on the side stream, the tail behind the join.
+    hipError_t e = launch_fused_grad(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, a, s, kname);
     if (e == hipErrorInvalidValue && !**kname)
       return ceed_error("no fused kernel instantiated for P=%d Q=%d QFunction %s", ai.basis->P1d, ai.basis->Q1d, qf->name.c_str());
     HIPCHK(e);
@@ -1337,8 +1339,8 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
       // launched AFTER the fused kernel, which never waits for it: whatever the queues do, the fused kernel completes;
       // the gated kernel's waits are bounded and the tail kernel finishes whatever it left
       static const int dbg = getenv("CEED_MI355X_GATED_DEBUG") ? atoi(getenv("CEED_MI355X_GATED_DEBUG")) : 0;   // bring-up only
-      HIPCHK(hipEventRecord(c->ev_join, c->side_stream));                 // fused kernel done
-      if (!(dbg & 1)) HIPCHK(launch_assemble_gated(ga, c->gated_waves, s));
+      if (!(dbg & 1)) HIPCHK(launch_assemble_gated(ga, c->gated_waves, c->side_stream));
+      HIPCHK(hipEventRecord(c->ev_join, c->side_stream));
       HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
       if (!(dbg & 2)) HIPCHK(launch_assemble_tail(ga, s));
     } else if (use_evec) {  // timed together with the fused kernel: the launches ARE the operator apply

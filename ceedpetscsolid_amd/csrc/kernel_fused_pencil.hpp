@@ -258,6 +258,9 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
   const ldsp_t lds0 = (lds_double *)slab + (CPS_WG4 ? (threadIdx.x >> 6) * (E * SE + G::GEO) : 0);
   constexpr bool geo = GEO;   // recompute the geometric factors per point instead of reading qdata (FusedGradArgs::geo set)
   const int lane = threadIdx.x & 63;
+#ifdef CPS_SETPRIO   // experiment (tools/variants): static priority for every other workgroup of an XCD (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+  if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(CPS_SETPRIO);
+#endif
 
   // ---- work list of this wave -----------------------------------------------------------------------
   // The groups are cut into 8 contiguous chunks, one per XCD (neighbouring elements share their nodes through one L2).

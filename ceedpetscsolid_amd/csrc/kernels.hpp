@@ -183,7 +183,9 @@ hipError_t launch_diag(int P, int Q, int qf, const BasisTables &t, const DiagArg
 // after both, the cut rows and every item the gated kernel did not finish (buckets with groups stolen by another XCD,
 // waves that never became resident) and resets the control block.  Correctness never depends on co-residency or on
 // the placement of workgroups: only the speed does.
-constexpr int GATED_ITEM_ROWS = 64;    // rows per item: one per lane of the wave that sums it (two per lane: the 48 value registers spilled in the folded form)
+constexpr int GATED_ITEM_ROWS = 64;    // rows per item of the FOLDED form: one per lane of the wave that sums it (two per lane: the 48 value
+                                       // registers spilled); the gated form uses items of GATED_ITEM_ROWS_BESIDE rows
+constexpr int GATED_ITEM_ROWS_BESIDE = 256;
 struct GatedCtrl {   // uint32 offsets into the control block (zero before the first launch; the tail kernel re-zeroes it)
   static constexpr int QUEUE = 0, AHEAD = 8 * QUEUE_STRIDE, READY = 16 * QUEUE_STRIDE, FRONT = 24 * QUEUE_STRIDE, DONE = 32 * QUEUE_STRIDE;
   static constexpr unsigned STOP = 0x80000000u;   // READY word: the gatekeeper has given up (foreign groups ahead, time-out)
@@ -205,6 +207,7 @@ struct GatedAsmArgs {
   int item_begin[9];
   int nb, nitems, nrows_local, nrows;        // rows [nrows_local, nrows) are the cut rows
   int max_spins;                             // bound of the gated kernel's wait for one bucket (then the tail kernel takes over)
+  int item_rows;                             // rows per item at most (64 or 256): the tail kernel's block size
   int dbg;                                   // bring-up switches (CEED_MI355X_GATED_KDBG): 1 L1-bypassing E-vector loads, 2 no frontier wait, 4 static items
 };
 hipError_t launch_assemble_gated(const GatedAsmArgs &a, int waves_per_cu, hipStream_t s);

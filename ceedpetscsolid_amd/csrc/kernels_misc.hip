@@ -403,6 +403,40 @@ CPS_DEV void assemble_row(const GatedAsmArgs &a, int r) {
   double *dst = a.y + (a.node_off[r] & OFF_MASK);
   dst[0] = (fl & 1u) ? 0. : a0; dst[1] = (fl & 2u) ? 0. : a1; dst[2] = (fl & 4u) ? 0. : a2;
 }
+// two rows at once (the second may be absent: rb < 0): both rows' dependent load levels (row pointers, columns, values)
+// are issued together, which halves the exposed latency per row of a wave that sums its rows one after the other
+CPS_DEV void assemble_rows2(const GatedAsmArgs &a, int ra, int rb) {
+  const bool two = rb >= 0;
+  const int rB = two ? rb : ra;
+  const uint32_t ka0 = a.rowptr[ra], ka1 = a.rowptr[ra + 1], kb0 = a.rowptr[rB], kb1 = two ? a.rowptr[rB + 1] : kb0;
+  const uint32_t noa = a.node_off[ra], nob = a.node_off[rB];
+  const unsigned fla = a.flags ? a.flags[ra] : 0u, flb = a.flags ? a.flags[rB] : 0u;
+  double sa[3] = {0., 0., 0.}, sb[3] = {0., 0., 0.};
+  for (uint32_t t = 0; ka0 + t < ka1 || kb0 + t < kb1; t += 4) {
+    uint32_t ca[4], cb[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      ca[j] = a.cols[min(ka0 + t + (uint32_t)j, max(ka1, ka0 + 1u) - 1u)];
+      cb[j] = a.cols[min(kb0 + t + (uint32_t)j, max(kb1, kb0 + 1u) - 1u)];
+    }
+    double va[4][3], vb[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int d = 0; d < 3; d++) { va[j][d] = a.evec[ca[j] + d]; vb[j][d] = a.evec[cb[j] + d]; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (ka0 + t + (uint32_t)j < ka1) { sa[0] += va[j][0]; sa[1] += va[j][1]; sa[2] += va[j][2]; }
+      if (kb0 + t + (uint32_t)j < kb1) { sb[0] += vb[j][0]; sb[1] += vb[j][1]; sb[2] += vb[j][2]; }
+    }
+  }
+  double *da = a.y + (noa & OFF_MASK);
+  da[0] = (fla & 1u) ? 0. : sa[0]; da[1] = (fla & 2u) ? 0. : sa[1]; da[2] = (fla & 4u) ? 0. : sa[2];
+  if (two) {
+    double *db = a.y + (nob & OFF_MASK);
+    db[0] = (flb & 1u) ? 0. : sb[0]; db[1] = (flb & 2u) ? 0. : sb[1]; db[2] = (flb & 4u) ? 0. : sb[2];
+  }
+}
 // Persistent single-wave workgroups beside the fused kernel.  Every wait is bounded: a wave that gives up (or never runs)
 // leaves its items to k_assemble_tail.
 __global__ __launch_bounds__(64) void k_assemble_gated(const GatedAsmArgs a) {
@@ -461,14 +495,16 @@ __global__ __launch_bounds__(64) void k_assemble_gated(const GatedAsmArgs a) {
     if (a.dbg & 8) continue;   // bring-up: waiting only, the rows are left to the tail kernel
     const int r0 = (int)a.item_row[it], r1 = (int)a.item_row[it + 1];
     if (a.dbg & 1) { for (int r = r0 + lane; r < r1; r += 64) assemble_row<true>(a, r); }
-    else { for (int r = r0 + lane; r < r1; r += 64) assemble_row<false>(a, r); }
+    else {
+      for (int r = r0 + lane; r < r1; r += 128) assemble_rows2(a, r, r + 64 < r1 ? r + 64 : -1);   // two rows' load chains in flight
+    }
     if (lane == 0) item_done[it] = 1u;
   }
 }
 // After the fused and the gated kernel: block j < ceil(nitems / TAIL_ITEMS) looks at TAIL_ITEMS items and sums those the gated
 // kernel did not; the blocks behind sum the cut rows; the control block is zeroed for the next apply.
 constexpr int TAIL_ITEMS = 1;   // (16 per block made the tail 3x slower: the undone items sit together at the end of a chunk and were then summed one after the other)
-__global__ __launch_bounds__(GATED_ITEM_ROWS) void k_assemble_tail(const GatedAsmArgs a) {
+__global__ __launch_bounds__(GATED_ITEM_ROWS_BESIDE) void k_assemble_tail(const GatedAsmArgs a) {   // blockDim.x = a.item_rows
   unsigned *item_done = a.ctrl + GatedCtrl::item_done(a.nb);
   const int j = blockIdx.x, nib = (a.nitems + TAIL_ITEMS - 1) / TAIL_ITEMS;
   if (j == 0) {
@@ -491,7 +527,7 @@ __global__ __launch_bounds__(GATED_ITEM_ROWS) void k_assemble_tail(const GatedAs
       if (threadIdx.x == 0) atomicAdd(a.ctrl + GatedCtrl::stats(a.nb, a.nitems), 1u);
     }
   } else {
-    const int r = a.nrows_local + (j - nib) * GATED_ITEM_ROWS + threadIdx.x;
+    const int r = a.nrows_local + (j - nib) * (int)blockDim.x + threadIdx.x;
     if (r < a.nrows) assemble_row<false>(a, r);
   }
 }
@@ -512,9 +548,10 @@ hipError_t launch_assemble_gated(const GatedAsmArgs &a, int waves_per_cu, hipStr
 }
 hipError_t launch_assemble_tail(const GatedAsmArgs &a, hipStream_t s) {
   const int ncut = a.nrows - a.nrows_local;
-  int grid = (a.nitems + TAIL_ITEMS - 1) / TAIL_ITEMS + (ncut + GATED_ITEM_ROWS - 1) / GATED_ITEM_ROWS;
+  const int bs = a.item_rows > 0 ? a.item_rows : GATED_ITEM_ROWS;
+  int grid = (a.nitems + TAIL_ITEMS - 1) / TAIL_ITEMS + (ncut + bs - 1) / bs;
   if (grid < 1) grid = 1;   // block 0 zeroes the control block (the fused kernel's ticket counters live there)
-  hipLaunchKernelGGL(k_assemble_tail, dim3(grid), dim3(GATED_ITEM_ROWS), 0, s, a);
+  hipLaunchKernelGGL(k_assemble_tail, dim3(grid), dim3(bs), 0, s, a);
   return hipGetLastError();
 }
 
