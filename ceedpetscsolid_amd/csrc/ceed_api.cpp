@@ -358,9 +358,10 @@ extern "C" int CeedXGraphDestroy(CeedXGraph *graph) {
 // CeedVector: host and device mirrors with validity flags
 // ---------------------------------------------------------------------------
 static size_t vbytes(CeedVector v) { return sizeof(double) * (size_t)(v->length > 0 ? v->length : 1); }
-// Zero `n` doubles on the Ceed's stream.  While a hipGraph is being recorded this is a fill KERNEL, not
-// hipMemsetAsync: on ROCm 7.2 a recorded memset node was observed to lose its ordering against the
-// neighbouring kernel nodes on replay (tools/graph_replay_check.py), kernel nodes do not.
+// Zero `n` doubles on the Ceed's stream.  While a hipGraph is being recorded this is a fill KERNEL rather than a memset node
+// (same cost).  Round 1 had blamed a wrong replay on recorded memset nodes losing their order; a library-free reproducer
+// (tools/microbench/graph_memset_repro.hip) and this library with CEED_MI355X_GRAPH_MEMSET=1 both replay correctly: the
+// cause was the scratch E-vector being re-allocated under recorded nodes (see ceed_need_evec).
 static int dev_zero(Ceed c, double *p, size_t n) {
   if (!n) return 0;
   static const bool memset_nodes = getenv("CEED_MI355X_GRAPH_MEMSET") && atoi(getenv("CEED_MI355X_GRAPH_MEMSET"));   // A/B: tools/graph_replay_check.py

@@ -1,7 +1,9 @@
 """hipGraph replay check for the multigrid V-cycle (CeedXGraph*): replay == eager, before and after
-unrelated eager work on the same operators.  History: with hipMemsetAsync recorded as memset nodes
-(ROCm 7.2) the replay went wrong after any eager Jacobian apply in between -- the zero-fill no longer
-ordered against its neighbours; ceed_api.cpp now records a fill kernel instead (dev_zero)."""
+unrelated eager work on the same operators.  History: round 1 saw a wrong replay after an eager Jacobian
+apply in between and blamed recorded memset nodes; round 2 could not reproduce that in isolation
+(tools/microbench/graph_memset_repro.hip) and this check passes with memset nodes too
+(CEED_MI355X_GRAPH_MEMSET=1): the cause was the scratch E-vector being re-allocated under recorded
+nodes, fixed by parking it (ceed_need_evec)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -19,3 +19,6 @@ run hyperSS --problem hyperSS
 run linElas --problem linElas
 run p6box32 --workload box --degree 6 --nr 32 --nth 32 --nz 32
 run p2box96 --workload box --degree 2 --nr 96 --nth 96 --nz 96
+run config5_whole --workload box --degree 6 --nr 64 --nth 64 --nz 64
+run p1box128 --workload box --degree 1 --nr 128 --nth 128 --nz 128
+run p3box64 --workload box --degree 3 --nr 64 --nth 64 --nz 64
