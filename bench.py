@@ -323,7 +323,7 @@ def main():
                                     f"degree {args.degree}, Q={Q}, z faces clamped, Jacobian apply y=J(u)x"),
                        "global_dofs": n_global, "elements_per_gpu": mesh.nelem, "ldofs_per_gpu": n,
                        "halo_dofs_rank0": halo.n_shared_dofs, "kernel": op.kernel_name,
-                       "assembly": os.environ.get("CEED_MI355X_ASSEMBLE", "serial"), "schedule": os.environ.get("CEED_MI355X_SCHED", "dynamic"),
+                       "assembly": os.environ.get("CEED_MI355X_ASSEMBLE", "serial"), "schedule": os.environ.get("CEED_MI355X_SCHED", "static"),
                        "partition": ((("z-layers of ONE mesh" if args.workload != "box" else "blocks %dx%dx%d of ONE box" % __import__("ceedpetscsolid_amd.halo", fromlist=["block_grid"]).block_grid(world)) if strong else "one such mesh per GPU (z-slabs)")
                                      + "; halo sum " + ("overlapped with interior elements" if overlap else "after the apply")
                                      + (" through CeedXHalo* (RCCL group of ncclSend/ncclRecv, pack / unpack-add kernels)" if use_rccl else " through torch.distributed P2P"))

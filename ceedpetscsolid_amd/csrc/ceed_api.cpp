@@ -78,7 +78,8 @@ struct Ceed_private {
   bool even_odd = true;         // pencil kernel applies the 1-D tables in even-odd form (CEED_MI355X_EO=0: plain products)
   bool direct_interior = true;  // pencil kernel: element-interior nodes go straight to y (CEED_MI355X_DIRECT=0: all via the E-vector)
   unsigned *queue = nullptr;    // per-XCD ticket counters of the pencil kernel's dynamic schedule (8 x QUEUE_STRIDE)
-  bool dynamic_sched = true;    // pencil kernel: groups taken dynamically per XCD (default; CEED_MI355X_SCHED=static: round-1 striding)
+  bool dynamic_sched = false;   // pencil kernel: groups taken dynamically per XCD (CEED_MI355X_SCHED=dynamic; the gated and folded assembly
+                                // forms always do); default: round 1's static striding -- equal on large meshes, faster on small ones
   int asm_overlap = 0;          // EXPERIMENT CEED_MI355X_ASM_OVERLAP=1: k_assemble on a second stream beside the fused kernel (ungated: timing only)
   // Restriction transpose of the fused residual / Jacobian apply (CEED_MI355X_ASSEMBLE): "serial" (default) = k_assemble after
   // the fused kernel; "gated" = k_assemble_gated beside the fused kernel on a second stream + k_assemble_tail; "folded" =
@@ -278,7 +279,7 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   const char *di = getenv("CEED_MI355X_DIRECT");
   c->direct_interior = c->fused_variant == 1 && !c->atomic_scatter && !(di && !strcmp(di, "0"));
   const char *sd = getenv("CEED_MI355X_SCHED");
-  c->dynamic_sched = c->fused_variant == 1 && !(sd && !strcmp(sd, "static"));
+  c->dynamic_sched = c->fused_variant == 1 && sd && !strcmp(sd, "dynamic");
   const char *ao = getenv("CEED_MI355X_ASM_OVERLAP");
   c->asm_overlap = ao ? atoi(ao) : 0;
   const char *ga = getenv("CEED_MI355X_ASSEMBLE");

@@ -281,19 +281,32 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
   int xs = 0;
   if (dyn) { xs = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); xs |= xs << 4; }   // hwreg(HW_REG_XCC_ID, 0, 4)
   auto chunk_groups = [&]() { return (((kargs_fresh<true>()->nelem + E - 1) / E) + 7) >> 3; };   // groups per chunk (uniform)
-  // next group of this wave, or -1: ticket of the current chunk; on exhaustion move on to the next chunk (at most 8 tries)
-  auto take = [&]() -> int {
-    for (;;) {
+  // next group of this wave, or -1: `n` tickets (1 or 2) of the current chunk; when that chunk has run dry, ONE load looks
+  // at all eight ticket counters (lane l reads chunk l's) and the wave moves on to the next chunk that still has groups --
+  // or leaves: a wave at the end of a launch costs one atomic and one load, not a round of eight returning atomics
+  // (which made every SMALL launch ~10 us longer: config 3's 16 000 applies of 50 us).
+  auto take = [&](int n, int &second) -> int {
+    second = -1;
+#pragma unroll 1
+    for (int tries = 0; tries < 10; tries++) {
       const kargs_t ka = kargs_fresh<true>();
       const int ng = (ka->nelem + E - 1) / E, ch = (ng + 7) >> 3, x = (xs >> 4) & 7;
       unsigned t = 0;
-      if (lane == 0) t = atomicAdd(ka->queue + x * QUEUE_STRIDE, 1u);
-      const int g = x * ch + (int)__builtin_amdgcn_readfirstlane(t);
-      if (g < min(ng, (x + 1) * ch)) return g;
-      const int st = (xs >> 8) + 1;
-      if (st >= 8) return -1;
-      xs = (xs & 15) | (((x + 1) & 7) << 4) | (st << 8);
+      if (lane == 0) t = atomicAdd(ka->queue + x * QUEUE_STRIDE, (unsigned)n);
+      const int g = x * ch + (int)__builtin_amdgcn_readfirstlane(t), gend_x = min(ng, (x + 1) * ch);
+      if (g < gend_x) {
+        if (n == 2 && g + 1 < gend_x) second = g + 1;
+        return g;
+      }
+      // this chunk is exhausted: which chunks still have groups?
+      const unsigned hv = lane < 8 ? __hip_atomic_load(ka->queue + lane * QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      const unsigned left = (unsigned)(__ballot(lane < 8 && (int)hv < min(ng, (lane + 1) * ch) - lane * ch) & 0xFFull);
+      if (!left) return -1;
+      const unsigned rot = ((left >> (x + 1)) | (left << (7 - x))) & 0xFFu;   // bit i: chunk (x + 1 + i) % 8 has groups left
+      const int nx = (x + 1 + __builtin_ctz(rot)) & 7;
+      xs = (xs & 15) | (nx << 4) | (((xs >> 8) + 1) << 8);
     }
+    return -1;
   };
   // Completion signal of the gated / folded assembly (FusedGradArgs::done): one add to the counter of group g's bucket -- in
   // its upper half if the group was taken from another XCD's chunk -- once the group's stores have been acknowledged
@@ -437,7 +450,17 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
     }
   };
   int grp, g_q1 = -1, g_prev = -1;   // current group; dynamic: the group after it (taken one group ahead), the one before it
-  if (dyn) { grp = take(); if (grp < 0) return; g_q1 = take(); }
+  if (dyn) {
+    int dummy;
+    grp = take(1, dummy);
+    if (grp < 0) return;
+    // The second ticket (the group whose data this wave prefetches) only after every wave of the launch has had the time
+    // to take its FIRST one (a 2 048-block grid starts within ~1.2 us): taken back to back, the early waves held two
+    // groups each and half the grid found none -- a launch of about as many groups as waves took twice as long
+    // (54 instead of 26 us at 2 200 groups).
+    __builtin_amdgcn_s_sleep(48);
+    g_q1 = take(1, dummy);
+  }
   else { grp = (int)(blockIdx.x % nxcd) * ((ngroups + nxcd - 1) / nxcd) + wrank; if (grp >= gend) return; }
   if (fold) as_request();
 
@@ -566,7 +589,7 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
     const int grp_nx = dyn ? g_q1 : grp + wper;
     const bool more = dyn ? grp_nx >= 0 : grp_nx < gend;  // wave-uniform
     const int g_nx = more ? grp_nx : grp;
-    if (dyn && more) g_q1 = take();   // the group after the next: its ticket returns under this group's work
+    if (dyn && more) { int dummy; g_q1 = take(1, dummy); }   // the group after the next: its ticket returns under this group's work
     FoldRows fr;        // (this iteration only)
     int sig_idx = -1;   // the completion counter bumped in this iteration, its value before (lane 0)
     unsigned sig_old = 0;

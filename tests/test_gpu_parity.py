@@ -461,16 +461,16 @@ def test_apply_is_bitwise_reproducible(gpu):
     (lambda: distorted_box(9, 7, 5), 1, "linElas"),             # Q = 2: eight elements per group, ragged last group
     (lambda: distorted_box(7, 6, 6), 6, "hyperFS"),             # Q = 7: one element per group
 ], ids=["cyl1536 p4", "cyl8000 p4", "box p2", "box p1", "box p6"])
-@pytest.mark.parametrize("mode", ["gated", "folded", "static"])
+@pytest.mark.parametrize("mode", ["gated", "folded", "dynamic"])
 def test_gated_assembly_equals_serial_assembly_bitwise(product_lib, mk, degree, problem, mode):
     """The opt-in forms of the restriction transpose -- "gated": k_assemble_gated BESIDE the fused kernel + k_assemble_tail;
-    "folded": summed by the pencil kernel's own waves + k_assemble_tail (CEED_MI355X_ASSEMBLE) -- and the static group
-    schedule (CEED_MI355X_SCHED=static) against the default (k_assemble after the dynamically scheduled fused kernel): same
+    "folded": summed by the pencil kernel's own waves + k_assemble_tail (CEED_MI355X_ASSEMBLE) -- and the dynamic per-XCD group
+    schedule (CEED_MI355X_SCHED=dynamic) against the default (k_assemble after the statically scheduled fused kernel): same
     E-vector values, same element order, so the results are BITWISE equal.  The inputs alternate between applies, so an
     E-vector entry read before its producer's store had reached the XCD's L2 (or from a stale L1 line) would show as the
     previous apply's value."""
     mesh = mk()
-    gated = _ceed_with_env(product_lib, "CEED_MI355X_SCHED", "static") if mode == "static" else _ceed_with_env(product_lib, "CEED_MI355X_ASSEMBLE", mode)
+    gated = _ceed_with_env(product_lib, "CEED_MI355X_SCHED", "dynamic") if mode == "dynamic" else _ceed_with_env(product_lib, "CEED_MI355X_ASSEMBLE", mode)
     serial = cd.Ceed(product_lib, "/gpu/hip/mi355x")
     probs = [SolidProblem(c, mesh, degree, problem, nu=0.3, E=1.0, bc_sides=[sorted(mesh.side_sets)[0]], multigrid="none") for c in (gated, serial)]
     n = probs[0].lsize()
