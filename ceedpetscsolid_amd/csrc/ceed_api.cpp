@@ -358,7 +358,10 @@ extern "C" int CeedXGraphDestroy(CeedXGraph *graph) {
 // ---------------------------------------------------------------------------
 // CeedVector: host and device mirrors with validity flags
 // ---------------------------------------------------------------------------
-static size_t vbytes(CeedVector v) { return sizeof(double) * (size_t)(v->length > 0 ? v->length : 1); }
+static size_t vbytes(CeedVector v) {
+  static const bool pad = getenv("CEED_MI355X_QPAD_ALLOC") != nullptr;   // experiment: room for padded q-point runs (tools/variants)
+  return sizeof(double) * (size_t)(v->length > 0 ? v->length : 1) * (pad ? 132 : 128) / 128;
+}
 // Zero `n` doubles on the Ceed's stream.  While a hipGraph is being recorded this is a fill KERNEL rather than a memset node
 // (same cost).  Round 1 had blamed a wrong replay on recorded memset nodes losing their order; a library-free reproducer
 // (tools/microbench/graph_memset_repro.hip) and this library with CEED_MI355X_GRAPH_MEMSET=1 both replay correctly: the

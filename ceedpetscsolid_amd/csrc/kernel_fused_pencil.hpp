@@ -249,6 +249,11 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
   constexpr int BI = 8, BJ = 8 * SJ, BK = 8 * SK, BC = 8 * SC;        // byte strides
   constexpr int oA = 0, oBX = 8 * G::ARR, oBZ = 16 * G::ARR;         // byte offsets of the arrays
   constexpr bool ST_IN = QFTraits<QF>::state_in, ST_OUT = QFTraits<QF>::state_out;
+#ifdef CPS_QPAD   // experiment (tools/variants, TIMING ONLY): stored-state runs padded to whole 128-byte lines
+  constexpr int QS = (Q3 + 15) / 16 * 16;
+#else
+  constexpr int QS = Q3;
+#endif
   static_assert(P <= Q, "interpolation to at least as many points as nodes");
   // re-read the launch arguments at every use (kargs_fresh) where that frees the SGPR file of spills: Q <= 5.  At
   // Q >= 6 one coefficient table alone (2 Q^2 SGPRs) overflows it and the extra scalar-load waits only cost (measured).
@@ -551,10 +556,10 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
       for (int c = 0; c < 10; c++) qdv[c] = (qb + c * Q3)[vo];
     }
     if constexpr (ST_IN) {
-      const double *sb = ka->state_in + e0 * (9 * Q3);
-      const uint32_t vs = (uint32_t)(el * (9 * Q3) + q);
+      const double *sb = ka->state_in + e0 * (9 * QS);
+      const uint32_t vs = (uint32_t)(el * (9 * QS) + q);
 #pragma unroll
-      for (int c = 0; c < 9; c++) stv[c] = (sb + c * Q3)[vs];
+      for (int c = 0; c < 9; c++) stv[c] = (sb + c * QS)[vs];
     }
   };
   auto load_offsets = [&](int g, uint32_t *o) {
@@ -722,10 +727,10 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
         qf_point<QF>(Phys{ka->nu, ka->E, ka->lambda, ka->TwoMu}, ug, qdl, st[r % NSET], dv, sto);
 #endif
         if constexpr (ST_OUT) {
-          double *sb = ka->state_out + (size_t)(ka->elem_begin + grp * E) * (9 * Q3);
-          const uint32_t vs = (uint32_t)(pel * (9 * Q3) + pq);
+          double *sb = ka->state_out + (size_t)(ka->elem_begin + grp * E) * (9 * QS);
+          const uint32_t vs = (uint32_t)(pel * (9 * QS) + pq);
 #pragma unroll
-          for (int c = 0; c < 9; c++) (sb + c * Q3)[vs] = sto[c];
+          for (int c = 0; c < 9; c++) (sb + c * QS)[vs] = sto[c];
         }
       } else {
 #pragma unroll
