@@ -263,6 +263,16 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
   const ldsp_t lds0 = (lds_double *)slab + (CPS_WG4 ? (threadIdx.x >> 6) * (E * SE + G::GEO) : 0);
   constexpr bool geo = GEO;   // recompute the geometric factors per point instead of reading qdata (FusedGradArgs::geo set)
   const int lane = threadIdx.x & 63;
+#ifndef CPS_NO_STAGGER
+  // Staggered start (large launches only: every wave has at least four groups): the persistent waves of a launch begin
+  // within a microsecond of each other and would walk through their phases -- gather, passes, q-point loads, physics,
+  // stores -- in step, all of the chip bursting on memory together.  A pseudo-random delay of 0 ... 6.5 us per workgroup
+  // (15 x s_sleep 16) spreads them over about half a group period.  Same-box A/B (profiles/r02_ab_experiments.txt): fused
+  // kernel 374.2 -> 367.1 us (-1.9 %); a fixed half-period delay of every second wave of a SIMD: -0.1 ... -1.2 %; per-CU
+  // slot-wise delays up to 12 us: -1.8 %; random up to 13 us: -1.2 %.
+  if ((a.nelem + E - 1) / E >= 4 * (int)gridDim.x)
+    for (int i = 0; i < (int)((blockIdx.x * 2654435761u) >> 28) * 2; i++) __builtin_amdgcn_s_sleep(8);
+#endif
 #ifdef CPS_SETPRIO   // experiment (tools/variants): static priority for every other workgroup of an XCD (MI355X_MICROARCH.md, two waves per SIMD, item 4)
   if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(CPS_SETPRIO);
 #endif
