@@ -78,6 +78,8 @@ struct Ceed_private {
   bool even_odd = true;         // pencil kernel applies the 1-D tables in even-odd form (CEED_MI355X_EO=0: plain products)
   bool direct_interior = true;  // pencil kernel: element-interior nodes go straight to y (CEED_MI355X_DIRECT=0: all via the E-vector)
   unsigned *queue = nullptr;    // per-XCD ticket counters of the pencil kernel's dynamic schedule (8 x QUEUE_STRIDE)
+  bool pair_merge = false;      // pencil kernel, two elements per wave: shared nodes summed in LDS before the store (CEED_MI355X_PAIR=1;
+                                // measured: k_assemble -10 %, fused kernel +3.7 %, net 0 -- off by default)
   bool dynamic_sched = false;   // pencil kernel: groups taken dynamically per XCD (CEED_MI355X_SCHED=dynamic; the gated and folded assembly
                                 // forms always do); default: round 1's static striding -- equal on large meshes, faster on small ones
   int asm_overlap = 0;          // EXPERIMENT CEED_MI355X_ASM_OVERLAP=1: k_assemble on a second stream beside the fused kernel (ungated: timing only)
@@ -172,6 +174,11 @@ struct CeedElemRestriction_private {
   CsrMap csr;   // default map (nodes in ascending offset order)
   CsrMap csr_shell;        // the same without the element-interior nodes (FusedGradArgs::direct)
   GatedMap gated;          // the map of the fused residual / Jacobian apply, re-ordered for the gated assembly
+  // pair merge (FusedGradArgs::pairs): built once per restriction for groups of two elements
+  int pair_state = 0;      // 0 not built, 1 built, -1 not applicable
+  uint16_t *d_pairs = nullptr;
+  std::vector<unsigned char> h_nflag;   // per (element, local node): 1 = merged into the group's first element, 2 = complete there
+  long pair_nodes = 0, pair_complete = 0;
   int interior_private = 0;  // 0: not checked yet; 1: every element-interior node has one contributor; -1: not so
 };
 
@@ -219,6 +226,7 @@ struct CeedOperator_private {
   unsigned char *d_node_flags_ovl = nullptr;  // per node of the operator's own (priority-first) map
   unsigned char *d_node_flags_shell = nullptr;  // per node of the restriction's shell map (direct-store mode)
   unsigned char *d_node_flags_gated = nullptr;  // per row of the restriction's gated map
+  uint32_t *d_off_paired = nullptr;             // offsets with the Dirichlet flags AND the pair-merge bits (whole applies of the pencil kernel)
   std::vector<unsigned char> h_mask;      // copy of the output mask (node flags are derived lazily)
   int mask_mode = 0;
   // optional fine-side scale for transfers
@@ -282,6 +290,8 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   c->dynamic_sched = c->fused_variant == 1 && sd && !strcmp(sd, "dynamic");
   const char *ao = getenv("CEED_MI355X_ASM_OVERLAP");
   c->asm_overlap = ao ? atoi(ao) : 0;
+  const char *pm = getenv("CEED_MI355X_PAIR");
+  c->pair_merge = c->fused_variant == 1 && pm && !strcmp(pm, "1");
   const char *ga = getenv("CEED_MI355X_ASSEMBLE");
   c->gated_assembly = c->fused_variant == 1 && !c->atomic_scatter && ga && (!strcmp(ga, "gated") || !strcmp(ga, "folded"));
   c->folded_assembly = c->gated_assembly && !strcmp(ga, "folded");
@@ -580,6 +590,7 @@ extern "C" int CeedElemRestrictionDestroy(CeedElemRestriction *rstr) {
   r->csr.release();
   r->csr_shell.release();
   r->gated.release();
+  if (r->d_pairs) (void)hipFree(r->d_pairs);
   ceed_unref(r->ceed);
   delete r;
   return 0;
@@ -800,6 +811,8 @@ static void op_free_flags(CeedOperator o) {
   if (o->d_node_flags_ovl) (void)hipFree(o->d_node_flags_ovl);
   if (o->d_node_flags_shell) (void)hipFree(o->d_node_flags_shell);
   if (o->d_node_flags_gated) (void)hipFree(o->d_node_flags_gated);
+  if (o->d_off_paired) (void)hipFree(o->d_off_paired);
+  o->d_off_paired = nullptr;
   o->d_node_flags = o->d_node_flags_ovl = o->d_node_flags_shell = o->d_node_flags_gated = nullptr;
   o->h_mask.clear();
   o->mask_mode = 0;
@@ -833,7 +846,7 @@ extern "C" int CeedOperatorDestroy(CeedOperator *op) {
 // come first.
 // `skipP` > 0 (elemsize == skipP^3): nodes interior to an element are left out of the map -- the fused kernel
 // stores them itself (FusedGradArgs::direct); the caller has checked rstr_interior_private().
-static int build_csr(CeedElemRestriction r, CsrMap &M, const unsigned char *prio, int skipP = 0) {
+static int build_csr(CeedElemRestriction r, CsrMap &M, const unsigned char *prio, int skipP = 0, const unsigned char *nflag = nullptr) {
   if (M.built) return 0;
   if (r->ceed->capturing)
     return ceed_error("first apply of an operator during graph capture: its restriction's transpose map is built on the host; "
@@ -842,9 +855,12 @@ static int build_csr(CeedElemRestriction r, CsrMap &M, const unsigned char *prio
   std::vector<uint32_t> cnt((size_t)r->lsize + 1, 0u);
   for (size_t i = 0; i < n; i++) cnt[(size_t)r->h_offsets[i]]++;
   M.nskipped = 0;
+  if (nflag)   // pair merge: the second element's copy of a shared node is no contributor
+    for (size_t i = 0; i < n; i++)
+      if (nflag[i] & 1) cnt[(size_t)r->h_offsets[i]]--;
   if (skipP > 0)
     for (size_t i = 0; i < n; i++)
-      if (node_is_element_interior((int)(i % (size_t)r->elemsize), skipP)) { cnt[(size_t)r->h_offsets[i]] = 0; M.nskipped++; }
+      if (node_is_element_interior((int)(i % (size_t)r->elemsize), skipP) || (nflag && (nflag[i] & 2))) { cnt[(size_t)r->h_offsets[i]] = 0; M.nskipped++; }   // stored by the fused kernel itself
   std::vector<uint32_t> slot((size_t)r->lsize, 0xFFFFFFFFu), rowptr;
   M.h_node_off.clear();
   rowptr.push_back(0u);
@@ -862,7 +878,7 @@ static int build_csr(CeedElemRestriction r, CsrMap &M, const unsigned char *prio
   std::vector<uint32_t> cursor(rowptr.begin(), rowptr.end() - 1), cols(n ? n : 1);
   for (size_t i = 0; i < n; i++) {  // element order => each node's contributors are sorted by element
     const uint32_t sl = slot[(size_t)r->h_offsets[i]];
-    if (sl == 0xFFFFFFFFu) continue;
+    if (sl == 0xFFFFFFFFu || (nflag && (nflag[i] & 1))) continue;
     // E position: e * elemsize + n, or in the shell-only E-vector of the direct-store mode e * shell size + shell rank
     const size_t e = i / (size_t)r->elemsize; const int ln = (int)(i % (size_t)r->elemsize);
     cols[cursor[sl]++] = skipP > 0 ? (uint32_t)(e * (size_t)element_shell_size(skipP) + (size_t)node_shell_rank(ln, skipP)) : (uint32_t)i;
@@ -895,6 +911,47 @@ static bool rstr_interior_private(CeedElemRestriction r, int P) {
   r->interior_private = 1;
   return true;
 }
+// Pair merge: for every group of two consecutive elements, the shell nodes they share (FusedGradArgs::pairs).
+static int build_pairs(CeedElemRestriction r, int P) {
+  if (r->pair_state) return 0;
+  r->pair_state = -1;
+  if (!r->ceed->pair_merge) return 0;
+  const int P3 = P * P * P;
+  if (P < 3 || P3 != r->elemsize || P3 > 255 || (uint32_t)r->lsize > PAIR_OFF_MASK || r->nelem < 2) return 0;
+  const size_t n = r->h_offsets.size();
+  std::vector<unsigned char> mult((size_t)r->lsize, 0);
+  for (size_t i = 0; i < n; i++) { unsigned char &m = mult[(size_t)r->h_offsets[i]]; if (m < 255) m++; }
+  const int ngroups = (r->nelem + 1) / 2;
+  std::vector<uint16_t> pairs((size_t)ngroups * PAIR_MAX, (uint16_t)0xFFFF);
+  r->h_nflag.assign(n, 0);
+  std::vector<int32_t> stamp((size_t)r->lsize, -1);   // (group << 8 | local node of the first element) + 1 ... as int64 would be safer; groups < 2^23
+  if (ngroups >= (1 << 22)) return 0;
+  for (int g = 0; g < ngroups; g++) {
+    const size_t e0 = (size_t)2 * g, e1 = e0 + 1;
+    if (e1 >= (size_t)r->nelem) break;
+    for (int k = 0; k < P3; k++)
+      if (!node_is_element_interior(k, P)) stamp[(size_t)r->h_offsets[e0 * P3 + k]] = (int32_t)((g << 8) | k);
+    int np = 0;
+    for (int k = 0; k < P3 && np < PAIR_MAX; k++) {
+      if (node_is_element_interior(k, P)) continue;
+      const size_t o = (size_t)r->h_offsets[e1 * P3 + k];
+      const int32_t st = stamp[o];
+      if (st < 0 || (st >> 8) != g) continue;
+      const int n0 = st & 0xFF;
+      if (r->h_nflag[e0 * P3 + n0] & 4) continue;   // (a node the second element holds twice: keep the first match only)
+      pairs[(size_t)g * PAIR_MAX + np++] = (uint16_t)(n0 | (k << 8));
+      r->h_nflag[e1 * P3 + k] |= 1;
+      r->h_nflag[e0 * P3 + n0] |= 4;
+      r->pair_nodes++;
+      if (mult[o] == 2) { r->h_nflag[e0 * P3 + n0] |= 2; r->pair_complete++; }
+    }
+  }
+  HIPCHK(hipMalloc((void **)&r->d_pairs, sizeof(uint16_t) * pairs.size()));
+  HIPCHK(hipMemcpy(r->d_pairs, pairs.data(), sizeof(uint16_t) * pairs.size(), hipMemcpyHostToDevice));
+  r->pair_state = 1;
+  return 0;
+}
+
 // Re-order the transpose map `M` (shell or full) of restriction r for the gated assembly with groups of E elements.
 static int build_gated(CeedElemRestriction r, const CsrMap &M, int E, int skipP, int item_rows, int max_contrib, GatedMap &G) {
   if (G.built && G.E == E && G.skipP == skipP && G.item_rows == item_rows && G.max_contrib == max_contrib) return 0;
@@ -1246,7 +1303,27 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
     if (split) {
       M = &op->ovl_csr;
       if ((M->nskipped > 0) != direct) return ceed_error("split-phase map and direct-store mode disagree");
-    } else if (direct) { CHK(build_csr(r, r->csr_shell, nullptr, ai.basis->P1d)); M = &r->csr_shell; }
+    } else if (direct) {
+      if (a.variant == 1 && pencil_group_elems(ai.basis->Q1d) == 2 && !op->ceed->capturing) CHK(build_pairs(r, ai.basis->P1d));
+      const bool paired = r->pair_state == 1 && a.variant == 1 && pencil_group_elems(ai.basis->Q1d) == 2;
+      CHK(build_csr(r, r->csr_shell, nullptr, ai.basis->P1d, paired ? r->h_nflag.data() : nullptr));
+      M = &r->csr_shell;
+      if (paired) {
+        if (!op->d_off_paired) {   // offsets + Dirichlet flags (bits 29-31) + pair bits (27, 28)
+          std::vector<uint32_t> fl(r->h_offsets.size());
+          for (size_t i = 0; i < fl.size(); i++) {
+            uint32_t o = (uint32_t)r->h_offsets[i], f = 0;
+            if (!op->h_mask.empty())
+              for (int cc = 0; cc < 3; cc++) if (op->h_mask[(size_t)o + (size_t)cc * r->compstride]) f |= 1u << cc;
+            fl[i] = o | (f << OFF_FLAG_SHIFT) | ((r->h_nflag[i] & 1) ? PAIR_SKIP : 0u) | ((r->h_nflag[i] & 2) ? PAIR_DIRECT : 0u);
+          }
+          HIPCHK(hipMalloc((void **)&op->d_off_paired, sizeof(uint32_t) * (fl.size() ? fl.size() : 1)));
+          HIPCHK(hipMemcpy(op->d_off_paired, fl.data(), sizeof(uint32_t) * fl.size(), hipMemcpyHostToDevice));
+        }
+        a.offsets = op->d_off_paired;
+        a.pairs = r->d_pairs;
+      }
+    }
     else { CHK(build_csr(r, r->csr, nullptr)); M = &r->csr; }
     unsigned char **flagsp = split ? &op->d_node_flags_ovl : (direct ? &op->d_node_flags_shell : &op->d_node_flags);
     if (!*flagsp && !op->h_mask.empty()) {

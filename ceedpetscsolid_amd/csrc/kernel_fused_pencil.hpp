@@ -584,10 +584,12 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
     }
   };
   auto load_x = [&](const uint32_t *o, double (*xv)[3]) {
-    const double *xb = kargs_fresh<KA>()->x;
+    const kargs_t kx = kargs_fresh<KA>();
+    const double *xb = kx->x;
+    const uint32_t omask = kx->pairs ? PAIR_OFF_MASK : OFF_MASK;   // (pair merge: two more flag bits ride in the offsets)
 #pragma unroll
     for (int r = 0; r < RN; r++) {
-      const uint32_t base = o[r] & OFF_MASK;
+      const uint32_t base = o[r] & omask;
 #pragma unroll
       for (int c = 0; c < 3; c++) xv[r][c] = xb[base + c];
     }
@@ -609,6 +611,11 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
     int sig_idx = -1;   // the completion counter bumped in this iteration, its value before (lane 0)
     unsigned sig_old = 0;
     as_stage0(fr);
+    uint32_t pair_e = 0xFFFFu;   // this group's pair entry of this lane (used after the last pass)
+    if constexpr (E == 2) {
+      const kargs_t kp = kargs_fresh<KA>();
+      if (kp->pairs && lane < PAIR_MAX) pair_e = (kp->pairs + (size_t)grp * PAIR_MAX)[lane]   /* whole applies only: elem_begin == 0 */;
+    }
     load_offsets(g_nx, off_nx);
     constexpr int RG = (E * GEO_NCOEF + 63) / 64;
     double gcoef[RG];    // this group's element-map coefficients, lane + 64 i; into LDS right before the physics
@@ -851,6 +858,19 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
 #if CPS_WG4
     __syncthreads();
 #endif
+    // ---- pair merge: the nodes the group's two elements share are summed in LDS (into the first element's slot) ------------
+    if constexpr (E == 2) {
+      if (kargs_fresh<KA>()->pairs) {
+        if (lane < PAIR_MAX && pair_e != 0xFFFFu) {
+          const int n0 = (int)(pair_e & 0xFFu), n1 = (int)(pair_e >> 8);
+          const ldsp_t a0 = lds0 + ((n0 / (P * P)) * SK + ((n0 / P) % P) * SJ + n0 % P);
+          const ldsp_t a1 = lds0 + (SE + (n1 / (P * P)) * SK + ((n1 / P) % P) * SJ + n1 % P);
+          const double s0 = lds_rd<oA + 0 * BC>(a0) + lds_rd<oA + 0 * BC>(a1), s1 = lds_rd<oA + 1 * BC>(a0) + lds_rd<oA + 1 * BC>(a1),
+                       s2 = lds_rd<oA + 2 * BC>(a0) + lds_rd<oA + 2 * BC>(a1);
+          lds_wr<oA + 0 * BC>(a0, s0); lds_wr<oA + 1 * BC>(a0, s1); lds_wr<oA + 2 * BC>(a0, s2);
+        }
+      }
+    }
     // ---- final: node owners -> E-vector (plain coalesced stores) or f64 atomics ---------------------------
     {
       double v[RN][3];
@@ -864,9 +884,11 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
       for (int r = 0; r < RN; r++) {
         const int nel = el_of(lane + 64 * r, P3), nn = lane + 64 * r - nel * P3;
         if (pencil_ok(lane, r, E * P3) && grp * E + nel < ka->nelem) {
-          const bool interior = (nd_interior >> r) & 1u;
-          if (ka->evec && interior) {  // sole contributor: the node's final value goes straight to y
-            const uint32_t base = off[r] & OFF_MASK;
+          const bool paired = ka->pairs != nullptr;
+          if (paired && (off[r] & PAIR_SKIP)) continue;   // merged into the group's other element (pair merge)
+          const bool interior = ((nd_interior >> r) & 1u) || (paired && (off[r] & PAIR_DIRECT));
+          if (ka->evec && interior) {  // no contributor outside this wave: the node's final value goes straight to y
+            const uint32_t base = off[r] & (paired ? PAIR_OFF_MASK : OFF_MASK);
             const uint32_t fl = ka->mask_out ? (off[r] >> OFF_FLAG_SHIFT) : 0u;
             double *yb = ka->y;
             yb[base] = (fl & 1u) ? 0. : v[r][0]; (yb + 1)[base] = (fl & 2u) ? 0. : v[r][1]; (yb + 2)[base] = (fl & 4u) ? 0. : v[r][2];

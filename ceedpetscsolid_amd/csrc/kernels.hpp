@@ -43,6 +43,8 @@ struct BasisTables {
 // top bits (set by CeedXOperatorSetDirichletMask); plain offsets have none.
 constexpr uint32_t OFF_MASK = 0x1FFFFFFFu;
 constexpr int OFF_FLAG_SHIFT = 29;
+constexpr uint32_t PAIR_OFF_MASK = 0x07FFFFFFu, PAIR_SKIP = 1u << 27, PAIR_DIRECT = 1u << 28;   // FusedGradArgs::pairs
+constexpr int PAIR_MAX = 32;
 
 struct FusedGradArgs {
   const uint32_t *offsets;  // [nelem][P^3] (flagged)
@@ -80,6 +82,12 @@ struct FusedGradArgs {
                                // group's bucket, done[chunk * nb + ((group - chunk begin) >> bucket_shift)]; a group taken from
                                // another XCD's chunk adds GatedCtrl::FOREIGN instead (its stores sit in another L2)
   int nb, bucket_shift;       // buckets per chunk, log2(groups per bucket)
+  // PAIR MERGE (pencil kernel, E = 2 elements per wave, direct mode): the nodes the two elements of a group share (a face,
+  // when consecutive elements are neighbours) are summed in LDS before anything is stored.  pairs[group][PAIR_MAX]: local node
+  // of the first element | local node of the second << 8, 0xFFFF = none.  The offsets then carry two more bits per node
+  // (lsize < 2^27): PAIR_SKIP on the second element's copy (nothing is stored for it), PAIR_DIRECT on the first element's
+  // when the node has no other contributor (its sum is final: straight to y, like an element-interior node).
+  const uint16_t *pairs;
   // FOLDED assembly (as_rowptr set; needs queue and done): the waves of the pencil kernel sum the rows of the re-ordered
   // transpose map themselves -- one item (<= GATED_ITEM_ROWS rows of one bucket of the wave's own XCD's chunk) per element
   // group, its four dependent load levels (item, row pointers, columns, E-vector values) issued at four points of the

@@ -116,7 +116,9 @@ def main():
                     if n_scratch or m.get("scratch", 0): why.append(f"scratch ({m.get('scratch', 0)} B, {n_scratch} instructions)")
                     # SGPR spills go to VGPR lanes (v_writelane / v_readlane): slower, not wrong.  The default (even-odd) instantiations
                     # up to Q = 5 are held to none (from Q = 6 one table fills the SGPR file); the plain-table fallback (eo=0, taken only for tables that are not centro-symmetric) has a few.
-                    if m.get("vspill", 0) or (eo and q <= 5 and m.get("sspill", 0) > (8 if ",fold" in short else 4)):   # (the opt-in folded form: a few more) why.append(f"spills (vgpr {m.get('vspill', 0)}, sgpr {m.get('sspill', 0)})")
+                    sgpr_spill_limit = 8 if ",fold" in short else 4   # (the opt-in folded form: a few more)
+                    if m.get("vspill", 0) or (eo and q <= 5 and m.get("sspill", 0) > sgpr_spill_limit):
+                        why.append(f"spills (vgpr {m.get('vspill', 0)}, sgpr {m.get('sspill', 0)})")
                     if m.get("vgpr", 0) > 256: why.append(f"{m['vgpr']} VGPRs > 256 (one wave per SIMD)")
                     if why:
                         bad.append(f"{short}: " + "; ".join(why))
