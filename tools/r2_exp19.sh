@@ -2,7 +2,7 @@
 # lockstep cost: the pencil kernel as 256-thread workgroups of four waves with two barriers per group (no merge yet)
 L=ceedpetscsolid_amd/csrc/libceed_mi355x.so; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2; cp $R/$L /tmp/orig.so
 cd /tmp && export TMPDIR=/tmp
-for v in orig nostag orig nostag orig nostag; do
+for v in orig maxilp iterilp memclause bias0 orig maxilp iterilp memclause bias0; do
   if [ $v = orig ]; then cp /tmp/orig.so $R/$L; else cp $R/tools/variants/lib_$v.so $R/$L; fi
   rm -rf /tmp/ab_$v
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_$v -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline > /tmp/ab_$v.log 2>&1 || { echo "$v failed"; tail -3 /tmp/ab_$v.log; }
