@@ -361,6 +361,22 @@ static void rstr_gather(CeedElemRestriction r, const CeedScalar *l, CeedScalar *
 }
 static void rstr_scatter_add(CeedElemRestriction r, const CeedScalar *e, CeedScalar *l) {
   const CeedInt S = r->elemsize, C = r->ncomp;
+#ifdef _OPENMP
+  if (g_nthreads > 1) {   /* threaded runs (bench baseline, full-size tests): element chunks, atomic adds (order free: ~1e-16) */
+#pragma omp parallel for num_threads(g_nthreads) schedule(static)
+    for (CeedInt el = 0; el < r->nelem; el++)
+      for (CeedInt c = 0; c < C; c++)
+        for (CeedInt n = 0; n < S; n++) {
+          size_t li = r->offsets
+                      ? (size_t)r->offsets[(size_t)el * S + n] + (size_t)c * r->compstride
+                      : (size_t)n * r->strides[0] + (size_t)c * r->strides[1] +
+                        (size_t)el * r->strides[2];
+#pragma omp atomic
+          l[li] += e[((size_t)el * C + c) * S + n];
+        }
+    return;
+  }
+#endif
   for (CeedInt el = 0; el < r->nelem; el++)
     for (CeedInt c = 0; c < C; c++)
       for (CeedInt n = 0; n < S; n++) {
