@@ -36,8 +36,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from ceedpetscsolid_amd import ceed as cd  # noqa: E402
-from ceedpetscsolid_amd.halo import (HaloExchange, RcclHalo, interface_elements, part_box, part_cylinder, slab_box,  # noqa: E402
-                                     slab_cylinder)
+from ceedpetscsolid_amd.halo import (HaloExchange, checked_rccl_halo, interface_elements, part_box, part_cylinder,  # noqa: E402
+                                     slab_box, slab_cylinder)
 from ceedpetscsolid_amd.mesh import reorder_elements_first  # noqa: E402
 from ceedpetscsolid_amd.harness import SolidApp  # noqa: E402
 from ceedpetscsolid_amd.solid import SolidProblem, smooth_displacement  # noqa: E402
@@ -208,50 +208,9 @@ def main():
     # the exchange itself: behind the C ABI over RCCL on a GPU node; the torch path on gloo (single-GPU rehearsal) or on request
     use_rccl = world > 1 and args.halo == "rccl" and dist.get_backend() == "nccl"
     chalo, halo_note = None, None
-    if use_rccl:
-        # The library's exchange has been run on ONE GPU only so far: it is brought up in a worker thread with a
-        # time limit and CHECKED against the torch exchange on a test vector before it is used; on any failure (exception,
-        # time-out, wrong sums, on any rank) every rank falls back to torch.distributed point-to-point and the line says so.
-        import threading
-        box = {}
-
-        def bring_up():
-            try:
-                h = RcclHalo(ceed, halo)
-                probe = torch.from_numpy(coord_hash_vector(dofmap.node_coords, np.zeros(n, dtype=np.uint8))).to(dev)
-                V = ceed.vector(n)
-                V.set_device_pointer(probe.data_ptr())
-                h.add(V)
-                ceed.synchronize(); torch.cuda.synchronize()
-                V.take_array(cd.MEM_DEVICE)
-                box["h"], box["got"] = h, probe
-            except Exception as e:   # noqa: BLE001
-                box["err"] = repr(e)
-
-        th = threading.Thread(target=bring_up, daemon=True)
-        th.start(); th.join(timeout=120.0)
-        good = 0.0
-        ref = torch.from_numpy(coord_hash_vector(dofmap.node_coords, np.zeros(n, dtype=np.uint8))).to(dev)
-        halo.add(ref)                                        # the torch exchange of the same test vector: EVERY rank, whatever its thread did
-        if th.is_alive():
-            halo_note = "CeedXHalo* bring-up timed out after 120 s"
-        elif "err" in box:
-            halo_note = f"CeedXHalo* failed to initialise ({box['err']})"
-        else:
-            err = float((box["got"] - ref).abs().max().item()) / max(float(ref.abs().max().item()), 1e-300)
-            if err < 1e-12:
-                chalo, good = box["h"], 1.0
-            else:
-                halo_note = f"CeedXHalo* sums differ from the torch exchange (rel {err:.2e})"
-        flag = torch.tensor([good], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if flag.item() == 0.0:
-            if chalo is not None:
-                halo_note = "CeedXHalo* failed on another rank"
-            chalo, use_rccl = None, False
-            halo_note = (halo_note or "CeedXHalo* unavailable") + "; fell back to torch.distributed point-to-point"
-        else:
-            halo_note = "CeedXHalo* checked against the torch exchange on a test vector at start-up"
+    if use_rccl:   # brought up with a time limit and checked against the torch exchange; falls back on every rank if it fails on any
+        chalo, halo_note = checked_rccl_halo(ceed, halo, coord_hash_vector(dofmap.node_coords, np.zeros(n, dtype=np.uint8)), dev)
+        use_rccl = chalo is not None
     free = (mask == 0).astype(np.float64)
     n_global = halo.global_count(free)
 

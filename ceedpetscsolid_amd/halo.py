@@ -184,6 +184,58 @@ class RcclHalo:
             self.h = None
 
 
+def checked_rccl_halo(ceed, halo: "HaloExchange", probe: np.ndarray, device, timeout_s: float = 120.0):
+    """Bring the library's exchange (RcclHalo) up in a worker thread with a time limit and CHECK it against the torch
+    exchange of the same test vector before it is used.  Collective.  Returns (RcclHalo or None, note): on any failure --
+    exception, time-out, wrong sums -- on ANY rank, every rank gets None and uses the torch exchange."""
+    import threading
+    from . import ceed as cd
+    box = {}
+    n = probe.size
+
+    def bring_up():
+        try:
+            h = RcclHalo(ceed, halo)
+            t = torch.from_numpy(probe).to(device)
+            V = ceed.vector(n)
+            V.set_device_pointer(t.data_ptr())
+            h.add(V)
+            ceed.synchronize()
+            if t.is_cuda:
+                torch.cuda.synchronize()
+            V.take_array(cd.MEM_DEVICE)
+            box["h"], box["got"] = h, t
+        except Exception as e:   # noqa: BLE001
+            box["err"] = repr(e)
+
+    th = threading.Thread(target=bring_up, daemon=True)
+    th.start(); th.join(timeout=timeout_s)
+    ref = torch.from_numpy(probe).to(device)
+    halo.add(ref)                      # the torch exchange of the same vector: EVERY rank, whatever its thread did
+    note, good, h = None, 0.0, None
+    if th.is_alive():
+        note = f"CeedXHalo* bring-up timed out after {timeout_s:.0f} s"
+    elif "err" in box:
+        note = f"CeedXHalo* failed to initialise ({box['err']})"
+    else:
+        err = float((box["got"] - ref).abs().max().item()) / max(float(ref.abs().max().item()), 1e-300)
+        if err < 1e-12:
+            h, good = box["h"], 1.0
+        else:
+            note = f"CeedXHalo* sums differ from the torch exchange (rel {err:.2e})"
+    if halo.world > 1:
+        flag = torch.tensor([good], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=halo.group)
+        good_all = flag.item() != 0.0
+    else:
+        good_all = good != 0.0
+    if not good_all:
+        if h is not None:
+            note = "CeedXHalo* failed on another rank"
+        return None, (note or "CeedXHalo* unavailable") + "; fell back to torch.distributed point-to-point"
+    return h, "CeedXHalo* checked against the torch exchange on a test vector at start-up"
+
+
 def interface_elements(mesh: HexMesh, group=None) -> np.ndarray:
     """bool per element: True if the element has a vertex that another rank also holds (its nodes may
     need the halo sum).  Collective; uses global vertex ids only."""

@@ -389,6 +389,15 @@ def test_halo_exchange_through_rccl_on_one_gpu(product_lib):
     assert np.array_equal(Y2.to_numpy(), y1)
     L.chk(L.lib.CeedXHaloDestroy(C.byref(hh)))
     L.chk(L.lib.CeedXHaloDestroy(C.byref(h)))
+    # bench.py's start-up check of the library's exchange (halo.checked_rccl_halo) on the one rank there is: no neighbours,
+    # so both exchanges leave the test vector alone and the library's is accepted
+    from ceedpetscsolid_amd.halo import HaloExchange, checked_rccl_halo
+    from ceedpetscsolid_amd.mesh import build_dofmap
+    dm = build_dofmap(mesh, 2)
+    hx = HaloExchange(mesh, dm, device="cuda")
+    got, note = checked_rccl_halo(ceed, hx, rng.uniform(-1, 1, dm.lsize), "cuda", timeout_s=60.0)
+    assert got is not None and "checked" in note
+    got.destroy()
     L.chk(L.lib.CeedXCommDestroy(ceed.h))
 
 
