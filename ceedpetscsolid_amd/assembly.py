@@ -79,6 +79,7 @@ class AssembledLevel:
         slot = np.full(rows.size, -1, dtype=np.int64)
         slot[keep] = inv[:int(keep.sum())]
         self.nrows, self.nnz = n, int(uniq.size)
+        self.rowptr, self.cols = rowptr, c_u            # the pattern, for the hierarchy under this level (amg.py)
         self.csr = cd.Csr(c, rowptr, c_u, slot, np.nonzero(constrained)[0])
 
     def assemble(self):

@@ -69,6 +69,7 @@ class CeedLib:
         "CeedXVectorPointwiseMult", "CeedXVectorAXPBY", "CeedXVectorDot", "CeedXVectorChebyshevUpdate",
         "CeedXGraphBeginCapture", "CeedXGraphEndCapture", "CeedXGraphLaunch", "CeedXGraphDestroy",
         "CeedXCsrCreate", "CeedXCsrAssemble", "CeedXCsrApply", "CeedXCsrGetDiagonal", "CeedXCsrDestroy",
+        "CeedXCsrCreateRect", "CeedXCsrCreateProduct", "CeedXCsrGetPattern", "CeedXCsrUpdate", "CeedXCsrGetValues", "CeedXCsrInvertDenseSPD",
     ]
     DATA = [
         "CeedMemTypes", "CEED_VECTOR_ACTIVE", "CEED_VECTOR_NONE", "CEED_ELEMRESTRICTION_NONE",
@@ -121,7 +122,7 @@ class Csr:
     """Assembled sparse operator on L-vectors (CeedXCsr*): the coarse multigrid level."""
 
     def __init__(self, ceed: "Ceed", rowptr, cols, coo_slot, unit_rows=()):
-        self.L = ceed.L
+        self.L, self._ceed = ceed.L, ceed
         self.h = C.c_void_p()
         rp = np.ascontiguousarray(rowptr, dtype=np.int32); cl = np.ascontiguousarray(cols, dtype=np.int32)
         sl = np.ascontiguousarray(coo_slot, dtype=np.int32); ur = np.ascontiguousarray(unit_rows, dtype=np.int32)
@@ -138,6 +139,59 @@ class Csr:
 
     def diagonal(self, d: "Vector"):
         self.L.chk(self.L.lib.CeedXCsrGetDiagonal(self.h, d.h))
+
+    # ---- pieces of the aggregation hierarchy (amg.py) ------------------------------------------------------
+    @classmethod
+    def rect(cls, ceed: "Ceed", nrows: int, ncols: int, rowptr, cols, vals=None) -> "Csr":
+        """nrows x ncols matrix with fixed values (``vals``) or values computed by ``update()`` (``vals=None``)."""
+        self = cls.__new__(cls)
+        self.L, self.h, self._ceed = ceed.L, C.c_void_p(), ceed
+        rp = np.ascontiguousarray(rowptr, dtype=np.int32); cl = np.ascontiguousarray(cols, dtype=np.int32)
+        if rp.size != nrows + 1 or cl.size != int(rp[-1]):
+            raise ValueError("rowptr / cols do not describe an nrows-row pattern")
+        self.nrows, self.ncols, self.nnz, self.ncoo = nrows, ncols, int(rp[-1]), 0
+        vp = None
+        if vals is not None:
+            va = np.ascontiguousarray(vals, dtype=np.float64)
+            if va.size != self.nnz:
+                raise ValueError("one value per pattern entry expected")
+            vp = va.ctypes.data_as(C.POINTER(C.c_double))
+        self.L.chk(self.L.lib.CeedXCsrCreateRect(ceed.h, c_int(nrows), c_int(ncols), rp.ctypes.data_as(c_int_p),
+                                                 cl.ctypes.data_as(c_int_p), vp, C.byref(self.h)))
+        return self
+
+    @classmethod
+    def product(cls, left: "Csr", right: "Csr", variable: int, dense: bool = False) -> "Csr":
+        """left * right with one operand of fixed values and the other (``variable``: 0 left, 1 right) read at every
+        ``update()``; pattern and term lists are worked out by the library (CeedXCsrCreateProduct)."""
+        self = cls.__new__(cls)
+        self.L, self.h, self._ceed = left.L, C.c_void_p(), left._ceed
+        self.L.chk(self.L.lib.CeedXCsrCreateProduct(left.h, right.h, c_int(variable), c_int(1 if dense else 0), C.byref(self.h)))
+        self.nrows, self.ncols, self.nnz = self.pattern()[:3]
+        self.ncoo = 0
+        return self
+
+    def pattern(self):
+        """(nrows, ncols, nnz, rowptr, cols): copies of the library's host pattern."""
+        nr, nc, nz = c_int(), c_int(), c_int()
+        rp, cl = c_int_p(), c_int_p()
+        self.L.chk(self.L.lib.CeedXCsrGetPattern(self.h, C.byref(nr), C.byref(nc), C.byref(nz), C.byref(rp), C.byref(cl)))
+        rowptr = np.ctypeslib.as_array(rp, shape=(nr.value + 1,)).copy()
+        cols = np.ctypeslib.as_array(cl, shape=(max(nz.value, 1),))[:nz.value].copy() if nz.value else np.zeros(0, np.int32)
+        return nr.value, nc.value, nz.value, rowptr, cols
+
+    def update(self):
+        self.L.chk(self.L.lib.CeedXCsrUpdate(self.h))
+
+    def values(self, ceed: "Ceed" = None) -> np.ndarray:
+        v = (ceed or self._ceed).vector(max(self.nnz, 1))
+        self.L.chk(self.L.lib.CeedXCsrGetValues(self.h, v.h))
+        out = v.to_numpy()[:self.nnz].copy()
+        v.destroy()
+        return out
+
+    def invert_dense_spd(self):
+        self.L.chk(self.L.lib.CeedXCsrInvertDenseSPD(self.h))
 
     def destroy(self):
         if self.h:

@@ -1935,10 +1935,19 @@ extern "C" int CeedXHaloDestroy(CeedXHalo *halo) {
 // ---------------------------------------------------------------------------
 struct CeedXCsr_private {
   Ceed ceed = nullptr;
-  int nrows = 0, nnz = 0, ncoo = 0, n_unit = 0;
+  int nrows = 0, ncols = 0, nnz = 0, ncoo = 0, n_unit = 0;
   uint32_t *d_rowptr = nullptr, *d_cols = nullptr, *d_slotptr = nullptr, *d_perm = nullptr, *d_unit_slot = nullptr,
            *d_diag_slot = nullptr;
   double *d_vals = nullptr;
+  // values as a fixed linear combination of another matrix's values (CeedXCsrSetSource / CeedXCsrUpdate)
+  CeedXCsr src = nullptr;
+  uint32_t *d_termptr = nullptr, *d_term_slot = nullptr;
+  double *d_term_w = nullptr, *d_gj = nullptr;
+  int *d_info = nullptr;
+  bool dense = false;       // full pattern, columns ascending: vals is a row-major nrows x nrows matrix
+  int refs = 1;             // a source is kept alive by the matrices combined from it
+  std::vector<int> h_rowptr, h_cols;      // host copy of the pattern (operand of CeedXCsrCreateProduct)
+  std::vector<double> h_vals;             // host copy of FIXED values (CeedXCsrCreateRect with values), else empty
 };
 template <class T>
 static int csr_upload(uint32_t **dst, const std::vector<T> &v) {
@@ -1979,7 +1988,8 @@ extern "C" int CeedXCsrCreate(Ceed ceed, CeedInt nrows, const CeedInt *rowptr, c
   }
   CeedXCsr A = new CeedXCsr_private;
   A->ceed = ceed; ceed_ref(ceed);
-  A->nrows = nrows; A->nnz = nnz; A->ncoo = ncoo; A->n_unit = n_unit;
+  A->nrows = nrows; A->ncols = nrows; A->nnz = nnz; A->ncoo = ncoo; A->n_unit = n_unit;
+  A->h_rowptr.assign(rowptr, rowptr + nrows + 1); A->h_cols.assign(cols, cols + nnz);
   CHK(csr_upload(&A->d_rowptr, rp)); CHK(csr_upload(&A->d_cols, cl)); CHK(csr_upload(&A->d_slotptr, slotptr));
   CHK(csr_upload(&A->d_perm, perm)); CHK(csr_upload(&A->d_unit_slot, unit)); CHK(csr_upload(&A->d_diag_slot, diag));
   HIPCHK(hipMalloc((void **)&A->d_vals, sizeof(double) * (nnz ? nnz : 1)));
@@ -1996,7 +2006,7 @@ extern "C" int CeedXCsrAssemble(CeedXCsr A, CeedVector coo_values) {
 }
 extern "C" int CeedXCsrApply(CeedXCsr A, CeedVector x, CeedVector y) {
   if (x == y) return ceed_error("CeedXCsrApply: in-place apply is not supported");
-  if (x->length < A->nrows || y->length < A->nrows) return ceed_error("CeedXCsrApply: vector shorter than the matrix");
+  if (x->length < A->ncols || y->length < A->nrows) return ceed_error("CeedXCsrApply: vector shorter than the matrix");
   double *px, *py;
   CHK(vec_dev(x, false, &px)); CHK(vec_dev(y, true, &py));
   HIPCHK(launch_csr_spmv(A->d_rowptr, A->d_cols, A->d_vals, px, py, A->nrows, A->ceed->stream));
@@ -2009,14 +2019,136 @@ extern "C" int CeedXCsrGetDiagonal(CeedXCsr A, CeedVector d) {
   HIPCHK(launch_csr_diag(A->d_diag_slot, A->d_vals, pd, A->nrows, A->ceed->stream));
   return 0;
 }
+// Rectangular matrix with fixed values (prolongation / restriction of the aggregation hierarchy), or a pattern whose
+// values come from CeedXCsrUpdate.
+extern "C" int CeedXCsrCreateRect(Ceed ceed, CeedInt nrows, CeedInt ncols, const CeedInt *rowptr, const CeedInt *cols,
+                                  const CeedScalar *vals, CeedXCsr *csr) {
+  if (nrows < 0 || ncols < 0 || !rowptr || (rowptr[nrows] > 0 && !cols)) return ceed_error("CeedXCsrCreateRect: bad pattern");
+  const int nnz = rowptr[nrows];
+  bool dense = nrows == ncols && (long long)nnz == (long long)nrows * nrows;
+  for (int r = 0; r < nrows; r++) {
+    if (rowptr[r + 1] < rowptr[r]) return ceed_error("CeedXCsrCreateRect: rowptr not monotone");
+    for (int k = rowptr[r]; k < rowptr[r + 1]; k++) {
+      if (cols[k] < 0 || cols[k] >= ncols) return ceed_error("CeedXCsrCreateRect: column %d out of range in row %d", cols[k], r);
+      if (dense && cols[k] != k - rowptr[r]) dense = false;
+    }
+  }
+  std::vector<uint32_t> rp(rowptr, rowptr + nrows + 1), cl(cols, cols + nnz), diag((size_t)nrows, 0xFFFFFFFFu);
+  for (int r = 0; r < nrows; r++)
+    for (int k = rowptr[r]; k < rowptr[r + 1]; k++) if (cols[k] == r) diag[r] = (uint32_t)k;
+  CeedXCsr A = new CeedXCsr_private;
+  A->ceed = ceed; ceed_ref(ceed);
+  A->nrows = nrows; A->ncols = ncols; A->nnz = nnz; A->dense = dense;
+  A->h_rowptr.assign(rowptr, rowptr + nrows + 1); A->h_cols.assign(cols, cols + nnz);
+  if (vals) A->h_vals.assign(vals, vals + nnz);
+  CHK(csr_upload(&A->d_rowptr, rp)); CHK(csr_upload(&A->d_cols, cl)); CHK(csr_upload(&A->d_diag_slot, diag));
+  HIPCHK(hipMalloc((void **)&A->d_vals, sizeof(double) * (nnz ? nnz : 1)));
+  if (vals && nnz) HIPCHK(hipMemcpy(A->d_vals, vals, sizeof(double) * nnz, hipMemcpyHostToDevice));
+  else HIPCHK(hipMemset(A->d_vals, 0, sizeof(double) * (nnz ? nnz : 1)));
+  *csr = A;
+  return 0;
+}
+// C = L R where one operand has FIXED values (given to CeedXCsrCreateRect) and the other is `variable`: its values are
+// read by every CeedXCsrUpdate(C).  The pattern of C and, per entry, the list of (slot of the variable operand, weight)
+// terms are worked out here once, row by row (Gustavson), terms of an entry ordered by slot: vals[s] = sum_k w[k] * V[slot[k]].
+// dense != 0: C gets the full pattern (entries without a term stay zero), for CeedXCsrInvertDenseSPD.
+extern "C" int CeedXCsrCreateProduct(CeedXCsr Lm, CeedXCsr Rm, int variable, int dense, CeedXCsr *csr) {
+  if (!Lm || !Rm || Lm == Rm || (variable != 0 && variable != 1)) return ceed_error("CeedXCsrCreateProduct: bad operands");
+  if (Lm->ncols != Rm->nrows) return ceed_error("CeedXCsrCreateProduct: %d columns times %d rows", Lm->ncols, Rm->nrows);
+  CeedXCsr V = variable == 0 ? Lm : Rm, F = variable == 0 ? Rm : Lm;
+  if ((int)F->h_vals.size() != F->nnz) return ceed_error("CeedXCsrCreateProduct: the fixed operand must carry values from CeedXCsrCreateRect");
+  const int nrows = Lm->nrows, ncols = Rm->ncols;
+  if (dense && nrows != ncols) return ceed_error("CeedXCsrCreateProduct: a dense result must be square");
+  struct Term { int col, slot; double w; };
+  std::vector<Term> row;
+  std::vector<uint32_t> rp((size_t)nrows + 1, 0u), cl, tp(1, 0u), ts;
+  std::vector<double> tw;
+  std::vector<int> h_cols;
+  for (int i = 0; i < nrows; i++) {
+    row.clear();
+    for (int a = Lm->h_rowptr[i]; a < Lm->h_rowptr[i + 1]; a++) {
+      const int j = Lm->h_cols[a];
+      for (int b = Rm->h_rowptr[j]; b < Rm->h_rowptr[j + 1]; b++)
+        row.push_back(variable == 0 ? Term{Rm->h_cols[b], a, F->h_vals[b]} : Term{Rm->h_cols[b], b, F->h_vals[a]});
+    }
+    std::sort(row.begin(), row.end(), [](const Term &x, const Term &y) { return x.col != y.col ? x.col < y.col : x.slot < y.slot; });
+    size_t k = 0;
+    for (int c = 0; dense ? c < ncols : k < row.size(); c++) {
+      if (!dense) c = row[k].col;
+      while (k < row.size() && row[k].col == c) { ts.push_back((uint32_t)row[k].slot); tw.push_back(row[k].w); k++; }
+      if (ts.size() >= 0x7FFFFFFFull) return ceed_error("CeedXCsrCreateProduct: more than 2^31 product terms");
+      cl.push_back((uint32_t)c); h_cols.push_back(c); tp.push_back((uint32_t)ts.size());
+    }
+    rp[i + 1] = (uint32_t)cl.size();
+  }
+  const int nnz = (int)cl.size();
+  std::vector<uint32_t> diag((size_t)nrows, 0xFFFFFFFFu);
+  for (int r = 0; r < nrows; r++)
+    for (uint32_t k = rp[r]; k < rp[r + 1]; k++) if ((int)cl[k] == r) diag[r] = k;
+  CeedXCsr A = new CeedXCsr_private;
+  A->ceed = V->ceed; ceed_ref(A->ceed);
+  A->nrows = nrows; A->ncols = ncols; A->nnz = nnz; A->dense = dense != 0;
+  A->h_rowptr.assign(rp.begin(), rp.end()); A->h_cols.swap(h_cols);
+  CHK(csr_upload(&A->d_rowptr, rp)); CHK(csr_upload(&A->d_cols, cl)); CHK(csr_upload(&A->d_diag_slot, diag));
+  CHK(csr_upload(&A->d_termptr, tp)); CHK(csr_upload(&A->d_term_slot, ts));
+  HIPCHK(hipMalloc((void **)&A->d_term_w, sizeof(double) * (tw.size() ? tw.size() : 1)));
+  if (!tw.empty()) HIPCHK(hipMemcpy(A->d_term_w, tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void **)&A->d_vals, sizeof(double) * (nnz ? nnz : 1)));
+  HIPCHK(hipMemset(A->d_vals, 0, sizeof(double) * (nnz ? nnz : 1)));
+  A->src = V; V->refs++;
+  *csr = A;
+  return 0;
+}
+extern "C" int CeedXCsrGetPattern(CeedXCsr A, CeedInt *nrows, CeedInt *ncols, CeedInt *nnz, const CeedInt **rowptr, const CeedInt **cols) {
+  if (nrows) *nrows = A->nrows;
+  if (ncols) *ncols = A->ncols;
+  if (nnz) *nnz = A->nnz;
+  if (rowptr) *rowptr = A->h_rowptr.data();
+  if (cols) *cols = A->h_cols.data();
+  return 0;
+}
+extern "C" int CeedXCsrUpdate(CeedXCsr A) {
+  if (!A->src) return ceed_error("CeedXCsrUpdate: not a product (CeedXCsrCreateProduct)");
+  HIPCHK(launch_csr_combine(A->d_termptr, A->d_term_slot, A->d_term_w, A->src->d_vals, A->d_vals, A->nnz, A->ceed->stream));
+  return 0;
+}
+extern "C" int CeedXCsrGetValues(CeedXCsr A, CeedVector v) {
+  if (v->length < A->nnz) return ceed_error("CeedXCsrGetValues: vector of %d for %d entries", v->length, A->nnz);
+  double *pv;
+  CHK(vec_dev(v, true, &pv));
+  if (A->nnz) HIPCHK(hipMemcpyAsync(pv, A->d_vals, sizeof(double) * A->nnz, hipMemcpyDeviceToDevice, A->ceed->stream));
+  return 0;
+}
+// In-place inverse of a matrix with a FULL pattern (every row holds columns 0..n-1 in order) and symmetric positive
+// definite values: the coarsest level of the aggregation hierarchy, applied afterwards with CeedXCsrApply.
+extern "C" int CeedXCsrInvertDenseSPD(CeedXCsr A) {
+  if (!A->dense) return ceed_error("CeedXCsrInvertDenseSPD: the pattern is not a full square one with ascending columns");
+  if (A->ceed->capturing) return ceed_error("CeedXCsrInvertDenseSPD cannot be recorded into a graph (it reports a status to the host)");
+  if (!A->d_gj) {
+    HIPCHK(hipMalloc((void **)&A->d_gj, sizeof(double) * 32 * 32));
+    HIPCHK(hipMalloc((void **)&A->d_info, sizeof(int)));
+  }
+  HIPCHK(hipMemsetAsync(A->d_info, 0, sizeof(int), A->ceed->stream));
+  HIPCHK(launch_dense_spd_inverse(A->d_vals, A->nrows, A->d_gj, A->d_info, A->ceed->stream));
+  int info = 0;
+  HIPCHK(hipMemcpyAsync(&info, A->d_info, sizeof(int), hipMemcpyDeviceToHost, A->ceed->stream));
+  HIPCHK(hipStreamSynchronize(A->ceed->stream));
+  if (info) return ceed_error("CeedXCsrInvertDenseSPD: pivot %d is not positive: the matrix is not positive definite", info - 1);
+  return 0;
+}
 extern "C" int CeedXCsrDestroy(CeedXCsr *csr) {
   if (!csr || !*csr) return 0;
   CeedXCsr A = *csr;
+  *csr = nullptr;
+  if (--A->refs > 0) return 0;        // still the source of another matrix: freed with the last of those
   (void)hipStreamSynchronize(A->ceed->stream);
-  for (uint32_t *p : {A->d_rowptr, A->d_cols, A->d_slotptr, A->d_perm, A->d_unit_slot, A->d_diag_slot}) if (p) (void)hipFree(p);
-  if (A->d_vals) (void)hipFree(A->d_vals);
+  for (uint32_t *p : {A->d_rowptr, A->d_cols, A->d_slotptr, A->d_perm, A->d_unit_slot, A->d_diag_slot, A->d_termptr, A->d_term_slot})
+    if (p) (void)hipFree(p);
+  for (double *p : {A->d_vals, A->d_term_w, A->d_gj}) if (p) (void)hipFree(p);
+  if (A->d_info) (void)hipFree(A->d_info);
+  CeedXCsr src = A->src;
   ceed_unref(A->ceed);
   delete A;
-  *csr = nullptr;
+  if (src) (void)CeedXCsrDestroy(&src);
   return 0;
 }

@@ -286,6 +286,9 @@ hipError_t launch_csr_sum(const uint32_t *slotptr, const uint32_t *perm, const d
 hipError_t launch_csr_spmv(const uint32_t *rowptr, const uint32_t *cols, const double *vals, const double *x, double *y,
                            int nrows, hipStream_t s);
 hipError_t launch_csr_diag(const uint32_t *diag_slot_of_row, const double *vals, double *d, int nrows, hipStream_t s);
+hipError_t launch_csr_combine(const uint32_t *termptr, const uint32_t *src_slot, const double *w, const double *src, double *vals,
+                              int nnz, hipStream_t s);
+hipError_t launch_dense_spd_inverse(double *A, int n, double *scratch /* 1024 doubles */, int *info, hipStream_t s);
 
 // Vector / restriction utilities.
 hipError_t launch_set_value(double *v, size_t n, double val, hipStream_t s);

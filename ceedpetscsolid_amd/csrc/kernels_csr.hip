@@ -36,6 +36,82 @@ __global__ void k_csr_diag(const uint32_t *diag_slot_of_row, const double *vals,
   }
 }
 
+// vals[s] = sum_k w[k] * src[src_slot[k]] over the terms of slot s, in ascending k (the host sorts the terms by slot): a
+// sparse product with one fixed factor and a fixed result pattern (T = A P, A_c = P^T T of the aggregation hierarchy).
+__global__ void k_csr_combine(const uint32_t *termptr, const uint32_t *src_slot, const double *w, const double *src, double *vals,
+                              int nnz) {
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nnz; s += gridDim.x * blockDim.x) {
+    double a = 0.;
+    for (uint32_t k = termptr[s]; k < termptr[s + 1]; k++) a += w[k] * src[src_slot[k]];
+    vals[s] = a;
+  }
+}
+
+// ---- in-place inverse of a dense SPD matrix (row-major n x n), blocked Gauss-Jordan without pivoting ------------------
+// Block step k with pivot block K and the rest R:  D = inv(A[K,K]);  A[K,R] = D A[K,R];  A[R,R] -= A[R,K] A[K,R];
+// A[R,K] = -A[R,K] D;  A[K,K] = D.  Four small launches per step; the matrix (a few MB) stays in L2.  Ragged last block:
+// loads outside the matrix read the identity, stores outside are dropped.
+constexpr int GJ = 32;
+__device__ inline double gj_load(const double *A, int n, int r, int c) { return (r < n && c < n) ? A[(size_t)r * n + c] : (r == c ? 1. : 0.); }
+// one workgroup of GJ x GJ threads: unblocked Gauss-Jordan of the pivot block in LDS
+__global__ __launch_bounds__(GJ * GJ) void k_gj_pivot(double *A, int n, int k0, double *D, int *info) {
+  __shared__ double M[GJ][GJ + 1];
+  const int i = threadIdx.y, j = threadIdx.x;
+  M[i][j] = gj_load(A, n, k0 + i, k0 + j);
+  __syncthreads();
+  for (int p = 0; p < GJ; p++) {
+    const double piv = M[p][p];
+    if (i == 0 && j == 0 && !(piv > 0.)) *info = k0 + p + 1;      // not positive definite (reported, not repaired)
+    __syncthreads();
+    const double rp = 1. / piv, mip = M[i][p], mpj = M[p][j];
+    __syncthreads();
+    double v;
+    if (i == p) v = (j == p) ? rp : mpj * rp;
+    else v = (j == p) ? -mip * rp : M[i][j] - mip * mpj * rp;
+    M[i][j] = v;
+    __syncthreads();
+  }
+  D[i * GJ + j] = M[i][j];
+  if (k0 + i < n && k0 + j < n) A[(size_t)(k0 + i) * n + k0 + j] = M[i][j];
+}
+// A[K, tile] = D * A[K, tile] for every column tile but the pivot's (mode 0);  A[tile, K] = -A[tile, K] * D (mode 1)
+__global__ __launch_bounds__(GJ * GJ) void k_gj_panel(double *A, int n, int k0, const double *D, int mode) {
+  __shared__ double Ds[GJ][GJ + 1], T[GJ][GJ + 1];
+  const int i = threadIdx.y, j = threadIdx.x, t0 = blockIdx.x * GJ;
+  if (t0 == k0) return;
+  Ds[i][j] = D[i * GJ + j];
+  const int r = mode == 0 ? k0 + i : t0 + i, c = mode == 0 ? t0 + j : k0 + j;
+  T[i][j] = (r < n && c < n) ? A[(size_t)r * n + c] : 0.;
+  __syncthreads();
+  double a = 0.;
+  if (mode == 0) { for (int p = 0; p < GJ; p++) a += Ds[i][p] * T[p][j]; }
+  else           { for (int p = 0; p < GJ; p++) a -= T[i][p] * Ds[p][j]; }
+  if (r < n && c < n) A[(size_t)r * n + c] = a;
+}
+// A[ti, tj] -= A[ti, K] * A[K, tj] for all tiles with ti != K, tj != K
+__global__ __launch_bounds__(GJ * GJ) void k_gj_update(double *A, int n, int k0) {
+  __shared__ double C[GJ][GJ + 1], R[GJ][GJ + 1];
+  const int i = threadIdx.y, j = threadIdx.x, r0 = blockIdx.y * GJ, c0 = blockIdx.x * GJ;
+  if (r0 == k0 || c0 == k0) return;
+  C[i][j] = (r0 + i < n && k0 + j < n) ? A[(size_t)(r0 + i) * n + k0 + j] : 0.;
+  R[i][j] = (k0 + i < n && c0 + j < n) ? A[(size_t)(k0 + i) * n + c0 + j] : 0.;
+  __syncthreads();
+  double a = 0.;
+  for (int p = 0; p < GJ; p++) a += C[i][p] * R[p][j];
+  if (r0 + i < n && c0 + j < n) A[(size_t)(r0 + i) * n + c0 + j] -= a;
+}
+// the inverse of a symmetric matrix is symmetric; rounding is not: A = (A + A^T) / 2, each pair by one thread
+__global__ void k_symmetrize(double *A, int n) {
+  const size_t tot = (size_t)n * n;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(t / n), c = (int)(t % n);
+    if (c < r) {
+      const double m = 0.5 * (A[t] + A[(size_t)c * n + r]);
+      A[t] = m; A[(size_t)c * n + r] = m;
+    }
+  }
+}
+
 static inline dim3 grid_for(size_t n, int per_block) {
   size_t b = (n + per_block - 1) / per_block;
   return dim3((unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b)));
@@ -55,6 +131,27 @@ hipError_t launch_csr_spmv(const uint32_t *rowptr, const uint32_t *cols, const d
 hipError_t launch_csr_diag(const uint32_t *diag_slot_of_row, const double *vals, double *d, int nrows, hipStream_t s) {
   if (nrows <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_csr_diag, grid_for((size_t)nrows, 256), dim3(256), 0, s, diag_slot_of_row, vals, d, nrows);
+  return hipGetLastError();
+}
+hipError_t launch_csr_combine(const uint32_t *termptr, const uint32_t *src_slot, const double *w, const double *src, double *vals,
+                              int nnz, hipStream_t s) {
+  if (nnz <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_csr_combine, grid_for((size_t)nnz, 256), dim3(256), 0, s, termptr, src_slot, w, src, vals, nnz);
+  return hipGetLastError();
+}
+// scratch: GJ * GJ doubles; info: one int, zero on entry, 1-based index of the first non-positive pivot otherwise
+hipError_t launch_dense_spd_inverse(double *A, int n, double *scratch, int *info, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const int nt = (n + GJ - 1) / GJ;
+  for (int k0 = 0; k0 < n; k0 += GJ) {
+    hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(GJ, GJ), 0, s, A, n, k0, scratch, info);
+    if (nt > 1) {
+      hipLaunchKernelGGL(k_gj_panel, dim3(nt), dim3(GJ, GJ), 0, s, A, n, k0, scratch, 0);
+      hipLaunchKernelGGL(k_gj_update, dim3(nt, nt), dim3(GJ, GJ), 0, s, A, n, k0);
+      hipLaunchKernelGGL(k_gj_panel, dim3(nt), dim3(GJ, GJ), 0, s, A, n, k0, scratch, 1);
+    }
+  }
+  hipLaunchKernelGGL(k_symmetrize, grid_for((size_t)n * n, 256), dim3(256), 0, s, A, n);
   return hipGetLastError();
 }
 

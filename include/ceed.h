@@ -304,6 +304,35 @@ CEED_EXTERN int CeedXCsrAssemble(CeedXCsr csr, CeedVector coo_values);
 CEED_EXTERN int CeedXCsrApply(CeedXCsr csr, CeedVector x, CeedVector y);       /* y = A x */
 CEED_EXTERN int CeedXCsrGetDiagonal(CeedXCsr csr, CeedVector d);
 CEED_EXTERN int CeedXCsrDestroy(CeedXCsr *csr);
+/* Algebraic hierarchy under the assembled level: what PCGAMG builds for the  */
+/* reference's coarse solve (elasticity.c:579-581, one V-cycle per outer      */
+/* iteration under KSPPREONLY, :575).  The library supplies the pieces with a */
+/* fixed sparsity, the caller the aggregation (ceedpetscsolid_amd/amg.py):    */
+/*  - CeedXCsrCreateRect: an nrows x ncols matrix; `vals` fixed (prolongation */
+/*    P, restriction P^T) or NULL for zeros;                                  */
+/*    CeedXCsrApply takes x of ncols, y of nrows.                             */
+/*  - CeedXCsrCreateProduct / CeedXCsrUpdate: C = left * right where one      */
+/*    operand carries FIXED values (from CeedXCsrCreateRect) and the other is */
+/*    `variable` (0: left, 1: right): CeedXCsrUpdate(C) recomputes C from the */
+/*    variable operand's current values.  The pattern of C and the term list  */
+/*    of every entry are worked out once, on the host; the update is one      */
+/*    launch that sums each entry's terms in a fixed order (deterministic).   */
+/*    Two of these form the Galerkin product T = A P, A_c = P^T T each Newton */
+/*    step.  dense != 0 gives C the full pattern (for the inverse below).     */
+/*  - CeedXCsrGetPattern: sizes and the host copy of the pattern (borrowed).  */
+/*  - CeedXCsrGetValues: copy of the values in pattern order.                 */
+/*  - CeedXCsrInvertDenseSPD: in-place inverse of a matrix whose pattern is   */
+/*    full (row r holds columns 0..n-1 in order) and whose values are         */
+/*    symmetric positive definite (the coarsest Galerkin matrix); an error    */
+/*    if a pivot is not positive.  Not recordable into a graph.               */
+CEED_EXTERN int CeedXCsrCreateRect(Ceed ceed, CeedInt nrows, CeedInt ncols, const CeedInt *rowptr,
+                                   const CeedInt *cols, const CeedScalar *vals, CeedXCsr *csr);
+CEED_EXTERN int CeedXCsrCreateProduct(CeedXCsr left, CeedXCsr right, int variable, int dense, CeedXCsr *csr);
+CEED_EXTERN int CeedXCsrGetPattern(CeedXCsr csr, CeedInt *nrows, CeedInt *ncols, CeedInt *nnz,
+                                   const CeedInt **rowptr, const CeedInt **cols);
+CEED_EXTERN int CeedXCsrUpdate(CeedXCsr csr);
+CEED_EXTERN int CeedXCsrGetValues(CeedXCsr csr, CeedVector values);
+CEED_EXTERN int CeedXCsrInvertDenseSPD(CeedXCsr csr);
 /* Accumulated device time (ms) and launch count of the operator's dominant   */
 /* kernel since the last reset; measured with hipEvents on the Ceed's stream  */
 /* when timing is enabled.                                                    */

@@ -1146,16 +1146,20 @@ int CeedXHaloDestroy(CeedXHalo *halo) { if (halo && *halo) { free(*halo); *halo 
 
 /* ---- assembled sparse operator (include/ceed.h, CeedXCsr*): plain CSR on the host ------------ */
 struct CeedXCsr_private {
-  CeedInt nrows, nnz, ncoo, n_unit;
+  CeedInt nrows, ncols, nnz, ncoo, n_unit;
   CeedInt *rowptr, *cols, *coo_slot, *unit_rows;
   double  *vals;
+  struct CeedXCsr_private *src;        /* CeedXCsrSetSource */
+  CeedInt *termptr, *term_slot;
+  double  *term_w;
+  int refs, fixed;                     /* fixed: values given to CeedXCsrCreateRect */
 };
 int CeedXCsrCreate(Ceed ceed, CeedInt nrows, const CeedInt *rowptr, const CeedInt *cols, CeedInt ncoo,
                    const CeedInt *coo_slot, CeedInt n_unit, const CeedInt *unit_rows, CeedXCsr *csr) {
   (void)ceed;
   if (nrows < 0 || ncoo < 0 || !rowptr) return oracle_error("CeedXCsrCreate: bad pattern");
   CeedXCsr A = calloc(1, sizeof *A);
-  A->nrows = nrows; A->nnz = rowptr[nrows]; A->ncoo = ncoo; A->n_unit = n_unit;
+  A->nrows = nrows; A->ncols = nrows; A->nnz = rowptr[nrows]; A->ncoo = ncoo; A->n_unit = n_unit; A->refs = 1;
   A->rowptr = malloc(sizeof(CeedInt) * (size_t)(nrows + 1)); memcpy(A->rowptr, rowptr, sizeof(CeedInt) * (size_t)(nrows + 1));
   A->cols = malloc(sizeof(CeedInt) * (size_t)(A->nnz + 1)); memcpy(A->cols, cols, sizeof(CeedInt) * (size_t)A->nnz);
   A->coo_slot = malloc(sizeof(CeedInt) * (size_t)(ncoo + 1)); memcpy(A->coo_slot, coo_slot, sizeof(CeedInt) * (size_t)ncoo);
@@ -1182,7 +1186,7 @@ int CeedXCsrAssemble(CeedXCsr A, CeedVector coo_values) {
 }
 int CeedXCsrApply(CeedXCsr A, CeedVector x, CeedVector y) {
   vec_ensure(x); vec_ensure(y);
-  if (x == y || x->length < A->nrows || y->length < A->nrows) return oracle_error("CeedXCsrApply: bad vectors");
+  if (x == y || x->length < A->ncols || y->length < A->nrows) return oracle_error("CeedXCsrApply: bad vectors");
   for (CeedInt r = 0; r < A->nrows; r++) {
     double a = 0.;
     for (CeedInt k = A->rowptr[r]; k < A->rowptr[r + 1]; k++) a += A->vals[k] * x->array[A->cols[k]];
@@ -1198,10 +1202,141 @@ int CeedXCsrGetDiagonal(CeedXCsr A, CeedVector d) {
   }
   return 0;
 }
+/* the pieces of the aggregation hierarchy (include/ceed.h): plain loops */
+int CeedXCsrCreateRect(Ceed ceed, CeedInt nrows, CeedInt ncols, const CeedInt *rowptr, const CeedInt *cols, const CeedScalar *vals,
+                       CeedXCsr *csr) {
+  (void)ceed;
+  if (nrows < 0 || ncols < 0 || !rowptr) return oracle_error("CeedXCsrCreateRect: bad pattern");
+  const CeedInt nnz = rowptr[nrows];
+  for (CeedInt k = 0; k < nnz; k++) if (cols[k] < 0 || cols[k] >= ncols) return oracle_error("CeedXCsrCreateRect: column out of range");
+  CeedXCsr A = calloc(1, sizeof *A);
+  A->nrows = nrows; A->ncols = ncols; A->nnz = nnz; A->refs = 1;
+  A->rowptr = malloc(sizeof(CeedInt) * (size_t)(nrows + 1)); memcpy(A->rowptr, rowptr, sizeof(CeedInt) * (size_t)(nrows + 1));
+  A->cols = malloc(sizeof(CeedInt) * (size_t)(nnz + 1)); if (nnz) memcpy(A->cols, cols, sizeof(CeedInt) * (size_t)nnz);
+  A->vals = calloc((size_t)(nnz + 1), sizeof(double));
+  if (vals && nnz) memcpy(A->vals, vals, sizeof(double) * (size_t)nnz);
+  A->fixed = vals != NULL;
+  *csr = A;
+  return 0;
+}
+typedef struct { CeedInt col, slot; double w; } ProdTerm;
+static int prodterm_cmp(const void *x, const void *y) {
+  const ProdTerm *a = x, *b = y;
+  if (a->col != b->col) return a->col < b->col ? -1 : 1;
+  return a->slot < b->slot ? -1 : (a->slot > b->slot);
+}
+/* C = left * right with one fixed and one variable operand (include/ceed.h): row-wise, terms of an entry by slot */
+int CeedXCsrCreateProduct(CeedXCsr Lm, CeedXCsr Rm, int variable, int dense, CeedXCsr *csr) {
+  if (!Lm || !Rm || Lm == Rm || (variable != 0 && variable != 1) || Lm->ncols != Rm->nrows) return oracle_error("CeedXCsrCreateProduct: bad operands");
+  CeedXCsr V = variable == 0 ? Lm : Rm, F = variable == 0 ? Rm : Lm;
+  if (!F->fixed) return oracle_error("CeedXCsrCreateProduct: the fixed operand must carry values from CeedXCsrCreateRect");
+  const CeedInt nrows = Lm->nrows, ncols = Rm->ncols;
+  if (dense && nrows != ncols) return oracle_error("CeedXCsrCreateProduct: a dense result must be square");
+  size_t cap_row = 1024, cap_e = 1024, cap_t = 4096, ne = 0, nt = 0;
+  ProdTerm *row = malloc(cap_row * sizeof *row);
+  CeedInt *rp = calloc((size_t)nrows + 1, sizeof *rp), *cl = malloc(cap_e * sizeof *cl), *tp = malloc((cap_e + 1) * sizeof *tp);
+  CeedInt *ts = malloc(cap_t * sizeof *ts);
+  double *tw = malloc(cap_t * sizeof *tw);
+  tp[0] = 0;
+  for (CeedInt i = 0; i < nrows; i++) {
+    size_t nr = 0;
+    for (CeedInt a = Lm->rowptr[i]; a < Lm->rowptr[i + 1]; a++) {
+      const CeedInt j = Lm->cols[a];
+      for (CeedInt b = Rm->rowptr[j]; b < Rm->rowptr[j + 1]; b++) {
+        if (nr == cap_row) { cap_row *= 2; row = realloc(row, cap_row * sizeof *row); }
+        row[nr].col = Rm->cols[b];
+        row[nr].slot = variable == 0 ? a : b;
+        row[nr].w = variable == 0 ? F->vals[b] : F->vals[a];
+        nr++;
+      }
+    }
+    qsort(row, nr, sizeof *row, prodterm_cmp);
+    size_t k = 0;
+    for (CeedInt c = 0; dense ? c < ncols : k < nr; c++) {
+      if (!dense) c = row[k].col;
+      while (k < nr && row[k].col == c) {
+        if (nt == cap_t) { cap_t *= 2; ts = realloc(ts, cap_t * sizeof *ts); tw = realloc(tw, cap_t * sizeof *tw); }
+        ts[nt] = row[k].slot; tw[nt] = row[k].w; nt++; k++;
+      }
+      if (ne == cap_e) { cap_e *= 2; cl = realloc(cl, cap_e * sizeof *cl); tp = realloc(tp, (cap_e + 1) * sizeof *tp); }
+      cl[ne] = c; ne++; tp[ne] = (CeedInt)nt;
+    }
+    rp[i + 1] = (CeedInt)ne;
+  }
+  free(row);
+  CeedXCsr A = calloc(1, sizeof *A);
+  A->nrows = nrows; A->ncols = ncols; A->nnz = (CeedInt)ne; A->refs = 1;
+  A->rowptr = rp; A->cols = cl; A->termptr = tp; A->term_slot = ts; A->term_w = tw;
+  A->vals = calloc(ne + 1, sizeof(double));
+  A->src = V; V->refs++;
+  *csr = A;
+  return 0;
+}
+int CeedXCsrGetPattern(CeedXCsr A, CeedInt *nrows, CeedInt *ncols, CeedInt *nnz, const CeedInt **rowptr, const CeedInt **cols) {
+  if (nrows) *nrows = A->nrows;
+  if (ncols) *ncols = A->ncols;
+  if (nnz) *nnz = A->nnz;
+  if (rowptr) *rowptr = A->rowptr;
+  if (cols) *cols = A->cols;
+  return 0;
+}
+int CeedXCsrUpdate(CeedXCsr A) {
+  if (!A->src) return oracle_error("CeedXCsrUpdate: not a product");
+  for (CeedInt s = 0; s < A->nnz; s++) {
+    double a = 0.;
+    for (CeedInt k = A->termptr[s]; k < A->termptr[s + 1]; k++) a += A->term_w[k] * A->src->vals[A->term_slot[k]];
+    A->vals[s] = a;
+  }
+  return 0;
+}
+int CeedXCsrGetValues(CeedXCsr A, CeedVector v) {
+  vec_ensure(v);
+  if (v->length < A->nnz) return oracle_error("CeedXCsrGetValues: vector too short");
+  memcpy(v->array, A->vals, sizeof(double) * (size_t)A->nnz);
+  return 0;
+}
+/* Cholesky A = L L^T, then A^-1 = L^-T L^-1 (a different algorithm from the device's Gauss-Jordan on purpose) */
+int CeedXCsrInvertDenseSPD(CeedXCsr A) {
+  const CeedInt n = A->nrows;
+  if (A->ncols != n || (long long)A->nnz != (long long)n * n) return oracle_error("CeedXCsrInvertDenseSPD: the pattern is not full");
+  for (CeedInt r = 0; r < n; r++) for (CeedInt c = 0; c < n; c++) if (A->cols[(size_t)r * n + c] != c) return oracle_error("CeedXCsrInvertDenseSPD: columns not in order");
+  double *a = A->vals, *L = calloc((size_t)n * n + 1, sizeof(double)), *X = calloc((size_t)n * n + 1, sizeof(double));
+  for (CeedInt j = 0; j < n; j++) {
+    double d = a[(size_t)j * n + j];
+    for (CeedInt k = 0; k < j; k++) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+    if (!(d > 0.)) { free(L); free(X); return oracle_error("CeedXCsrInvertDenseSPD: pivot %d is not positive", j); }
+    L[(size_t)j * n + j] = sqrt(d);
+    for (CeedInt i = j + 1; i < n; i++) {
+      double v = a[(size_t)i * n + j];
+      for (CeedInt k = 0; k < j; k++) v -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+      L[(size_t)i * n + j] = v / L[(size_t)j * n + j];
+    }
+  }
+  for (CeedInt c = 0; c < n; c++) {            /* X = L^-1, column by column (lower triangular) */
+    X[(size_t)c * n + c] = 1. / L[(size_t)c * n + c];
+    for (CeedInt i = c + 1; i < n; i++) {
+      double v = 0.;
+      for (CeedInt k = c; k < i; k++) v -= L[(size_t)i * n + k] * X[(size_t)k * n + c];
+      X[(size_t)i * n + c] = v / L[(size_t)i * n + i];
+    }
+  }
+  for (CeedInt r = 0; r < n; r++)
+    for (CeedInt c = 0; c <= r; c++) {
+      double v = 0.;
+      for (CeedInt k = r; k < n; k++) v += X[(size_t)k * n + r] * X[(size_t)k * n + c];
+      a[(size_t)r * n + c] = v; a[(size_t)c * n + r] = v;
+    }
+  free(L); free(X);
+  return 0;
+}
 int CeedXCsrDestroy(CeedXCsr *csr) {
   if (!csr || !*csr) return 0;
   CeedXCsr A = *csr;
-  free(A->rowptr); free(A->cols); free(A->coo_slot); free(A->unit_rows); free(A->vals); free(A);
   *csr = NULL;
+  if (--A->refs > 0) return 0;
+  CeedXCsr src = A->src;
+  free(A->rowptr); free(A->cols); free(A->coo_slot); free(A->unit_rows); free(A->vals);
+  free(A->termptr); free(A->term_slot); free(A->term_w); free(A);
+  if (src) CeedXCsrDestroy(&src);
   return 0;
 }

@@ -1,0 +1,206 @@
+"""The coarse solve of the p-multigrid cycle as ONE cycle of an aggregation hierarchy on the assembled matrix (the role of
+PCGAMG under KSPPREONLY, elasticity.c:568-585): the library pieces (`CeedXCsrCreateRect`, `CeedXCsrCreateProduct`,
+`CeedXCsrUpdate`, `CeedXCsrInvertDenseSPD`) against scipy / numpy on the CPU oracle, the device against the oracle, and the
+solve with it against the solve with the Chebyshev coarse solver."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from ceedpetscsolid_amd import ceed as cd
+from ceedpetscsolid_amd.amg import AggregationAMG, aggregate_nodes, rigid_body_prolongation
+from ceedpetscsolid_amd.assembly import AssembledLevel
+from ceedpetscsolid_amd.mesh import hollow_cylinder_mesh, load_mesh_npz
+from ceedpetscsolid_amd.solid import SolidProblem
+from ceedpetscsolid_amd.solver import NewtonPMG
+from conftest import GOLDEN, rel_err
+
+CLAMP = {998: dict(translate=(0.0, -0.05, 0.1)), 999: dict()}
+
+
+def to_scipy(m: cd.Csr) -> sp.csr_matrix:
+    nr, nc, nz, rp, cl = m.pattern()
+    return sp.csr_matrix((m.values(), cl, rp), shape=(nr, nc))
+
+
+def random_pieces(ceed, n=57, nc=13, seed=3):
+    rng = np.random.default_rng(seed)
+    A = sp.random(n, n, density=0.15, random_state=seed, format="csr")
+    A = (A + A.T + sp.diags(np.full(n, 4.0))).tocsr(); A.sort_indices()
+    P = sp.random(n, nc, density=0.3, random_state=seed + 1, format="csr"); P.sort_indices()
+    Pt = P.T.tocsr(); Pt.sort_indices()
+    # the variable operand: an assembled matrix whose COO entries are its own entries
+    a = cd.Csr(ceed, A.indptr, A.indices, np.arange(A.nnz))
+    return rng, A, P, Pt, a
+
+
+def products_follow_the_variable_operand(ceed, tol):
+    rng, A, P, Pt, a = random_pieces(ceed)
+    n, nc = P.shape
+    p, pt = cd.Csr.rect(ceed, n, nc, P.indptr, P.indices, P.data), cd.Csr.rect(ceed, nc, n, Pt.indptr, Pt.indices, Pt.data)
+    T = cd.Csr.product(a, p, variable=0)
+    Ac = cd.Csr.product(pt, T, variable=1, dense=True)
+    assert (Ac.nrows, Ac.ncols, Ac.nnz) == (nc, nc, nc * nc)
+    for trial in range(2):                       # the values change, the patterns and term lists stay
+        vals = A.data * (1.0 + 0.1 * trial * rng.standard_normal(A.nnz))
+        a.assemble(ceed.vector(A.nnz).set_array(vals))
+        T.update(); Ac.update()
+        Av = sp.csr_matrix((vals, A.indices, A.indptr), shape=A.shape)
+        assert abs(to_scipy(T) - Av @ P).max() < tol
+        assert np.abs(to_scipy(Ac).toarray() - (P.T @ Av @ P).toarray()).max() < tol
+    # rectangular apply: x of ncols, y of nrows
+    x = rng.standard_normal(nc)
+    y = ceed.vector(n)
+    p.apply(ceed.vector(nc).set_array(x), y)
+    assert np.abs(y.to_numpy() - P @ x).max() < tol
+    with pytest.raises(cd.CeedError):
+        cd.Csr.product(a, T, variable=0)         # neither operand carries fixed values
+    with pytest.raises(cd.CeedError):
+        cd.Csr.product(p, p, variable=0)         # same matrix twice / shapes do not chain
+
+
+def dense_inverse(ceed, n, tol):
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n))
+    S = B @ B.T + n * np.eye(n)
+    D = cd.Csr.rect(ceed, n, n, np.arange(n + 1) * n, np.tile(np.arange(n), n), S.reshape(-1))
+    D.invert_dense_spd()
+    inv = D.values().reshape(n, n)
+    assert np.abs(inv @ S - np.eye(n)).max() < tol
+    assert np.array_equal(inv, inv.T)
+    # applied like any other matrix
+    x = rng.standard_normal(n)
+    y = ceed.vector(n)
+    D.apply(ceed.vector(n).set_array(x), y)
+    assert rel_err(y.to_numpy(), np.linalg.solve(S, x)) < tol
+    # not positive definite: refused loudly; a sparse pattern: refused
+    S[n // 2, n // 2] = -1.0
+    bad = cd.Csr.rect(ceed, n, n, np.arange(n + 1) * n, np.tile(np.arange(n), n), S.reshape(-1))
+    with pytest.raises(cd.CeedError):
+        bad.invert_dense_spd()
+    if n > 1:
+        eye = cd.Csr.rect(ceed, n, n, np.arange(n + 1), np.arange(n), np.ones(n))
+        with pytest.raises(cd.CeedError):
+            eye.invert_dense_spd()
+
+
+def test_products_follow_the_variable_operand_on_oracle(oracle):
+    products_follow_the_variable_operand(oracle, 1e-13)
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 70])
+def test_dense_inverse_on_oracle(oracle, n):
+    dense_inverse(oracle, n, 1e-11)
+
+
+def test_aggregates_cover_the_graph_and_rigid_body_modes_are_reproduced():
+    mesh = hollow_cylinder_mesh(2, 8, 6)
+    from ceedpetscsolid_amd.mesh import build_dofmap
+    dm = build_dofmap(mesh, 1)
+    # node graph of the p=1 mesh: nodes sharing an element
+    off = dm.elem_nodes.astype(np.int64)
+    r = np.repeat(off, 8, axis=1).reshape(-1); c = np.tile(off, (1, 8)).reshape(-1)
+    G = sp.csr_matrix((np.ones(r.size), (r, c)), shape=(dm.nnodes, dm.nnodes)).tocsr()
+    agg, na = aggregate_nodes(G.indptr, G.indices)
+    assert agg.min() == 0 and agg.max() == na - 1 and np.unique(agg).size == na
+    sizes = np.bincount(agg)
+    assert sizes.min() >= 4 and 8 < sizes.mean() < 60
+    free = np.zeros(3 * dm.nnodes, dtype=bool)
+    P0 = rigid_body_prolongation(agg, na, dm.node_coords, free)
+    assert P0.shape == (3 * dm.nnodes, 6 * na)
+    assert abs(P0.T @ P0 - sp.identity(6 * na)).max() < 1e-12          # orthonormal columns, disjoint supports
+    # every global rigid-body motion lies in the range of P0
+    X = dm.node_coords
+    for u in (np.tile([1.0, 0.0, 0.0], dm.nnodes), np.stack([-X[:, 1], X[:, 0], 0 * X[:, 0]], axis=1).reshape(-1)):
+        assert np.abs(P0 @ (P0.T @ u) - u).max() < 1e-12
+
+
+def hierarchy_on_fixture(ceed):
+    mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_672e_4ss_us.npz"))
+    p = SolidProblem(ceed, mesh, 2, "hyperSS", nu=0.3, E=1e3, bc_sides=[998, 999])
+    U, R = ceed.vector(p.lsize()), ceed.vector(p.lsize())
+    X = p.levels[p.fine].dofmap.node_coords
+    u = 0.02 * np.stack([np.sin(X[:, 1]) * X[:, 2], np.cos(X[:, 0]) * X[:, 2], np.sin(X[:, 0] + X[:, 1])], axis=1).reshape(-1)
+    U.set_array(u * (p.levels[p.fine].mask == 0)); p.form_residual(U, R)
+    a = AssembledLevel(p, 0); a.assemble()
+    amg = AggregationAMG(a); amg.setup()
+    return p, a, amg
+
+
+def test_hierarchy_on_the_assembled_level_on_oracle(oracle):
+    p, a, amg = hierarchy_on_fixture(oracle)
+    A, P, Pt, T = to_scipy(a.csr), to_scipy(amg.P), to_scipy(amg.Pt), to_scipy(amg.T)
+    assert abs(Pt - P.T).max() == 0.0
+    assert abs(T - A @ P).max() < 1e-12 * abs(A).max()
+    Ac = (P.T @ A @ P).toarray()
+    inv = to_scipy(amg.Ac).toarray()
+    assert np.abs(inv @ Ac - np.eye(amg.nc)).max() < 1e-10
+    # constrained rows of the prolongation are empty: the correction leaves Dirichlet dofs alone
+    con = p.levels[0].mask != 0
+    assert abs(P[con]).sum() == 0.0
+    # the coarse correction is the A-orthogonal projection onto range(P): a vector of the range is reproduced
+    n = a.nrows
+    xc = np.random.default_rng(5).standard_normal(amg.nc)
+    r, z = oracle.vector(n).set_array(A @ (P @ xc)), oracle.vector(n)
+    amg.restrict(r); amg.solve_coarsest(); amg.prolong(z)
+    assert rel_err(z.to_numpy(), P @ xc) < 1e-9
+
+
+def test_solve_with_the_aggregation_coarse_solve_on_oracle(oracle):
+    mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_672e_4ss_us.npz"))
+    p = SolidProblem(oracle, mesh, 2, "hyperSS", nu=0.3, E=1e3, bc_sides=[998, 999])
+    ref = NewtonPMG(p, clamp=CLAMP, coarse="assembled", coarse_cheb_its=40, coarse_cheb_ratio=100.0)
+    st_ref = ref.solve(1)
+    s = NewtonPMG(p, clamp=CLAMP, coarse="amg")
+    st = s.solve(1)
+    assert st.converged and st_ref.converged and st.newton_its == st_ref.newton_its
+    assert rel_err(s.U.to_numpy(), ref.U.to_numpy()) < 1e-7
+    assert st.ksp_its < st_ref.ksp_its                  # a better coarse solve, at a fifth of the matrix products per cycle
+    assert st.coarse_its < st_ref.coarse_its / 4
+
+
+# ---- the device against the oracle ------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_products_follow_the_variable_operand_on_device(gpu):
+    products_follow_the_variable_operand(gpu, 1e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 70, 1080])
+def test_dense_inverse_on_device(gpu, n):
+    dense_inverse(gpu, n, 1e-10)
+
+
+@pytest.mark.gpu
+def test_hierarchy_on_device_matches_oracle(oracle, gpu):
+    (po, ao, mo), (pg, ag, mg) = hierarchy_on_fixture(oracle), hierarchy_on_fixture(gpu)
+    assert mo.info["aggregates"] == mg.info["aggregates"] and mo.nc == mg.nc
+    assert rel_err(mg.T.values(), mo.T.values()) < 1e-12
+    # the inverses come from different algorithms (Gauss-Jordan on the device, Cholesky on the host)
+    assert rel_err(mg.Ac.values(), mo.Ac.values()) < 1e-9
+    n = ao.nrows
+    r = np.random.default_rng(9).standard_normal(n) * (po.levels[0].mask == 0)
+    out = []
+    for c, m in ((oracle, mo), (gpu, mg)):
+        z = c.vector(n)
+        m.restrict(c.vector(n).set_array(r)); m.solve_coarsest(); m.prolong(z)
+        out.append(z.to_numpy())
+    assert rel_err(out[1], out[0]) < 1e-9
+
+
+@pytest.mark.gpu
+def test_config3_solve_with_the_aggregation_coarse_solve(gpu):
+    """BASELINE config 3 (hyperSS, cylinder8_5580e_4ss_us, degree 4, 10 increments) with coarse='amg', replayed as a graph:
+    same Newton path and displacement as with the 40-step Chebyshev coarse solve, in well under half the Krylov iterations."""
+    mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_5580e_4ss_us.npz"))
+    tr = (0.0, -0.05, 0.1)
+    res = {}
+    for coarse in ("assembled", "amg"):
+        p = SolidProblem(gpu, mesh, 4, "hyperSS", nu=0.3, E=1e3, bc_sides=[998, 999])
+        s = NewtonPMG(p, clamp={998: dict(translate=tr), 999: dict()}, coarse=coarse, graph=True)
+        st = s.solve(10)
+        assert st.converged and st.increments == 10 and st.newton_its == 30
+        res[coarse] = (s.U.to_numpy(), st.ksp_its, st.seconds)
+    assert rel_err(res["amg"][0], res["assembled"][0]) < 1e-6
+    assert res["amg"][1] < 0.55 * res["assembled"][1], (res["amg"][1], res["assembled"][1])
