@@ -31,6 +31,8 @@ ap.add_argument("--coarse", default="cg", choices=["cg", "chebyshev", "assembled
 ap.add_argument("--graph", action="store_true", help="replay the V-cycle as a hipGraph")
 ap.add_argument("--coarse-cheb-its", type=int, default=40)
 ap.add_argument("--coarse-cheb-ratio", type=float, default=100.0)
+ap.add_argument("--amg-smooth-its", type=int, default=3)
+ap.add_argument("--amg-smooth-ratio", type=float, default=10.0)
 ap.add_argument("--coarse-maxit", type=int, default=200)
 ap.add_argument("--coarse-rtol", type=float, default=1e-3)
 args = ap.parse_args()
@@ -64,7 +66,8 @@ if world > 1:
 tr = tuple(float(t) for t in args.translate.split(","))
 solver = NewtonPMG(prob, clamp={s: (dict(translate=tr) if s == 998 else dict()) for s in bc_sides}, halo=halos, verbose=args.verbose and rank == 0,
                    coarse_maxit=args.coarse_maxit, coarse_rtol=args.coarse_rtol, coarse=args.coarse, graph=args.graph,
-                   coarse_cheb_its=args.coarse_cheb_its, coarse_cheb_ratio=args.coarse_cheb_ratio)
+                   coarse_cheb_its=args.coarse_cheb_its, coarse_cheb_ratio=args.coarse_cheb_ratio,
+                   amg_smooth_its=args.amg_smooth_its, amg_smooth_ratio=args.amg_smooth_ratio)
 t_setup = time.perf_counter() - t0
 st = solver.solve(args.increments)
 u = solver.U.to_numpy().reshape(-1, 3)
