@@ -1757,7 +1757,28 @@ extern "C" int CeedXVectorChebyshevUpdate(CeedVector x, CeedVector d, CeedVector
   CHK(vec_dev(dinv, false, &pi));
   if (t && t != CEED_VECTOR_NONE) CHK(vec_dev(t, false, &pt));
   CHK(vec_dev(r, pt != nullptr, &pr)); CHK(vec_dev(d, true, &pd)); CHK(vec_dev(x, true, &px));
-  HIPCHK(launch_cheb_update(px, pd, pr, pt, pi, c1, c2, assign_x, (size_t)n, x->ceed->stream));
+  HIPCHK(launch_cheb_update(px, pd, pr, nullptr, pt, pi, c1, c2, assign_x, (size_t)n, x->ceed->stream));
+  return 0;
+}
+// first step of a Chebyshev sweep: r = b - t (t may be NULL), d = c1 dinv r, x = d or x + d -- no copy of b into r first
+extern "C" int CeedXVectorChebyshevStart(CeedVector x, CeedVector d, CeedVector r, CeedVector b, CeedVector t, CeedVector dinv,
+                                         double c1, int assign_x) {
+  double *px, *pd, *pr, *pb, *pt = nullptr, *pi;
+  const CeedInt n = x->length;
+  if (d->length != n || r->length != n || b->length != n || dinv->length != n || (t && t != CEED_VECTOR_NONE && t->length != n))
+    return ceed_error("CeedXVectorChebyshevStart: vector lengths differ");
+  if (b == r || b == x || b == d) return ceed_error("CeedXVectorChebyshevStart: the right-hand side must be a vector of its own");
+  CHK(vec_dev(dinv, false, &pi)); CHK(vec_dev(b, false, &pb));
+  if (t && t != CEED_VECTOR_NONE) CHK(vec_dev(t, false, &pt));
+  CHK(vec_dev(r, true, &pr)); CHK(vec_dev(d, true, &pd)); CHK(vec_dev(x, true, &px));
+  HIPCHK(launch_cheb_update(px, pd, pr, pb, pt, pi, c1, 0., assign_x, (size_t)n, x->ceed->stream));
+  return 0;
+}
+extern "C" int CeedXVectorWAXPBY(CeedVector w, double a, CeedVector x, double b, CeedVector y) {
+  if (x->length != w->length || y->length != w->length) return ceed_error("CeedXVectorWAXPBY: vector lengths differ");
+  double *px, *py, *pw;
+  CHK(vec_dev(x, false, &px)); CHK(vec_dev(y, false, &py)); CHK(vec_dev(w, true, &pw));
+  HIPCHK(launch_waxpby(pw, a, px, b, py, (size_t)w->length, w->ceed->stream));
   return 0;
 }
 extern "C" int CeedXVectorDot(CeedVector x, CeedVector y, CeedVector weight, double *result) {
@@ -1773,6 +1794,37 @@ extern "C" int CeedXVectorDot(CeedVector x, CeedVector y, CeedVector weight, dou
   HIPCHK(hipMemcpyAsync(x->ceed->h_scalar, dres, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   *result = *x->ceed->h_scalar;
+  return 0;
+}
+// Scalars that stay on the device: a CeedVector as a small register file, so that a Krylov recurrence with a fixed number
+// of steps (the Lanczos eigenvalue estimate of the smoothers) runs without a host round trip per dot.  All recordable.
+extern "C" int CeedXVectorDotTo(CeedVector x, CeedVector y, CeedVector weight, CeedVector scalars, CeedInt idx) {
+  if (idx < 0 || idx >= scalars->length) return ceed_error("CeedXVectorDotTo: scalar %d of %d", idx, scalars->length);
+  if (y->length != x->length) return ceed_error("CeedXVectorDotTo: vector lengths differ");
+  double *px, *py, *pw = nullptr, *ps;
+  CHK(vec_dev(x, false, &px)); CHK(vec_dev(y, false, &py)); CHK(vec_dev(scalars, true, &ps));
+  if (weight && weight != CEED_VECTOR_NONE) CHK(vec_dev(weight, false, &pw));
+  if (!x->ceed->d_scalar) {
+    if (x->ceed->capturing) return ceed_error("CeedXVectorDotTo: take one dot product before recording (scratch allocation)");
+    HIPCHK(hipMalloc((void **)&x->ceed->d_scalar, sizeof(double) * (1 + 2048)));
+  }
+  HIPCHK(launch_dot(px, py, pw, (size_t)x->length, x->ceed->d_scalar, x->ceed->stream, ps + idx));
+  return 0;
+}
+extern "C" int CeedXScalarDivide(CeedVector scalars, CeedInt dst, CeedInt num, CeedInt den, double scale) {
+  const CeedInt n = scalars->length;
+  if (dst < 0 || dst >= n || num < 0 || num >= n || den >= n) return ceed_error("CeedXScalarDivide: index out of range");
+  double *ps;
+  CHK(vec_dev(scalars, true, &ps));
+  HIPCHK(launch_scalar_div(ps, dst, num, den, scale, scalars->ceed->stream));
+  return 0;
+}
+extern "C" int CeedXVectorAXPBYScalars(CeedVector y, CeedVector scalars, CeedInt ia, double sa, CeedVector x, CeedInt ib, double sb) {
+  if (ia >= scalars->length || ib >= scalars->length) return ceed_error("CeedXVectorAXPBYScalars: index out of range");
+  if (x->length != y->length || x == y) return ceed_error("CeedXVectorAXPBYScalars: bad vectors");
+  double *px, *py, *ps;
+  CHK(vec_dev(x, false, &px)); CHK(vec_dev(scalars, false, &ps)); CHK(vec_dev(y, true, &py));
+  HIPCHK(launch_axpby_dev(py, ps, ia, sa, px, ib, sb, (size_t)y->length, y->ceed->stream));
   return 0;
 }
 

@@ -292,7 +292,8 @@ hipError_t launch_dense_spd_inverse(double *A, int n, double *scratch /* 1024 do
 
 // Vector / restriction utilities.
 hipError_t launch_set_value(double *v, size_t n, double val, hipStream_t s);
-hipError_t launch_cheb_update(double *x, double *d, double *r, const double *t, const double *dinv, double c1, double c2,
+hipError_t launch_waxpby(double *w, double a, const double *x, double b, const double *y, size_t n, hipStream_t s);
+hipError_t launch_cheb_update(double *x, double *d, double *r, const double *r0, const double *t, const double *dinv, double c1, double c2,
                               int assign_x, size_t n, hipStream_t s);
 hipError_t launch_reciprocal(double *v, size_t n, hipStream_t s);
 hipError_t launch_pointwise_mult(double *w, const double *x, const double *y, size_t n, hipStream_t s);
@@ -306,6 +307,8 @@ hipError_t launch_rstr_scatter_add(const uint32_t *off, int nelem, int elemsize,
 hipError_t launch_multiplicity(const uint32_t *off, int nelem, int elemsize, int ncomp, int compstride,
                                double *l, hipStream_t s);
 hipError_t launch_dot(const double *x, const double *y, const double *w, size_t n, double *result_dev,
-                      hipStream_t s);  // result_dev[0] = sum w_i x_i y_i (w may be null), reproducibly; result_dev: 1 + 2048 doubles
+                      hipStream_t s, double *out = nullptr);  // result_dev[0] (and *out) = sum w_i x_i y_i (w may be null), reproducibly; result_dev: 1 + 2048 doubles
+hipError_t launch_scalar_div(double *sc, int dst, int num, int den, double scale, hipStream_t s);
+hipError_t launch_axpby_dev(double *y, const double *sc, int ia, double sa, const double *x, int ib, double sb, size_t n, hipStream_t s);
 
 }  // namespace cps

@@ -308,11 +308,12 @@ __global__ void k_axpby(double *y, double a, const double *x, double b, size_t n
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     y[i] = a * x[i] + (b == 0. ? 0. : b * y[i]);
 }
-__global__ void k_cheb_update(double *x, double *d, double *r, const double *t, const double *dinv, double c1, double c2,
-                              int assign_x, size_t n) {
+__global__ void k_cheb_update(double *x, double *d, double *r, const double *r0, const double *t, const double *dinv, double c1,
+                              double c2, int assign_x, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    double ri = r[i];
-    if (t) { ri -= t[i]; r[i] = ri; }
+    double ri = r0 ? r0[i] : r[i];          // r0: the right-hand side of a first step (r = b - t without a copy of b)
+    if (t) ri -= t[i];
+    if (t || r0) r[i] = ri;
     const double di = c1 * dinv[i] * ri + (c2 == 0. ? 0. : c2 * d[i]);
     d[i] = di;
     x[i] = assign_x ? di : x[i] + di;
@@ -583,7 +584,7 @@ __global__ void k_dot(const double *x, const double *y, const double *w, size_t 
   // per-block partial, summed in a fixed order by k_dot_final: the dot is reproducible run to run
   if (threadIdx.x == 0) result[1 + blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
-__global__ __launch_bounds__(256) void k_dot_final(double *result, int nparts) {
+__global__ __launch_bounds__(256) void k_dot_final(double *result, int nparts, double *out) {
   __shared__ double sh[256];
   double s = 0.;
   for (int i = threadIdx.x; i < nparts; i += 256) s += result[1 + i];
@@ -593,7 +594,20 @@ __global__ __launch_bounds__(256) void k_dot_final(double *result, int nparts) {
     if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) result[0] = sh[0];
+  if (threadIdx.x == 0) { result[0] = sh[0]; if (out) *out = sh[0]; }
+}
+// scalars kept on the device (a Krylov recurrence without a host round trip per dot): s[dst] = scale * s[num] / s[den]
+// (den < 0: no division); a non-positive denominator gives 0, which the host reads as "breakdown" afterwards
+__global__ void k_scalar_div(double *s, int dst, int num, int den, double scale) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double d = den < 0 ? 1. : s[den];
+    s[dst] = (den < 0 || d > 0.) ? scale * s[num] / d : 0.;
+  }
+}
+// y = sa * (ia < 0 ? 1 : s[ia]) * x + sb * (ib < 0 ? 1 : s[ib]) * y
+__global__ void k_axpby_dev(double *y, const double *s, int ia, double sa, const double *x, int ib, double sb, size_t n) {
+  const double a = sa * (ia < 0 ? 1. : s[ia]), b = sb * (ib < 0 ? 1. : s[ib]);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = a * x[i] + b * y[i];
 }
 
 hipError_t launch_set_value(double *v, size_t n, double val, hipStream_t s) {
@@ -611,15 +625,23 @@ hipError_t launch_pointwise_mult(double *w, const double *x, const double *y, si
   hipLaunchKernelGGL(k_pointwise_mult, stream_grid(n), dim3(256), 0, s, w, x, y, n);
   return hipGetLastError();
 }
+__global__ void k_waxpby(double *w, double a, const double *x, double b, const double *y, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) w[i] = a * x[i] + b * y[i];
+}
+hipError_t launch_waxpby(double *w, double a, const double *x, double b, const double *y, size_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_waxpby, stream_grid(n), dim3(256), 0, s, w, a, x, b, y, n);
+  return hipGetLastError();
+}
 hipError_t launch_axpby(double *y, double a, const double *x, double b, size_t n, hipStream_t s) {
   if (!n) return hipSuccess;
   hipLaunchKernelGGL(k_axpby, stream_grid(n), dim3(256), 0, s, y, a, x, b, n);
   return hipGetLastError();
 }
-hipError_t launch_cheb_update(double *x, double *d, double *r, const double *t, const double *dinv, double c1, double c2,
+hipError_t launch_cheb_update(double *x, double *d, double *r, const double *r0, const double *t, const double *dinv, double c1, double c2,
                               int assign_x, size_t n, hipStream_t s) {
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(k_cheb_update, stream_grid(n), dim3(256), 0, s, x, d, r, t, dinv, c1, c2, assign_x, n);
+  hipLaunchKernelGGL(k_cheb_update, stream_grid(n), dim3(256), 0, s, x, d, r, r0, t, dinv, c1, c2, assign_x, n);
   return hipGetLastError();
 }
 hipError_t launch_masked_copy(double *dst, const double *src, const unsigned char *mask, size_t n, hipStream_t s) {
@@ -654,11 +676,20 @@ hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const u
   hipLaunchKernelGGL(k_assemble, dim3((unsigned)((std::max(nnodes, 1) + 255) / 256)), dim3(256), 0, s, rowptr, cols, node_off, flags, evec, y, nnodes, add, queue_reset);
   return hipGetLastError();
 }
-hipError_t launch_dot(const double *x, const double *y, const double *w, size_t n, double *result_dev, hipStream_t s) {
-  // result_dev: 1 + 2048 doubles ([0] the result, then the per-block partials)
+hipError_t launch_dot(const double *x, const double *y, const double *w, size_t n, double *result_dev, hipStream_t s, double *out) {
+  // result_dev: 1 + 2048 doubles ([0] the result, then the per-block partials); out: a second, device-side destination
   const dim3 g = n ? stream_grid(n) : dim3(1);
   hipLaunchKernelGGL(k_dot, g, dim3(256), 0, s, x, y, w, n, result_dev);
-  hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(256), 0, s, result_dev, (int)g.x);
+  hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(256), 0, s, result_dev, (int)g.x, out);
+  return hipGetLastError();
+}
+hipError_t launch_scalar_div(double *sc, int dst, int num, int den, double scale, hipStream_t s) {
+  hipLaunchKernelGGL(k_scalar_div, dim3(1), dim3(64), 0, s, sc, dst, num, den, scale);
+  return hipGetLastError();
+}
+hipError_t launch_axpby_dev(double *y, const double *sc, int ia, double sa, const double *x, int ib, double sb, size_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_axpby_dev, stream_grid(n), dim3(256), 0, s, y, sc, ia, sa, x, ib, sb, n);
   return hipGetLastError();
 }
 

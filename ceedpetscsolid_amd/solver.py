@@ -137,6 +137,7 @@ class NewtonPMG:
         self.w = [{k: mk(lv) for k in ("x", "b", "r", "d", "t", "dinv", "z")} for lv in range(self.nlev)]
         self.emax = [1.0] * self.nlev
         self._x0 = {}
+        self._scal = None
         n = prob.lsize()
         top = self.nlev - 1
         self.U, self.R, self.dU, self.Xloc, self.bcv, self.Rtry, self.Utry = (self._vec(n, top) for _ in range(7))
@@ -170,6 +171,9 @@ class NewtonPMG:
     # ---- vector helpers ---------------------------------------------------------------------
     def axpby(self, y, a, x, b):
         self.L.chk(self.L.lib.CeedXVectorAXPBY(y.h, C.c_double(a), x.h, C.c_double(b)))
+
+    def waxpby(self, w, a, x, b, y):
+        self.L.chk(self.L.lib.CeedXVectorWAXPBY(w.h, C.c_double(a), x.h, C.c_double(b), y.h))
 
     def copy(self, dst, src):
         self.axpby(dst, 1.0, src, 0.0)
@@ -288,14 +292,14 @@ class NewtonPMG:
             w = self.w[lv]
             self.p.get_diag(lv, w["dinv"])
             self._halo_sum(lv, w["dinv"])
-            d = w["dinv"].to_numpy()
+            # 1 / diagonal; constrained rows come out of the masked operator as zeros and stay zero (CeedVectorReciprocal
+            # leaves zeros alone): residuals and corrections are zero there anyway.  No trip through the host.
+            w["dinv"].reciprocal()
+            if hasattr(w["dinv"], "t"):
+                self._touched(w["dinv"])
             mask = self.p.levels[lv].mask != 0
-            d[mask] = 1.0                       # constrained rows: identity
-            self._set(w["dinv"], 1.0 / d)
-            # largest eigenvalue of D^-1 A by power iteration from a noisy start (the reference lets
-            # PETSc estimate it with a few CG-Lanczos steps on a noisy right-hand side, :546-549).
-            # The start vector is drawn once per level; no BLAS on the host (a threaded BLAS call
-            # leaves its worker pool spinning, which starves a CPU-quota'd process for ~0.1 s a call).
+            # The start vector of the eigenvalue estimate is drawn once per level; no BLAS on the host (a threaded BLAS
+            # call leaves its worker pool spinning, which starves a CPU-quota'd process for ~0.1 s a call).
             if lv not in self._x0:
                 if self.halos:   # shared nodes must get the same value on every rank: a hash of the coordinates
                     X = self.p.levels[lv].dofmap.node_coords
@@ -303,28 +307,14 @@ class NewtonPMG:
                     v = np.sin(X @ k.T) * 437.5453
                     x = (2.0 * (v - np.floor(v)) - 1.0).reshape(-1) * (~mask)
                 else:
-                    x = np.random.default_rng(1234 + lv).uniform(-1, 1, d.size) * (~mask)
-                self._x0[lv] = x / np.sqrt(np.square(x).sum())     # (any positive scale: the iteration renormalises)
+                    x = np.random.default_rng(1234 + lv).uniform(-1, 1, mask.size) * (~mask)
+                x0 = self._vec(mask.size, lv)
+                self._set(x0, x / np.sqrt(np.square(x).sum()))     # (any positive scale: the iteration renormalises)
+                self._x0[lv] = x0
             # largest eigenvalue of D^-1 A: 10 steps of Jacobi-preconditioned CG on the noisy right-hand side and
             # the largest eigenvalue of its Lanczos tridiagonal -- what KSPChebyshevEstEig does (elasticity.c:546-549).
             # (A plain power iteration from the same vector was 2x low after 12 steps on the config-3 mesh.)
-            r, z, pv, Ap = w["r"], w["z"], w["d"], w["t"]
-            self._set(r, self._x0[lv])
-            self.pmult(z, r, w["dinv"]); self.copy(pv, z)
-            rz = self.dot(r, z, lv=lv)
-            alphas, betas = [], []
-            for _ in range(10):
-                self.A(lv, pv, Ap)
-                pAp = self.dot(pv, Ap, lv=lv)
-                if not (pAp > 0.0 and rz > 0.0):
-                    break
-                alpha = rz / pAp
-                self.axpby(r, -alpha, Ap, 1.0)
-                self.pmult(z, r, w["dinv"])
-                rz_new = self.dot(r, z, lv=lv)
-                alphas.append(alpha); betas.append(rz_new / rz)
-                self.axpby(pv, 1.0, z, rz_new / rz)
-                rz = rz_new
+            alphas, betas = self._lanczos_host(lv, 10) if self.halos else self._lanczos_device(lv, 10)
             k = len(alphas)
             T = np.zeros((max(k, 1), max(k, 1)))
             for j in range(k):
@@ -332,6 +322,60 @@ class NewtonPMG:
                 if j + 1 < k:
                     T[j, j + 1] = T[j + 1, j] = np.sqrt(max(betas[j], 0.0)) / alphas[j]
             self.emax[lv] = float(np.linalg.eigvalsh(T).max()) if k else 1.0
+
+    def _lanczos_host(self, lv, steps):
+        """CG coefficients with every dot product read on the host (several ranks: the dots are all-reduced)."""
+        w = self.w[lv]
+        r, z, pv, Ap = w["r"], w["z"], w["d"], w["t"]
+        self.copy(r, self._x0[lv])
+        self.pmult(z, r, w["dinv"]); self.copy(pv, z)
+        rz = self.dot(r, z, lv=lv)
+        alphas, betas = [], []
+        for _ in range(steps):
+            self.A(lv, pv, Ap)
+            pAp = self.dot(pv, Ap, lv=lv)
+            if not (pAp > 0.0 and rz > 0.0):
+                break
+            alpha = rz / pAp
+            self.axpby(r, -alpha, Ap, 1.0)
+            self.pmult(z, r, w["dinv"])
+            rz_new = self.dot(r, z, lv=lv)
+            alphas.append(alpha); betas.append(rz_new / rz)
+            self.axpby(pv, 1.0, z, rz_new / rz)
+            rz = rz_new
+        return alphas, betas
+
+    def _lanczos_device(self, lv, steps):
+        """The same recurrence with its scalars kept on the device (CeedXVectorDotTo / CeedXScalarDivide /
+        CeedXVectorAXPBYScalars): one read of the 2 * steps coefficients at the end instead of 2 * steps + 1 host round
+        trips.  Scalar slots: 0 / 3 rz of the even / odd steps, 1 pAp; 8 + 2 j alpha_j, 9 + 2 j beta_j."""
+        w, lib, chk = self.w[lv], self.L.lib, self.L.chk
+        r, z, pv, Ap = w["r"], w["z"], w["d"], w["t"]
+        if self._scal is None:
+            self._scal = self.ceed.vector(8 + 2 * 16)
+        sc = self._scal
+        sc.set_value(0.0)
+        self.copy(r, self._x0[lv])
+        self.pmult(z, r, w["dinv"]); self.copy(pv, z)
+        one, neg = C.c_double(1.0), C.c_double(-1.0)
+        chk(lib.CeedXVectorDotTo(r.h, z.h, None, sc.h, 0))
+        for j in range(steps):
+            rz, rz_new, ja, jb = (0, 3, 8 + 2 * j, 9 + 2 * j) if j % 2 == 0 else (3, 0, 8 + 2 * j, 9 + 2 * j)
+            self.A(lv, pv, Ap)
+            chk(lib.CeedXVectorDotTo(pv.h, Ap.h, None, sc.h, 1))
+            chk(lib.CeedXScalarDivide(sc.h, ja, rz, 1, one))                           # alpha_j = rz / pAp (0 on breakdown)
+            chk(lib.CeedXVectorAXPBYScalars(r.h, sc.h, ja, neg, Ap.h, -1, one))         # r -= alpha Ap
+            self.pmult(z, r, w["dinv"])
+            chk(lib.CeedXVectorDotTo(r.h, z.h, None, sc.h, rz_new))
+            chk(lib.CeedXScalarDivide(sc.h, jb, rz_new, rz, one))                       # beta_j = rz_new / rz
+            chk(lib.CeedXVectorAXPBYScalars(pv.h, sc.h, -1, one, z.h, jb, one))         # p = z + beta p
+        v = sc.to_numpy()
+        alphas, betas = [], []
+        for j in range(steps):
+            if not (v[8 + 2 * j] > 0.0) or not np.isfinite(v[9 + 2 * j]):
+                break
+            alphas.append(float(v[8 + 2 * j])); betas.append(float(v[9 + 2 * j]))
+        return alphas, betas
 
     def chebyshev(self, lv, b, x, its, zero_guess, lmin_frac=0.1):
         """Chebyshev iteration on D^-1 A with bounds [0.1, 1.1] x emax (KSPChebyshevEstEigSet(0,0.1,0,1.1))."""
@@ -342,13 +386,13 @@ class NewtonPMG:
         rho = 1.0 / sigma
         r, d, t = w["r"], w["d"], w["t"]
         upd = self.L.lib.CeedXVectorChebyshevUpdate
-        # first step: r = b - A x;  d = dinv r / theta;  x (+)= d      (fused: one pass over the vectors)
-        self.copy(r, b)
+        # first step: r = b - A x;  d = dinv r / theta;  x (+)= d      (fused: one pass over the vectors, b read in place)
+        start = self.L.lib.CeedXVectorChebyshevStart
         if zero_guess:
-            self.L.chk(upd(x.h, d.h, r.h, None, w["dinv"].h, C.c_double(1.0 / theta), C.c_double(0.0), 1))
+            self.L.chk(start(x.h, d.h, r.h, b.h, None, w["dinv"].h, C.c_double(1.0 / theta), 1))
         else:
             self.A(lv, x, t)
-            self.L.chk(upd(x.h, d.h, r.h, t.h, w["dinv"].h, C.c_double(1.0 / theta), C.c_double(0.0), 0))
+            self.L.chk(start(x.h, d.h, r.h, b.h, t.h, w["dinv"].h, C.c_double(1.0 / theta), 0))
         for k in range(1, its):
             self.A(lv, d, t)
             rho_new = 1.0 / (2.0 * sigma - rho)
@@ -385,7 +429,7 @@ class NewtonPMG:
         lf = 1.0 / self.amg_smooth_ratio
         self.chebyshev(0, b, x, self.amg_smooth_its, True, lf)
         self.A(0, x, w["t"])
-        self.copy(w["z"], b); self.axpby(w["z"], -1.0, w["t"], 1.0)      # residual
+        self.waxpby(w["z"], 1.0, b, -1.0, w["t"])                          # residual
         amg.restrict(w["z"])
         amg.solve_coarsest()
         amg.prolong(w["z"])
@@ -409,7 +453,7 @@ class NewtonPMG:
         w, wc = self.w[lv], self.w[lv - 1]
         self.chebyshev(lv, b, x, self.smooth_its, True)
         self.A(lv, x, w["t"])
-        self.copy(w["z"], b); self.axpby(w["z"], -1.0, w["t"], 1.0)      # residual
+        self.waxpby(w["z"], 1.0, b, -1.0, w["t"])                          # residual
         self.p.restrict(lv, w["z"], wc["b"])                                # Restrict_Ceed
         self._halo_sum(lv - 1, wc["b"])
         self.vcycle(lv - 1, wc["b"], wc["x"])

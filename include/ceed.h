@@ -277,6 +277,19 @@ CEED_EXTERN int CeedXVectorAXPBY(CeedVector y, double a, CeedVector x,
                                  double b);
 CEED_EXTERN int CeedXVectorDot(CeedVector x, CeedVector y,
                                CeedVector weight /* or NULL */, double *result);
+/* Scalars that stay in backend memory: a CeedVector as a register file, for  */
+/* recurrences with a fixed number of steps (KSPChebyshevEstEig's Lanczos,    */
+/* elasticity.c:546-549) without a host round trip per dot:                    */
+/*   DotTo: scalars[idx] = sum weight .* x .* y;                               */
+/*   ScalarDivide: scalars[dst] = scale * scalars[num] / scalars[den]          */
+/*     (den < 0: no division; a non-positive denominator gives 0);             */
+/*   AXPBYScalars: y = a x + b y, a = sa * scalars[ia], b = sb * scalars[ib];  */
+/*     a negative index stands for the constant 1.                            */
+CEED_EXTERN int CeedXVectorDotTo(CeedVector x, CeedVector y, CeedVector weight /* or NULL */,
+                                 CeedVector scalars, CeedInt idx);
+CEED_EXTERN int CeedXScalarDivide(CeedVector scalars, CeedInt dst, CeedInt num, CeedInt den, double scale);
+CEED_EXTERN int CeedXVectorAXPBYScalars(CeedVector y, CeedVector scalars, CeedInt ia, double sa,
+                                        CeedVector x, CeedInt ib, double sb);
 /* One Jacobi-Chebyshev smoother update in a single pass over the vectors     */
 /* (the KSPCHEBYSHEV + PCJACOBI smoother of elasticity.c:539-552):            */
 /*   r -= t (skipped if t is NULL);  d = c1 * dinv .* r + c2 * d;             */
@@ -284,6 +297,13 @@ CEED_EXTERN int CeedXVectorDot(CeedVector x, CeedVector y,
 CEED_EXTERN int CeedXVectorChebyshevUpdate(CeedVector x, CeedVector d, CeedVector r,
                                            CeedVector t /* or NULL */, CeedVector dinv,
                                            double c1, double c2, int assign_x);
+/* First step of a sweep, without copying the right-hand side into r first:   */
+/*   r = b - t (t may be NULL);  d = c1 * dinv .* r;  x = d if assign_x else  */
+/*   x + d.  And w = a x + b y (VecWAXPY-like; the residual z = b - A x).     */
+CEED_EXTERN int CeedXVectorChebyshevStart(CeedVector x, CeedVector d, CeedVector r, CeedVector b,
+                                          CeedVector t /* or NULL */, CeedVector dinv,
+                                          double c1, int assign_x);
+CEED_EXTERN int CeedXVectorWAXPBY(CeedVector w, double a, CeedVector x, double b, CeedVector y);
 /* Assembled sparse operator on L-vectors: the coarse level of the multigrid. */
 /* The reference builds it by finite-difference colouring of the p=1 operator */
 /* (misc.c:151-183, elasticity.c:457-483) and hands it to GAMG; here the      */

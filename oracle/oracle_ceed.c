@@ -1100,6 +1100,28 @@ int CeedXVectorAXPBY(CeedVector y, double a, CeedVector x, double b) {
   for (CeedInt i = 0; i < y->length; i++) y->array[i] = a * x->array[i] + (b == 0. ? 0. : b * y->array[i]);
   return 0;
 }
+int CeedXVectorWAXPBY(CeedVector w, double a, CeedVector x, double b, CeedVector y) {
+  vec_ensure(x); vec_ensure(y); vec_ensure(w);
+  if (x->length != w->length || y->length != w->length) return oracle_error("CeedXVectorWAXPBY: vector lengths differ");
+  for (CeedInt i = 0; i < w->length; i++) w->array[i] = a * x->array[i] + b * y->array[i];
+  return 0;
+}
+int CeedXVectorChebyshevStart(CeedVector x, CeedVector d, CeedVector r, CeedVector b, CeedVector t, CeedVector dinv,
+                              double c1, int assign_x) {
+  vec_ensure(x); vec_ensure(d); vec_ensure(r); vec_ensure(b); vec_ensure(dinv);
+  const int have_t = t && t != CEED_VECTOR_NONE;
+  if (have_t) vec_ensure(t);
+  if (b == r || b == x || b == d) return oracle_error("CeedXVectorChebyshevStart: the right-hand side must be a vector of its own");
+  for (CeedInt i = 0; i < x->length; i++) {
+    double ri = b->array[i];
+    if (have_t) ri -= t->array[i];
+    r->array[i] = ri;
+    const double di = c1 * dinv->array[i] * ri;
+    d->array[i] = di;
+    x->array[i] = assign_x ? di : x->array[i] + di;
+  }
+  return 0;
+}
 int CeedXVectorChebyshevUpdate(CeedVector x, CeedVector d, CeedVector r, CeedVector t, CeedVector dinv,
                                double c1, double c2, int assign_x) {
   vec_ensure(x); vec_ensure(d); vec_ensure(r); vec_ensure(dinv);
@@ -1123,6 +1145,26 @@ int CeedXVectorDot(CeedVector x, CeedVector y, CeedVector weight, double *result
     for (CeedInt i = 0; i < x->length; i++) s += x->array[i] * y->array[i];
   }
   *result = s;
+  return 0;
+}
+int CeedXVectorDotTo(CeedVector x, CeedVector y, CeedVector weight, CeedVector scalars, CeedInt idx) {
+  vec_ensure(scalars);
+  if (idx < 0 || idx >= scalars->length) return oracle_error("CeedXVectorDotTo: index out of range");
+  return CeedXVectorDot(x, y, weight, &scalars->array[idx]);
+}
+int CeedXScalarDivide(CeedVector scalars, CeedInt dst, CeedInt num, CeedInt den, double scale) {
+  vec_ensure(scalars);
+  const CeedInt n = scalars->length;
+  if (dst < 0 || dst >= n || num < 0 || num >= n || den >= n) return oracle_error("CeedXScalarDivide: index out of range");
+  const double d = den < 0 ? 1. : scalars->array[den];
+  scalars->array[dst] = (den < 0 || d > 0.) ? scale * scalars->array[num] / d : 0.;
+  return 0;
+}
+int CeedXVectorAXPBYScalars(CeedVector y, CeedVector scalars, CeedInt ia, double sa, CeedVector x, CeedInt ib, double sb) {
+  vec_ensure(x); vec_ensure(y); vec_ensure(scalars);
+  if (ia >= scalars->length || ib >= scalars->length || x == y || x->length != y->length) return oracle_error("CeedXVectorAXPBYScalars: bad arguments");
+  const double a = sa * (ia < 0 ? 1. : scalars->array[ia]), b = sb * (ib < 0 ? 1. : scalars->array[ib]);
+  for (CeedInt i = 0; i < y->length; i++) y->array[i] = a * x->array[i] + b * y->array[i];
   return 0;
 }
 int CeedXOperatorSetTiming(CeedOperator op, int enable) { (void)op; (void)enable; return 0; }

@@ -200,3 +200,74 @@ def test_assembled_coarse_level_on_device(oracle, gpu):
     s = NewtonPMG(p, clamp=CLAMP, coarse="assembled", coarse_cheb_its=20, coarse_cheb_ratio=50.0, graph=True)
     assert s.solve(2).converged
     assert rel_err(s.U.to_numpy(), ref.U.to_numpy()) < 1e-8
+
+
+def vector_helpers(ceed, tol):
+    """CeedXVectorChebyshevStart / WAXPBY / DotTo / ScalarDivide / AXPBYScalars against numpy."""
+    import ctypes as C
+    L = ceed.L
+    rng = np.random.default_rng(11)
+    n = 1000
+    a = {k: rng.standard_normal(n) for k in ("x", "d", "r", "b", "t", "dinv", "y")}
+    v = {k: ceed.vector(n).set_array(val.copy()) for k, val in a.items()}
+    L.chk(L.lib.CeedXVectorChebyshevStart(v["x"].h, v["d"].h, v["r"].h, v["b"].h, v["t"].h, v["dinv"].h, C.c_double(0.7), 0))
+    r = a["b"] - a["t"]; d = 0.7 * a["dinv"] * r
+    assert np.abs(v["r"].to_numpy() - r).max() < tol and np.abs(v["d"].to_numpy() - d).max() < tol
+    assert np.abs(v["x"].to_numpy() - (a["x"] + d)).max() < tol
+    L.chk(L.lib.CeedXVectorChebyshevStart(v["x"].h, v["d"].h, v["r"].h, v["b"].h, None, v["dinv"].h, C.c_double(0.7), 1))
+    assert np.abs(v["r"].to_numpy() - a["b"]).max() < tol and np.abs(v["x"].to_numpy() - 0.7 * a["dinv"] * a["b"]).max() < tol
+    with pytest.raises(Exception):
+        L.chk(L.lib.CeedXVectorChebyshevStart(v["x"].h, v["d"].h, v["r"].h, v["r"].h, None, v["dinv"].h, C.c_double(0.7), 1))
+    w = ceed.vector(n)
+    L.chk(L.lib.CeedXVectorWAXPBY(w.h, C.c_double(2.0), v["b"].h, C.c_double(-3.0), v["t"].h))
+    assert np.abs(w.to_numpy() - (2.0 * a["b"] - 3.0 * a["t"])).max() < tol
+    sc = ceed.vector(8).set_value(0.0)
+    L.chk(L.lib.CeedXVectorDotTo(v["b"].h, v["t"].h, None, sc.h, 2))
+    L.chk(L.lib.CeedXVectorDotTo(v["b"].h, v["b"].h, v["dinv"].h, sc.h, 3))
+    L.chk(L.lib.CeedXScalarDivide(sc.h, 4, 2, 3, C.c_double(-2.0)))
+    L.chk(L.lib.CeedXScalarDivide(sc.h, 5, 2, -1, C.c_double(1.0)))
+    L.chk(L.lib.CeedXScalarDivide(sc.h, 6, 2, 7, C.c_double(1.0)))          # zero denominator: 0, not inf
+    s = sc.to_numpy()
+    bt, bwb = a["b"] @ a["t"], (a["dinv"] * a["b"]) @ a["b"]
+    assert abs(s[2] - bt) < 100 * tol and abs(s[3] - bwb) < 100 * tol
+    assert abs(s[4] - (-2.0 * bt / bwb if bwb > 0 else 0.0)) < 100 * tol and s[5] == s[2] and s[6] == 0.0
+    L.chk(L.lib.CeedXVectorAXPBYScalars(v["y"].h, sc.h, 2, C.c_double(-1.0), v["b"].h, -1, C.c_double(0.5)))
+    assert np.abs(v["y"].to_numpy() - (-s[2] * a["b"] + 0.5 * a["y"])).max() < 1e3 * tol
+    with pytest.raises(Exception):
+        L.chk(L.lib.CeedXVectorDotTo(v["b"].h, v["t"].h, None, sc.h, 8))
+
+
+def test_vector_helpers_on_oracle(oracle):
+    vector_helpers(oracle, 1e-14)
+
+
+@pytest.mark.gpu
+def test_vector_helpers_on_device(gpu):
+    vector_helpers(gpu, 1e-13)
+
+
+def lanczos_paths_agree(ceed, tol):
+    mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_672e_4ss_us.npz"))
+    p = SolidProblem(ceed, mesh, 2, "hyperSS", nu=0.3, E=1e3, bc_sides=[998, 999])
+    s = NewtonPMG(p, clamp=CLAMP, coarse="assembled")
+    s.U.set_value(0.0); s._set(s.bcv, s.bc_values(0.5)); s.residual(s.U, s.R)
+    s.setup_preconditioner()
+    for lv in range(s.nlev):
+        ah, bh = s._lanczos_host(lv, 10)
+        ad, bd = s._lanczos_device(lv, 10)
+        assert len(ah) == len(ad) == 10
+        assert rel_err(np.array(ad), np.array(ah)) < tol and rel_err(np.array(bd), np.array(bh)) < tol
+        assert 1.0 < s.emax[lv] < 10.0
+    # the reciprocal of the diagonal never left the device: zeros (constrained rows) stay zeros, the rest is positive
+    for lv in range(s.nlev):
+        d = s.w[lv]["dinv"].to_numpy(); m = p.levels[lv].mask != 0
+        assert np.all(d[m] == 0.0) and np.all(d[~m] > 0.0)
+
+
+def test_eigenvalue_estimate_with_device_scalars_equals_host_path_on_oracle(oracle):
+    lanczos_paths_agree(oracle, 1e-15)
+
+
+@pytest.mark.gpu
+def test_eigenvalue_estimate_with_device_scalars_equals_host_path_on_device(gpu):
+    lanczos_paths_agree(gpu, 1e-12)
