@@ -294,6 +294,9 @@ def main():
         P, Q = args.degree + 1, args.degree + 1
         abytes = algorithmic_bytes(mesh.nelem, P, Q, n, args.problem != "linElas")
         avg_s = kernel_ms * 1e-3 / max(args.steps, 1)   # per APPLY (a split-phase apply is two timed launch pairs)
+        li = op.launch_info()
+        assembly_form = ("pipelined: %d segments on %d streams, last segment %d elements" % (li["segments"], li["streams"], li["last_segment_elements"])
+                         if li["segments"] > 1 else os.environ.get("CEED_MI355X_ASSEMBLE", "serial (launch too small to pipeline, split-phase apply, or switched off)"))
         achieved = abytes / avg_s / 1e9
         traffic, traffic_src = traffic_from_profile(op.kernel_name, mesh.nelem)
         out = {
@@ -314,7 +317,7 @@ def main():
                                     f"degree {args.degree}, Q={Q}, z faces clamped, Jacobian apply y=J(u)x"),
                        "global_dofs": n_global, "elements_per_gpu": mesh.nelem, "ldofs_per_gpu": n,
                        "halo_dofs_rank0": halo.n_shared_dofs, "kernel": op.kernel_name,
-                       "assembly": os.environ.get("CEED_MI355X_ASSEMBLE", "serial"), "schedule": os.environ.get("CEED_MI355X_SCHED", "static"),
+                       "assembly": assembly_form, "schedule": os.environ.get("CEED_MI355X_SCHED", "static"),
                        "partition": ((("z-layers of ONE mesh" if args.workload != "box" else "blocks %dx%dx%d of ONE box" % __import__("ceedpetscsolid_amd.halo", fromlist=["block_grid"]).block_grid(world)) if strong else "one such mesh per GPU (z-slabs)")
                                      + "; halo sum " + ("overlapped with interior elements" if overlap else "after the apply")
                                      + (" through CeedXHalo* (RCCL group of ncclSend/ncclRecv, pack / unpack-add kernels)" if use_rccl else " through torch.distributed P2P"))
@@ -329,7 +332,10 @@ def main():
                          "measured_traffic_GBs": (traffic / avg_s / 1e9) if traffic else None,
                          "algorithmic_bytes_per_launch": abytes, "kernel_avg_us": avg_s * 1e6,
                          "kernel_launches_timed": launches,
-                         "kernels": "k_fused_pencil (gather..physics..shell E-vector, interior nodes straight to y) + k_assemble (deterministic per-node sum of the shared nodes): the two launches of one CeedOperatorApply, timed together with hipEvents on their stream",
+                         "launches_per_apply": li["segments"] + li["assemble_launches"],
+                         "kernels": ("k_fused_pencil (gather..physics..shell E-vector, interior nodes straight to y) + k_assemble (deterministic per-node sum of the shared nodes): "
+                                     + ("the two launches of one CeedOperatorApply, timed together with hipEvents on their stream" if li["segments"] <= 1 else
+                                        "one CeedOperatorApply = %d segments of consecutive elements, each a fused launch followed by the k_assemble of the rows it completes, alternating between %d streams so that the rows of a segment are summed beside the next fused kernel; kernel_avg_us is the hipEvent time of the WHOLE apply on the operator's stream (fork to join), not a sum of per-kernel durations, which overlap (profiles/README.md)" % (li["segments"], li["streams"]))),
                          "peak_measured_copy_GBs": 6290.0},
         }
         if not args.no_cpu_baseline and world == 1 and args.workload == "cylinder":

@@ -63,7 +63,7 @@ class CeedLib:
         "CeedOperatorLinearAssembleDiagonal", "CeedOperatorDestroy",
         "CeedXSetErrorReturn", "CeedXLastError", "CeedXSetStream", "CeedXSynchronize",
         "CeedXOperatorGetKernelName", "CeedXOperatorSetDirichletMask",
-        "CeedXOperatorSetTiming", "CeedXOperatorGetTiming", "CeedXOperatorSetDirichletMaskMode", "CeedXOperatorGetGatedStats",
+        "CeedXOperatorSetTiming", "CeedXOperatorGetTiming", "CeedXOperatorSetDirichletMaskMode", "CeedXOperatorGetGatedStats", "CeedXOperatorGetLaunchInfo",
         "CeedXCommGetUniqueId", "CeedXCommInit", "CeedXCommDestroy", "CeedXHaloCreate", "CeedXHaloStart", "CeedXHaloFinish", "CeedXHaloDestroy",
         "CeedXOperatorSetFineScale", "CeedXOperatorSetOverlapSplit", "CeedXOperatorApplyPhase",
         "CeedXVectorPointwiseMult", "CeedXVectorAXPBY", "CeedXVectorDot", "CeedXVectorChebyshevUpdate",
@@ -511,6 +511,12 @@ class Operator:
         ms, n = C.c_double(), C.c_int64()
         self.L.chk(self.L.lib.CeedXOperatorGetTiming(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def launch_info(self) -> dict:
+        """CeedXOperatorGetLaunchInfo: how the last apply was launched (segments of the pipelined restriction transpose)."""
+        out = (C.c_int * 4)()
+        self.L.chk(self.L.lib.CeedXOperatorGetLaunchInfo(self.h, out))
+        return dict(segments=out[0], streams=out[1], assemble_launches=out[2], last_segment_elements=out[3])
 
     def gated_stats(self) -> dict:
         """CeedXOperatorGetGatedStats: how much of the restriction transpose ran beside the fused kernel."""

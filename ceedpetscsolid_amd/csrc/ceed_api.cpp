@@ -92,6 +92,13 @@ struct Ceed_private {
   int gated_spins = 1 << 19;    // the gated kernel's bounded wait for one bucket, in ~2 us polls (CEED_MI355X_ASM_SPINS)
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int pipe_segments = 0;        // CEED_MI355X_ASSEMBLE=pipelined: segments per apply (CEED_MI355X_PIPE_SEGMENTS, default 4)
+  int pipe_blocks = 0;          // workgroups of the k_assemble launches that run beside a fused kernel (0: one per 256 rows)
+  int pipe_chains = 0;          // CEED_MI355X_PIPE_CHAINS=1: segments alternate between two streams (fused kernel + its rows per stream)
+  int pipe_last_rounds = 4;     // rounds of the persistent waves in the LAST segment (CEED_MI355X_PIPE_LAST; 0: equal segments)
+  int pipe_min_total_rounds = 20;   // rounds a whole apply must have to be pipelined (CEED_MI355X_PIPE_MIN_TOTAL)
+  int pipe_min_rounds = 4;      // rounds of the persistent waves a segment must have (CEED_MI355X_PIPE_MIN_ROUNDS; 0: tests on small meshes)
+  hipEvent_t ev_seg[16] = {nullptr};
   // RCCL communicator of the halo exchange (CeedXCommInit) and the stream its sends / receives run on
   void *comm = nullptr;
   int comm_rank = 0, comm_size = 1;
@@ -161,6 +168,22 @@ struct GatedMap {
   }
 };
 
+// The transpose map re-ordered for the PIPELINED assembly: the apply is cut into segments of consecutive elements, one
+// launch of the fused kernel each; a row (node) belongs to the segment of its LAST contributor, rows are sorted by segment,
+// and the rows of segment k are summed by their own k_assemble launch beside the fused kernel of segment k + 1.
+struct PipeMap {
+  bool built = false;
+  int nseg = 0, req_seg = 0, E = 0, waves = 0, nrows = 0;
+  const void *base = nullptr;              // the CsrMap it was derived from
+  std::vector<int> elem_bound, row_bound;  // nseg + 1 each
+  std::vector<uint32_t> h_node_off;        // re-ordered (for the per-operator Dirichlet flags)
+  uint32_t *d_rowptr = nullptr, *d_cols = nullptr, *d_node_off = nullptr;
+  void release() {
+    for (uint32_t *p : {d_rowptr, d_cols, d_node_off}) if (p) (void)hipFree(p);
+    d_rowptr = d_cols = d_node_off = nullptr; built = false;
+  }
+};
+
 struct CeedElemRestriction_private {
   Ceed ceed = nullptr;
   int refcount = 1;
@@ -174,6 +197,7 @@ struct CeedElemRestriction_private {
   CsrMap csr;   // default map (nodes in ascending offset order)
   CsrMap csr_shell;        // the same without the element-interior nodes (FusedGradArgs::direct)
   GatedMap gated;          // the map of the fused residual / Jacobian apply, re-ordered for the gated assembly
+  PipeMap pipe;            // ... re-ordered for the pipelined assembly
   // pair merge (FusedGradArgs::pairs): built once per restriction for groups of two elements
   int pair_state = 0;      // 0 not built, 1 built, -1 not applicable
   uint16_t *d_pairs = nullptr;
@@ -226,6 +250,7 @@ struct CeedOperator_private {
   unsigned char *d_node_flags_ovl = nullptr;  // per node of the operator's own (priority-first) map
   unsigned char *d_node_flags_shell = nullptr;  // per node of the restriction's shell map (direct-store mode)
   unsigned char *d_node_flags_gated = nullptr;  // per row of the restriction's gated map
+  unsigned char *d_node_flags_pipe = nullptr;   // per row of the restriction's pipelined map
   uint32_t *d_off_paired = nullptr;             // offsets with the Dirichlet flags AND the pair-merge bits (whole applies of the pencil kernel)
   std::vector<unsigned char> h_mask;      // copy of the output mask (node flags are derived lazily)
   int mask_mode = 0;
@@ -241,6 +266,7 @@ struct CeedOperator_private {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   double ms_accum = 0.;
   int64_t launches = 0;
+  int launch_info[4] = {0, 0, 0, 0};   // CeedXOperatorGetLaunchInfo
 };
 
 // sentinels
@@ -295,6 +321,20 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   const char *ga = getenv("CEED_MI355X_ASSEMBLE");
   c->gated_assembly = c->fused_variant == 1 && !c->atomic_scatter && ga && (!strcmp(ga, "gated") || !strcmp(ga, "folded"));
   c->folded_assembly = c->gated_assembly && !strcmp(ga, "folded");
+  // DEFAULT form of the restriction transpose on large launches: pipelined (CEED_MI355X_ASSEMBLE=serial switches it off)
+  if (c->fused_variant == 1 && !c->atomic_scatter && !c->gated_assembly && !(ga && !strcmp(ga, "serial"))) {
+    const char *ps = getenv("CEED_MI355X_PIPE_SEGMENTS"), *pb = getenv("CEED_MI355X_PIPE_BLOCKS");
+    c->pipe_segments = ps && atoi(ps) >= 2 ? std::min(atoi(ps), 16) : -1;     // -1: chosen per launch (build_pipe)
+    c->pipe_blocks = pb ? atoi(pb) : 0;
+    const char *pc = getenv("CEED_MI355X_PIPE_CHAINS");
+    c->pipe_chains = pc ? atoi(pc) : 1;
+    const char *pl = getenv("CEED_MI355X_PIPE_LAST");
+    if (pl) c->pipe_last_rounds = std::max(0, atoi(pl));
+    const char *pt = getenv("CEED_MI355X_PIPE_MIN_TOTAL");
+    if (pt) c->pipe_min_total_rounds = std::max(0, atoi(pt));
+    const char *pr = getenv("CEED_MI355X_PIPE_MIN_ROUNDS");
+    if (pr) c->pipe_min_rounds = std::max(0, atoi(pr));
+  }
   const char *gw = getenv("CEED_MI355X_ASM_WAVES");
   if (gw && atoi(gw) > 0) c->gated_waves = atoi(gw);
   const char *gs = getenv("CEED_MI355X_ASM_SPINS");
@@ -305,7 +345,7 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
 static void ceed_ref(Ceed c) { c->refcount++; }
 static int (*g_rccl_destroy)(void *) = nullptr;   // set when RCCL is bound (CeedXCommInit)
 static void ceed_free_parked(Ceed c) { for (double *p : c->evec_parked) (void)hipFree(p); c->evec_parked.clear(); }
-static void ceed_unref(Ceed c) { if (--c->refcount == 0) { if (c->capture_stream) (void)hipStreamDestroy(c->capture_stream); if (c->evec) (void)hipFree(c->evec); ceed_free_parked(c); if (c->queue) (void)hipFree(c->queue); if (c->side_stream) (void)hipStreamDestroy(c->side_stream); if (c->comm && g_rccl_destroy) g_rccl_destroy(c->comm); if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream); if (c->ev_fork) (void)hipEventDestroy(c->ev_fork); if (c->ev_join) (void)hipEventDestroy(c->ev_join); if (c->d_scalar) (void)hipFree(c->d_scalar); if (c->h_scalar) (void)hipHostFree(c->h_scalar); delete c; } }
+static void ceed_unref(Ceed c) { if (--c->refcount == 0) { if (c->capture_stream) (void)hipStreamDestroy(c->capture_stream); if (c->evec) (void)hipFree(c->evec); ceed_free_parked(c); if (c->queue) (void)hipFree(c->queue); if (c->side_stream) (void)hipStreamDestroy(c->side_stream); if (c->comm && g_rccl_destroy) g_rccl_destroy(c->comm); if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream); if (c->ev_fork) (void)hipEventDestroy(c->ev_fork); if (c->ev_join) (void)hipEventDestroy(c->ev_join); for (hipEvent_t e : c->ev_seg) if (e) (void)hipEventDestroy(e); if (c->d_scalar) (void)hipFree(c->d_scalar); if (c->h_scalar) (void)hipHostFree(c->h_scalar); delete c; } }
 extern "C" int CeedDestroy(Ceed *ceed) {
   if (!ceed || !*ceed) return 0;
   ceed_unref(*ceed);
@@ -590,6 +630,7 @@ extern "C" int CeedElemRestrictionDestroy(CeedElemRestriction *rstr) {
   r->csr.release();
   r->csr_shell.release();
   r->gated.release();
+  r->pipe.release();
   if (r->d_pairs) (void)hipFree(r->d_pairs);
   ceed_unref(r->ceed);
   delete r;
@@ -811,6 +852,8 @@ static void op_free_flags(CeedOperator o) {
   if (o->d_node_flags_ovl) (void)hipFree(o->d_node_flags_ovl);
   if (o->d_node_flags_shell) (void)hipFree(o->d_node_flags_shell);
   if (o->d_node_flags_gated) (void)hipFree(o->d_node_flags_gated);
+  if (o->d_node_flags_pipe) (void)hipFree(o->d_node_flags_pipe);
+  o->d_node_flags_pipe = nullptr;
   if (o->d_off_paired) (void)hipFree(o->d_off_paired);
   o->d_off_paired = nullptr;
   o->d_node_flags = o->d_node_flags_ovl = o->d_node_flags_shell = o->d_node_flags_gated = nullptr;
@@ -1028,6 +1071,94 @@ static int build_gated(CeedElemRestriction r, const CsrMap &M, int E, int skipP,
   const size_t nctrl = (size_t)GatedCtrl::size(G.nb, G.nitems);
   HIPCHK(hipMalloc((void **)&G.d_ctrl, sizeof(unsigned) * nctrl));
   HIPCHK(hipMemset(G.d_ctrl, 0, sizeof(unsigned) * nctrl));
+  G.built = true;
+  return 0;
+}
+// Segments of the pipelined assembly: element ranges whose group counts are whole rounds of the fused kernel's persistent
+// waves (`waves` per launch) where the mesh is large enough for that -- a launch then ends with every wave finishing its
+// last group at about the same time -- and the rows of the map sorted by the segment of their last contributor.
+static int build_pipe(CeedElemRestriction r, const CsrMap &M, int E, int per_elem, int req_seg, int waves, PipeMap &G) {
+  if (G.built && G.E == E && G.req_seg == req_seg && G.waves == waves && G.base == (const void *)&M) return 0;
+  if (getenv("CEED_MI355X_PIPE_DEBUG")) fprintf(stderr, "build_pipe: %d elements, E %d, %d segments asked, %d waves\n", r->nelem, E, req_seg, waves);
+  if (r->ceed->capturing)
+    return ceed_error("first apply of an operator during graph capture: its restriction's transpose map is built on the host; "
+                      "apply the operator once before recording");
+  G.release();
+  G.E = E; G.req_seg = req_seg; G.waves = waves; G.base = (const void *)&M;
+  const int ngroups = (r->nelem + E - 1) / E;
+  // at least `min_rounds` rounds per segment, else fewer segments (down to one: the caller then takes the serial path)
+  const int min_rounds = r->ceed->pipe_min_rounds;
+  // Below ~20 rounds of the persistent waves the fixed cost of the form (fork and join of the second stream, the summing
+  // kernels competing with the fused kernel for memory: ~40 us at p = 4) exceeds what is hidden: measured -3 % at 24 rounds
+  // (99 000 hexes, p = 4), +7 % at 11 rounds (44 928 hexes) -- such launches keep the serial form.
+  if (min_rounds > 0 && ngroups < r->ceed->pipe_min_total_rounds * std::max(waves, 1)) req_seg = 1;
+  // Segments asked for = 0: one per ~90 MB of E-vector (3 for config 4's 233 MB, 5 for twice that mesh, 15 for the whole of
+  // config 5) -- a segment boundary costs ~10 us, and the smaller a segment the more of its E-vector is still in the 256 MB
+  // last-level cache when its rows are summed (config 5, 1.4 GB of E-vector: 4.27 ms serial, 4.00 with 3 segments, 3.57
+  // with 8, 3.42 with 12-16; config 4: 3 segments best, 4 already slower).
+  else if (req_seg == 0) req_seg = std::max(2, std::min(16, (int)((double)r->nelem * per_elem * 24. / 90e6 + 0.5)));
+  int nseg = min_rounds > 0 ? std::max(1, std::min(req_seg, ngroups / (min_rounds * std::max(waves, 1)))) : std::min(req_seg, std::max(1, ngroups));
+  // Boundaries are laid out FROM THE END in whole rounds of the waves: the last segment (whose rows are summed with nothing
+  // to hide behind) is `last_rounds` rounds, the others share the rest equally in whole rounds, and the odd remainder of the
+  // mesh lands in the FIRST segment, where the next fused kernel fills the chip behind its ragged last round.
+  G.elem_bound.assign(1, 0);
+  const int last_rounds = r->ceed->pipe_last_rounds;
+  const long total_rounds = ngroups / std::max(waves, 1);
+  std::vector<long> gb;        // group boundaries, descending
+  if (min_rounds > 0 && last_rounds > 0 && nseg >= 2 && total_rounds >= last_rounds + (long)(nseg - 1) * min_rounds) {
+    long g = (long)ngroups - (long)last_rounds * waves;
+    gb.push_back(g);
+    const long per = (total_rounds - last_rounds) / (nseg - 1);       // rounds of the middle segments
+    for (int k = nseg - 2; k >= 1; k--) { g -= per * waves; gb.push_back(g); }
+  } else {
+    for (int k = nseg - 1; k >= 1; k--) {
+      long g = (long)ngroups * k / nseg;
+      const long up = (long)ngroups - (((long)ngroups - g) / waves) * waves;           // whole rounds behind it, if that moves it sensibly
+      gb.push_back(min_rounds > 0 && up > 0 && up < ngroups ? up : g);
+    }
+  }
+  for (auto it = gb.rbegin(); it != gb.rend(); ++it) {
+    const int e = (int)std::min<long>((long)r->nelem, *it * E);
+    if (e > G.elem_bound.back() && e < r->nelem) G.elem_bound.push_back(e);
+  }
+  G.elem_bound.push_back(r->nelem);
+  nseg = (int)G.elem_bound.size() - 1;
+  G.nseg = nseg;
+  const int nn = M.nnodes;
+  std::vector<uint32_t> rowptr((size_t)nn + 1), cols;
+  HIPCHK(hipMemcpy(rowptr.data(), M.d_rowptr, sizeof(uint32_t) * ((size_t)nn + 1), hipMemcpyDeviceToHost));
+  cols.resize(rowptr[nn] ? rowptr[nn] : 1);
+  HIPCHK(hipMemcpy(cols.data(), M.d_cols, sizeof(uint32_t) * rowptr[nn], hipMemcpyDeviceToHost));
+  std::vector<int> seg((size_t)nn);
+  std::vector<uint32_t> cnt((size_t)nseg + 1, 0u);
+  for (int i = 0; i < nn; i++) {
+    const int elast = (int)(cols[rowptr[i + 1] - 1] / (uint32_t)per_elem);      // contributors are in element order
+    const int k = (int)(std::upper_bound(G.elem_bound.begin(), G.elem_bound.end(), elast) - G.elem_bound.begin()) - 1;
+    seg[i] = k; cnt[(size_t)k + 1]++;
+  }
+  for (int k = 0; k < nseg; k++) cnt[k + 1] += cnt[k];
+  G.row_bound.assign(cnt.begin(), cnt.end());
+  std::vector<uint32_t> cursor(cnt.begin(), cnt.end() - 1), order((size_t)nn);
+  for (int i = 0; i < nn; i++) order[cursor[seg[i]]++] = (uint32_t)i;   // stable: ascending node offset within a segment
+  std::vector<uint32_t> rp2((size_t)nn + 1, 0u), cols2(cols.size()), no2((size_t)(nn ? nn : 1));
+  G.h_node_off.resize((size_t)nn);
+  for (int j = 0; j < nn; j++) {
+    const uint32_t i = order[j], len = rowptr[i + 1] - rowptr[i];
+    for (uint32_t k = 0; k < len; k++) cols2[rp2[j] + k] = cols[rowptr[i] + k];
+    rp2[j + 1] = rp2[j] + len;
+    no2[j] = G.h_node_off[j] = M.h_node_off[i];
+  }
+  G.nrows = nn;
+  if (getenv("CEED_MI355X_PIPE_DEBUG"))
+    for (int k = 0; k < nseg; k++)
+      fprintf(stderr, "  segment %d: elements %d..%d (%.2f rounds), rows %d..%d\n", k, G.elem_bound[k], G.elem_bound[k + 1],
+              (double)(G.elem_bound[k + 1] - G.elem_bound[k]) / E / waves, G.row_bound[k], G.row_bound[k + 1]);
+  auto up = [](uint32_t **dst, const std::vector<uint32_t> &v) -> int {
+    HIPCHK(hipMalloc((void **)dst, sizeof(uint32_t) * (v.size() ? v.size() : 1)));
+    if (!v.empty()) HIPCHK(hipMemcpy(*dst, v.data(), sizeof(uint32_t) * v.size(), hipMemcpyHostToDevice));
+    return 0;
+  };
+  CHK(up(&G.d_rowptr, rp2)); CHK(up(&G.d_cols, cols2)); CHK(up(&G.d_node_off, no2));
   G.built = true;
   return 0;
 }
@@ -1397,6 +1528,96 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
       if (qd & 1) { static unsigned *dummy = nullptr; if (!dummy) { HIPCHK(hipMalloc((void **)&dummy, 4096)); HIPCHK(hipMemset(dummy, 0, 4096)); } a.done = dummy; a.nb = 1; a.bucket_shift = 30; }
       if (qd & 2) CHK(dev_zero(c, (double *)c->queue, 8 * QUEUE_STRIDE / 2));
     }
+    // pipelined assembly: whole applies in overwrite mode through the pencil kernel, large enough for two segments
+    PipeMap *PM = nullptr;
+    if (c->pipe_segments != 0 && !gated && use_evec && !add && !split && a.variant == 1 && !a.pairs && !a.queue) {
+      int waves = 0;            // persistent waves of a full launch of THIS kernel (LDS-limited from Q = 6 on)
+      {
+        FusedGradArgs aq = a;
+        aq.query_waves = &waves;
+        const char *nm = "";
+        HIPCHK(launch_fused_grad(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, aq, s, &nm));
+        if (waves <= 0) return ceed_error("pipelined assembly: no persistent-wave count for P=%d Q=%d", ai.basis->P1d, ai.basis->Q1d);
+      }
+      const int per_elem = direct ? element_shell_size(ai.basis->P1d) : r->elemsize;
+      if (!r->pipe.built && c->capturing) { /* cold map while recording: the serial path (its map exists) */ }
+      else {
+        CHK(build_pipe(r, *M, pencil_group_elems(ai.basis->Q1d), per_elem, std::max(c->pipe_segments, 0), waves, r->pipe));
+        if (r->pipe.nseg >= 2) PM = &r->pipe;
+      }
+      if (PM && !op->d_node_flags_pipe && !op->h_mask.empty()) {
+        std::vector<unsigned char> fl((size_t)PM->nrows, 0);
+        for (int i = 0; i < PM->nrows; i++)
+          for (int cc = 0; cc < r->ncomp && cc < 3; cc++)
+            if (op->h_mask[(size_t)PM->h_node_off[i] + (size_t)cc * r->compstride]) fl[i] |= (unsigned char)(1u << cc);
+        HIPCHK(hipMalloc((void **)&op->d_node_flags_pipe, fl.size() ? fl.size() : 1));
+        HIPCHK(hipMemcpy(op->d_node_flags_pipe, fl.data(), fl.size(), hipMemcpyHostToDevice));
+      }
+    }
+    if (PM) {
+      // segment k: fused kernel on the Ceed's stream, then its rows on the side stream beside the fused kernel of segment
+      // k + 1; the last segment's rows on the Ceed's stream again, which then waits for the side stream.  Every row is summed
+      // in contributor order by one thread, whatever the segment: bitwise the serial result.
+      if (!c->side_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+      }
+      const unsigned char *fl = (op->mask_mode & 2) ? op->d_node_flags_pipe : nullptr;
+      const int nseg = PM->nseg;
+      op->launch_info[0] = nseg; op->launch_info[1] = c->pipe_chains ? 2 : 1; op->launch_info[2] = nseg;
+      op->launch_info[3] = PM->elem_bound[nseg] - PM->elem_bound[nseg - 1];
+      if (c->pipe_chains) {
+        // two chains: segment k's fused kernel AND its rows on stream k % 2 -- the fused kernel of segment k + 1 sits in the
+        // other queue and fills the chip as the waves of segment k retire (no kernel boundary between fused kernels)
+        HIPCHK(hipEventRecord(c->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        for (int k = 0; k < nseg; k++) {
+          hipStream_t sk = (k & 1) ? c->side_stream : s;
+          FusedGradArgs ak = a;
+          ak.elem_begin = PM->elem_bound[k]; ak.nelem = PM->elem_bound[k + 1] - PM->elem_bound[k];
+          hipError_t e = launch_fused_grad(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, ak, sk, kname);
+          if (e == hipErrorInvalidValue && !**kname)
+            return ceed_error("no fused kernel instantiated for P=%d Q=%d QFunction %s", ai.basis->P1d, ai.basis->Q1d, qf->name.c_str());
+          HIPCHK(e);
+          // the rows of segment k have contributors in EARLIER segments too (the nodes on the cut between two segments):
+          // segment k - 1's fused kernel runs on the other stream, the ones before it precede one of the two in stream order
+          if (!c->ev_seg[k]) HIPCHK(hipEventCreateWithFlags(&c->ev_seg[k], hipEventDisableTiming));
+          HIPCHK(hipEventRecord(c->ev_seg[k], sk));
+          if (k >= 1) HIPCHK(hipStreamWaitEvent(sk, c->ev_seg[k - 1], 0));
+          const int r0 = PM->row_bound[k], nr = PM->row_bound[k + 1] - r0;
+          HIPCHK(launch_assemble(PM->d_rowptr + r0, PM->d_cols, PM->d_node_off + r0, fl ? fl + r0 : nullptr, a.evec, py, nr, r->elemsize, 0,
+                                 sk, nullptr, k + 1 < nseg ? c->pipe_blocks : 0));
+        }
+        HIPCHK(hipEventRecord(c->ev_join, c->side_stream));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+        op->launches++;
+        return 0;
+      }
+      for (int k = 0; k < nseg; k++) {
+        FusedGradArgs ak = a;
+        ak.elem_begin = PM->elem_bound[k]; ak.nelem = PM->elem_bound[k + 1] - PM->elem_bound[k];
+        hipError_t e = launch_fused_grad(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, ak, s, kname);
+        if (e == hipErrorInvalidValue && !**kname)
+          return ceed_error("no fused kernel instantiated for P=%d Q=%d QFunction %s", ai.basis->P1d, ai.basis->Q1d, qf->name.c_str());
+        HIPCHK(e);
+        const int r0 = PM->row_bound[k], nr = PM->row_bound[k + 1] - r0;
+        if (k + 1 < nseg) {
+          if (!c->ev_seg[k]) HIPCHK(hipEventCreateWithFlags(&c->ev_seg[k], hipEventDisableTiming));
+          HIPCHK(hipEventRecord(c->ev_seg[k], s));
+          HIPCHK(hipStreamWaitEvent(c->side_stream, c->ev_seg[k], 0));
+          HIPCHK(launch_assemble(PM->d_rowptr + r0, PM->d_cols, PM->d_node_off + r0, fl ? fl + r0 : nullptr, a.evec, py, nr, r->elemsize, 0,
+                                 c->side_stream, nullptr, c->pipe_blocks));
+        } else {
+          HIPCHK(hipEventRecord(c->ev_join, c->side_stream));
+          HIPCHK(launch_assemble(PM->d_rowptr + r0, PM->d_cols, PM->d_node_off + r0, fl ? fl + r0 : nullptr, a.evec, py, nr, r->elemsize, 0, s, nullptr, 0));
+          HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+        }
+      }
+      op->launches++;
+      return 0;
+    }
+    op->launch_info[0] = 1; op->launch_info[1] = 1; op->launch_info[2] = use_evec ? 1 : 0; op->launch_info[3] = a.nelem;
     const bool folded = gated && c->folded_assembly;
     const bool side = ((gated && !folded) || c->asm_overlap) && use_evec;
     if (side) {   // fork: the assembly runs on a second stream beside the fused kernel (also while a graph is recorded)
@@ -1715,6 +1936,10 @@ extern "C" int CeedXOperatorApplyPhase(CeedOperator op, CeedVector in, CeedVecto
   return 0;
 }
 
+extern "C" int CeedXOperatorGetLaunchInfo(CeedOperator op, int out[4]) {
+  for (int i = 0; i < 4; i++) out[i] = op->launch_info[i];
+  return 0;
+}
 // Gated assembly of the operator's active restriction: out[0] = items of the transpose map, out[1] = rows in them,
 // out[2] = cut rows, out[3] = items the tail kernel had to sum (the gated kernel had not), out[4] = applies -- [3], [4]
 // since the last call.  Diagnostic only (placement and co-residency decide [3], never the result).

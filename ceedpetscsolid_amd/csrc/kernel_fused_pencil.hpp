@@ -972,6 +972,7 @@ hipError_t launch_fused_pencil_t(const BasisTables &t, const FusedGradArgs &a, h
   static int wpc = 0;  // tuning hook: CEED_MI355X_PENCIL_WAVES=<persistent waves per CU>
   if (!wpc) { const char *e = getenv("CEED_MI355X_PENCIL_WAVES"); wpc = e && atoi(e) > 0 ? atoi(e) : -1; }
   int grid = ncu * (wpc > 0 ? wpc : pencil_waves_per_cu<P, Q>());
+  if (a.query_waves) { *a.query_waves = CPS_WG4 ? (grid / 32) * 32 : grid; return hipSuccess; }
   if (grid > ngroups) grid = ngroups;
   if (CPS_WG4) grid = (grid / 32) * 8;   // workgroups of four waves, a multiple of 8
   if constexpr (Q <= 5) {

@@ -103,6 +103,8 @@ struct FusedGradArgs {
                                // verified on the host) are stored straight into y and skip the E-vector round trip; the
                                // E-vector then is [elem][shell node][3] and the transpose map handed to launch_assemble()
                                // holds the shell nodes only, its columns being positions e * element_shell_size(P) + rank
+  int *query_waves;           // host side only (last member: the kernels' view of the struct is unchanged): if set, the
+                               // launcher stores the number of persistent waves a full launch has and launches nothing
 };
 // element-interior test shared by the kernel and the host-side map builder
 #ifdef __HIPCC__
@@ -244,7 +246,7 @@ constexpr int pencil_group_elems(int Q) { return Q <= 2 ? 8 : (Q <= 4 ? 4 : (Q =
 // order, of E[3 * cols[k] + c] (cols[k] = e * P3 + n).  `flags` (one byte per node, bit c = component c constrained) may be null.
 hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off,
                            const unsigned char *flags, const double *evec, double *y, int nnodes, int P3,
-                           int add, hipStream_t s, unsigned *queue_reset = nullptr);   // queue_reset: the pencil kernel's ticket counters, zeroed for its next launch
+                           int add, hipStream_t s, unsigned *queue_reset = nullptr, int max_blocks = 0);   // queue_reset: the pencil kernel's ticket counters, zeroed for its next launch; max_blocks: cap on the grid (pipelined assembly)
 
 // Coordinate-driven set-up operators (kernels_coord.hip): opSetupForce and opTrue of setuplibceed.c:555-623.
 struct CoordOpArgs {

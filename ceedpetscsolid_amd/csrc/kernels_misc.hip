@@ -670,10 +670,12 @@ hipError_t launch_multiplicity(const uint32_t *off, int nelem, int elemsize, int
 }
 hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off,
                            const unsigned char *flags, const double *evec, double *y, int nnodes, int P3,
-                           int add, hipStream_t s, unsigned *queue_reset) {
+                           int add, hipStream_t s, unsigned *queue_reset, int max_blocks) {
   if (nnodes <= 0 && !queue_reset) return hipSuccess;
   (void)P3;
-  hipLaunchKernelGGL(k_assemble, dim3((unsigned)((std::max(nnodes, 1) + 255) / 256)), dim3(256), 0, s, rowptr, cols, node_off, flags, evec, y, nnodes, add, queue_reset);
+  unsigned grid = (unsigned)((std::max(nnodes, 1) + 255) / 256);
+  if (max_blocks > 0 && grid > (unsigned)max_blocks) grid = (unsigned)max_blocks;     // (grid-stride loop over the rows)
+  hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(256), 0, s, rowptr, cols, node_off, flags, evec, y, nnodes, add, queue_reset);
   return hipGetLastError();
 }
 hipError_t launch_dot(const double *x, const double *y, const double *w, size_t n, double *result_dev, hipStream_t s, double *out) {

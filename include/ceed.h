@@ -384,5 +384,10 @@ CEED_EXTERN int CeedXHaloDestroy(CeedXHalo *halo);
 /* transpose map, out[1] rows in them, out[2] cut rows, out[3] items summed by */
 /* the tail kernel since the last call, out[4] applies since the last call.    */
 CEED_EXTERN int CeedXOperatorGetGatedStats(CeedOperator op, long long out[5]);
+/* Diagnostic: how the last apply of a residual / Jacobian operator was        */
+/* launched.  out[0] segments (fused-kernel launches) of the apply, 1 = the    */
+/* serial form; out[1] streams they alternate between; out[2] k_assemble       */
+/* launches; out[3] elements of the last segment.                              */
+CEED_EXTERN int CeedXOperatorGetLaunchInfo(CeedOperator op, int out[4]);
 
 #endif /* CEED_MI355X_CEED_H */

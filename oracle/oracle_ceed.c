@@ -1169,6 +1169,7 @@ int CeedXVectorAXPBYScalars(CeedVector y, CeedVector scalars, CeedInt ia, double
 }
 int CeedXOperatorSetTiming(CeedOperator op, int enable) { (void)op; (void)enable; return 0; }
 int CeedXOperatorGetTiming(CeedOperator op, double *ms, int64_t *launches) { (void)op; *ms = 0; *launches = 0; return 0; }
+int CeedXOperatorGetLaunchInfo(CeedOperator op, int out[4]) { (void)op; out[0] = 1; out[1] = 1; out[2] = 0; out[3] = 0; return 0; }
 int CeedXOperatorGetGatedStats(CeedOperator op, long long out[5]) { (void)op; for (int i = 0; i < 5; i++) out[i] = 0; return 0; }
 /* Halo exchange: the oracle is a single-process CPU checker; the multi-rank tests exchange through torch.distributed
    (ceedpetscsolid_amd/halo.py, gloo).  Only the neighbour-free halo exists here. */

@@ -470,17 +470,23 @@ def test_apply_is_bitwise_reproducible(gpu):
     (lambda: distorted_box(9, 7, 5), 1, "linElas"),             # Q = 2: eight elements per group, ragged last group
     (lambda: distorted_box(7, 6, 6), 6, "hyperFS"),             # Q = 7: one element per group
 ], ids=["cyl1536 p4", "cyl8000 p4", "box p2", "box p1", "box p6"])
-@pytest.mark.parametrize("mode", ["gated", "folded", "dynamic"])
+@pytest.mark.parametrize("mode", ["gated", "folded", "dynamic", "pipelined"])
 def test_gated_assembly_equals_serial_assembly_bitwise(product_lib, mk, degree, problem, mode):
     """The opt-in forms of the restriction transpose -- "gated": k_assemble_gated BESIDE the fused kernel + k_assemble_tail;
-    "folded": summed by the pencil kernel's own waves + k_assemble_tail (CEED_MI355X_ASSEMBLE) -- and the dynamic per-XCD group
+    "folded": summed by the pencil kernel's own waves + k_assemble_tail; "pipelined": the apply cut into segments, the rows of
+    segment k summed by a k_assemble launch beside the fused kernel of segment k + 1 (CEED_MI355X_ASSEMBLE) -- and the dynamic per-XCD group
     schedule (CEED_MI355X_SCHED=dynamic) against the default (k_assemble after the statically scheduled fused kernel): same
     E-vector values, same element order, so the results are BITWISE equal.  The inputs alternate between applies, so an
     E-vector entry read before its producer's store had reached the XCD's L2 (or from a stale L1 line) would show as the
     previous apply's value."""
     mesh = mk()
-    gated = _ceed_with_env(product_lib, "CEED_MI355X_SCHED", "dynamic") if mode == "dynamic" else _ceed_with_env(product_lib, "CEED_MI355X_ASSEMBLE", mode)
-    serial = cd.Ceed(product_lib, "/gpu/hip/mi355x")
+    if mode == "pipelined":      # three segments whatever the mesh size (the default asks for four rounds of the waves per segment)
+        os.environ["CEED_MI355X_PIPE_MIN_ROUNDS"], os.environ["CEED_MI355X_PIPE_SEGMENTS"] = "0", "3"
+    try:
+        gated = _ceed_with_env(product_lib, "CEED_MI355X_SCHED", "dynamic") if mode == "dynamic" else _ceed_with_env(product_lib, "CEED_MI355X_ASSEMBLE", mode)
+    finally:
+        os.environ.pop("CEED_MI355X_PIPE_MIN_ROUNDS", None); os.environ.pop("CEED_MI355X_PIPE_SEGMENTS", None)
+    serial = _ceed_with_env(product_lib, "CEED_MI355X_ASSEMBLE", "serial")
     probs = [SolidProblem(c, mesh, degree, problem, nu=0.3, E=1.0, bc_sides=[sorted(mesh.side_sets)[0]], multigrid="none") for c in (gated, serial)]
     n = probs[0].lsize()
     rng = np.random.default_rng(11)
@@ -500,6 +506,23 @@ def test_gated_assembly_equals_serial_assembly_bitwise(product_lib, mk, degree, 
             outs.append(Y.to_numpy())
         assert np.array_equal(outs[0], outs[1]), f"apply {it}"
     assert probs[0].levels[probs[0].fine].opJacob.kernel_name == probs[1].levels[probs[1].fine].opJacob.kernel_name
+    info = [p.levels[p.fine].opJacob.launch_info() for p in probs]
+    assert info[1]["segments"] == 1
+    if mode == "pipelined":
+        assert info[0]["segments"] == 3 and info[0]["streams"] == 2 and info[0]["assemble_launches"] == 3
+        # recorded into a graph (fork to the second stream and join inside the capture) and replayed on new data
+        (X, Y), p = vecs[0], probs[0]
+        Yg = gated.vector(n)
+        g = gated.capture(lambda: p.apply_jacobian(p.fine, X, Yg))
+        for _ in range(3):
+            x = rng.uniform(-1, 1, n)
+            for (Xs, Ys), ps in zip(vecs, probs):
+                Xs.set_array(x); Xs.device_pointer()
+            probs[1].apply_jacobian(probs[1].fine, vecs[1][0], vecs[1][1])
+            Yg.set_value(-7.0)
+            g.launch()
+            assert np.array_equal(Yg.to_numpy(), vecs[1][1].to_numpy())
+        g.destroy()
 
 
 def test_recorded_graph_survives_growth_of_the_scratch(product_lib):
