@@ -18,6 +18,13 @@ def load(d):
 
 def mean(v): return sum(v) / len(v)
 
+# An apply of the pipelined form is several launches of each kernel (bench.py: config.assembly): counters are summed
+# over the launches and divided by the number of applies (= launches of the kernel / segments per apply).
+import re
+m = re.search(r"(\d+) segments", json.load(open(sys.argv[3]))["config"].get("assembly") or "")
+SEG = int(m.group(1)) if m else 1
+def per_apply(v): return sum(v) / (len(v) / SEG)
+
 fetch, write, bench = load(sys.argv[1]), load(sys.argv[2]), json.load(open(sys.argv[3]))
 def find(agg, key):
     return [k for k in agg if key in k]
@@ -31,14 +38,15 @@ tag = sys.argv[4] if len(sys.argv) > 4 else "r02"
 out = {"kernel": bench["config"]["kernel"], "elements_per_gpu": bench["config"]["elements_per_gpu"],
        "commit": sys.argv[5] if len(sys.argv) > 5 else os.environ.get("GRAFT_COMMIT", "unknown"),
        "assembly": bench["config"].get("assembly"), "schedule": bench["config"].get("schedule"),
+       "note": "rocprofv3 serialises the kernels while it collects counters: the bytes are those of the launches run one after the other",
        "fetch_calibration_factor": f_cal, "write_calibration_factor": w_cal, "per_kernel": {}}
 tot = 0.0
 for name in ("k_fused_pencil<5, 5, 6", "k_fused_grad<5, 5, 6>", "k_assemble(", "k_assemble_gated", "k_assemble_tail"):
     kf, kw = find(fetch, name), find(write, name)
     if not kf: continue
-    fb = mean(fetch[kf[0]]["FETCH_SIZE"]) * 1024.0 * (f_cal or 2.0)
-    wb = mean(write[kw[0]]["WRITE_SIZE"]) * 1024.0 * (w_cal or 1.0)
-    out["per_kernel"][name] = {"fetch_bytes": fb, "write_bytes": wb}
+    fb = per_apply(fetch[kf[0]]["FETCH_SIZE"]) * 1024.0 * (f_cal or 2.0)
+    wb = per_apply(write[kw[0]]["WRITE_SIZE"]) * 1024.0 * (w_cal or 1.0)
+    out["per_kernel"][name] = {"fetch_bytes": fb, "write_bytes": wb, "launches_per_apply": SEG}
     tot += fb + wb
 out["hbm_bytes_per_apply"] = tot
 out["algorithmic_bytes_per_apply"] = bench["roofline"]["algorithmic_bytes_per_launch"]

@@ -12,22 +12,41 @@ for pw in 150 0; do
   rm -rf /tmp/prof_stats_$pw
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats_$pw -- python3 $R/bench.py --steps 50 --warmup 5 --prewarm-ms $pw --no-cpu-baseline > $O/stats_run_$pw.log 2>&1 || { echo stats failed; tail -5 $O/stats_run_$pw.log; exit 1; }
 done
+rm -rf /tmp/prof_stats_serial
+CEED_MI355X_ASSEMBLE=serial timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats_serial -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/stats_run_serial.log 2>&1 || { echo serial stats failed; tail -5 $O/stats_run_serial.log; exit 1; }
+grep '^{"metric"' $O/stats_run_serial.log > $O/${T}_bench_serial_form.json
+cp $(find /tmp/prof_stats_serial -name "*kernel_stats.csv" | head -1) $O/${T}_kernel_stats_serial_form.csv
 cp $(find /tmp/prof_stats_150 -name "*kernel_stats.csv" | head -1) $O/${T}_kernel_stats.csv
 cp $(find /tmp/prof_stats_0 -name "*kernel_stats.csv" | head -1) $O/${T}_kernel_stats_no_prewarm.csv
 python3 - <<PY
 import csv, glob
+# one APPLY = the fused launches and the k_assemble launches between two joins: its time is the span from the first
+# kernel's start to the last kernel's end (the pipelined form overlaps its kernels: per-kernel durations do not add up)
 out = open("$O/${T}_dispatch_series.txt", "w")
 for pw in (0, 150):
     f = glob.glob(f"/tmp/prof_stats_{pw}/**/*kernel_trace.csv", recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if "k_fused_pencil<5, 5, 6" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "k_fused_pencil<5, 5, 6" in r["Kernel_Name"] or "k_assemble" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    t0 = int(rows[0]["Start_Timestamp"])
-    out.write(f"# k_fused_pencil<5,5,HyperFSdF,geo,eo> per dispatch, bench.py --steps 50 --warmup 5 --prewarm-ms {pw}: index, start (us after the first), duration (us)\n")
-    for i, r in enumerate(rows):
-        out.write(f"{i}\t{(int(r['Start_Timestamp']) - t0) / 1e3:.1f}\t{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.1f}\n")
-    last = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows[-50:]]
+    first = next(i for i, r in enumerate(rows) if "k_fused_pencil<5, 5, 6" in r["Kernel_Name"])
+    rows = rows[first:]
+    applies, cur, cur_end, seen_asm = [], [], 0, False
+    for r in rows:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if cur and "k_fused" in r["Kernel_Name"] and seen_asm and s >= cur_end:
+            applies.append(cur); cur, seen_asm, cur_end = [], False, 0
+        cur.append(r); cur_end = max(cur_end, e); seen_asm = seen_asm or "k_assemble" in r["Kernel_Name"]
+    if cur: applies.append(cur)
+    t0 = int(applies[0][0]["Start_Timestamp"])
+    out.write(f"# one line per CeedOperatorApply of bench.py --steps 50 --warmup 5 --prewarm-ms {pw}: index, start (us after the first), span first kernel start .. last kernel end (us), kernels in it, sum of the fused kernels' own durations (us)\n")
+    spans = []
+    for i, a in enumerate(applies):
+        s0 = min(int(r["Start_Timestamp"]) for r in a); e1 = max(int(r["End_Timestamp"]) for r in a)
+        fsum = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in a if "k_fused" in r["Kernel_Name"])
+        spans.append((e1 - s0) / 1e3)
+        out.write(f"{i}\t{(s0 - t0) / 1e3:.1f}\t{(e1 - s0) / 1e3:.1f}\t{len(a)}\t{fsum / 1e3:.1f}\n")
+    last = spans[-50:]
     m = sum(last) / len(last); sd = (sum((x - m) ** 2 for x in last) / len(last)) ** 0.5
-    out.write(f"# last 50 dispatches (the timed ones): mean {m:.1f} us, sigma {sd:.1f} us = {100 * sd / m:.1f} %\n\n")
+    out.write(f"# last 50 applies (the timed ones): mean span {m:.1f} us, sigma {sd:.1f} us = {100 * sd / m:.1f} %\n\n")
 out.close()
 PY
 tail -2 $O/${T}_dispatch_series.txt
