@@ -1573,7 +1573,7 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
         HIPCHK(hipEventRecord(c->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
         for (int k = 0; k < nseg; k++) {
-          hipStream_t sk = (k & 1) ? c->side_stream : s;
+          hipStream_t sk = (k & 1) ? c->side_stream : s;     // (the FIRST segment on the operator's own stream; putting the last one there instead, so that the join is never waited for, measured 6-9 % slower at even segment counts)
           FusedGradArgs ak = a;
           ak.elem_begin = PM->elem_bound[k]; ak.nelem = PM->elem_bound[k + 1] - PM->elem_bound[k];
           hipError_t e = launch_fused_grad(ai.basis->P1d, ai.basis->Q1d, qf->kind, op->tables, ak, sk, kname);
