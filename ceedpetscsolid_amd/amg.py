@@ -92,9 +92,9 @@ def rigid_body_prolongation(agg: np.ndarray, na: int, coords: np.ndarray, constr
 class AggregationAMG:
     """Two-level smoothed aggregation under an `AssembledLevel` (see the module docstring)."""
 
-    def __init__(self, asm, prolongator_damping: float = 0.66, verbose: bool = False):
+    def __init__(self, asm, prolongator_damping: float = 0.66, verbose: bool = False, max_coarse_dofs: int = 4096):
         self.asm, self.ceed = asm, asm.ceed
-        self.damping, self.verbose = prolongator_damping, verbose
+        self.damping, self.verbose, self.max_coarse_dofs = prolongator_damping, verbose, max_coarse_dofs
         self.P = self.Pt = self.T = self.Ac = None
         self.rc = self.xc = None
         self.nc = 0
@@ -134,6 +134,11 @@ class AggregationAMG:
         P = (P0 - (self.damping * 4.0 / 3.0 / lam) * (sp.diags(dinv) @ (A @ P0))).tocsr()
         P.sort_indices()
         nc = P.shape[1]
+        if nc > self.max_coarse_dofs:
+            # two levels only: the coarsest matrix is inverted densely every Newton step (n^3: 1.3 ms at 1 080 rows, ~0.1 s at
+            # 4 096); a mesh this large needs a third level (not built) -- the Chebyshev coarse solve takes any size
+            raise ValueError(f"the aggregation leaves {nc} coarse dofs (limit {self.max_coarse_dofs}: the coarsest level is inverted "
+                             f"densely); use coarse='assembled' for this mesh or raise max_coarse_dofs")
         Pt = P.T.tocsr()
         Pt.sort_indices()
         self.P = cd.Csr.rect(c, n, nc, P.indptr, P.indices, P.data)
