@@ -1,28 +1,33 @@
 """Aggregation multigrid under the assembled p = 1 level: the coarse solve of the p-multigrid V-cycle.
 
 The reference hands the assembled coarse Jacobian to PCGAMG and applies ONE cycle of it per outer iteration
-(KSPPREONLY + PCGAMG, elasticity.c:568-585).  This module builds the same kind of hierarchy, two levels deep:
+(KSPPREONLY + PCGAMG, elasticity.c:568-585).  This module builds the same kind of hierarchy:
 
-* aggregates of the node graph of the assembled matrix (a root and its neighbours, leftovers join the
-  neighbouring aggregate they touch most): ~40 nodes per aggregate on a hexahedral mesh;
-* tentative prolongation P0 from the six rigid-body modes of each aggregate (translations and rotations about
-  the aggregate's centroid, rows of constrained dofs zeroed, orthonormalised per aggregate by an SVD that also
-  drops dependent columns) -- PCGAMG's near-null space for elasticity;
+* aggregates of the node graph of a level's matrix (a root and its neighbours, leftovers join the neighbouring
+  aggregate they touch most): ~40 nodes per aggregate on a hexahedral mesh, ~25 aggregates per aggregate above;
+* tentative prolongation P0 from the near-null space B (level 0: the six rigid-body modes, translations and
+  rotations about the aggregate's centroid, rows of constrained dofs zeroed -- PCGAMG's near-null space for
+  elasticity): per aggregate B restricted to it is orthonormalised by an SVD that also drops dependent columns;
+  U spans the aggregate's columns of P0, S V^T is the aggregate's block of the next level's B;
 * smoothed prolongation P = (I - w D^-1 A) P0, computed ONCE from the first Jacobian of the solve and kept
-  (P defines the coarse space; the Galerkin matrix below uses the current Jacobian every Newton step, so the
+  (P defines the coarse space; the Galerkin matrices below use the current Jacobian every Newton step, so every
   coarse correction stays an exact projection.  Outer iteration counts with the frozen and with a refreshed P
   are equal on BASELINE config 3's mesh: DESIGN.md);
-* per Newton step on the device, through `CeedXCsr*` of include/ceed.h: T = A P and A_c = P^T T as fixed linear
-  combinations of values (`CeedXCsrCreateProduct` / `CeedXCsrUpdate`: the library builds the term lists once), then
-  the in-place inverse of the dense A_c (`CeedXCsrInvertDenseSPD`, ~10^3 rows);
-* per cycle: r_c = P^T r,  x_c = A_c^-1 r_c,  x += P x_c  -- three `CeedXCsrApply` launches between the level's own
-  Chebyshev pre- and post-smoothing (solver.py).
+* levels are added until one has at most ``max_coarse_dofs`` rows (default 1 500): that one is stored dense and
+  inverted.  BASELINE config 3 (7 198 coarse nodes) gets two levels, 21 594 -> 1 080;
+* per Newton step on the device, through `CeedXCsr*` of include/ceed.h: T = A P and A_next = P^T T per level as
+  fixed linear combinations of values (`CeedXCsrCreateProduct` / `CeedXCsrUpdate`: the library builds the term
+  lists once), the diagonal and a 10-step Lanczos bound for the smoother of every intermediate level (scalars
+  on the device), then the in-place inverse of the dense last level (`CeedXCsrInvertDenseSPD`);
+* per cycle and level: Chebyshev pre-smoothing, r_c = P^T r, the next level's cycle (or x_c = A_c^-1 r_c),
+  x += P x_c, Chebyshev post-smoothing.  Level 0's smoothing is the solver's own (solver.py).
 
 Everything the cycle launches is on the Ceed's stream and recordable into the V-cycle graph.  The host part
 (this file) is numpy / scipy on patterns and runs once per solve.
 """
 from __future__ import annotations
 
+import ctypes as C
 import time
 
 import numpy as np
@@ -58,123 +63,295 @@ def aggregate_nodes(indptr: np.ndarray, indices: np.ndarray) -> tuple[np.ndarray
     return out, na
 
 
-def rigid_body_prolongation(agg: np.ndarray, na: int, coords: np.ndarray, constrained: np.ndarray):
-    """Tentative prolongation (scipy CSR, 3 * nnodes rows): per aggregate the orthonormalised rigid-body modes."""
+def rigid_body_modes(coords: np.ndarray, constrained: np.ndarray) -> np.ndarray:
+    """Near-null space of the elasticity operator on the nodes: translations and rotations (about the origin; the
+    aggregates re-centre them), rows of constrained dofs zeroed.  Shape (3 * nnodes, 6)."""
+    n = coords.shape[0]
+    B = np.zeros((3 * n, 6))
+    B[0::3, 0] = 1.0; B[1::3, 1] = 1.0; B[2::3, 2] = 1.0
+    B[0::3, 4] = coords[:, 2]; B[0::3, 5] = -coords[:, 1]
+    B[1::3, 3] = -coords[:, 2]; B[1::3, 5] = coords[:, 0]
+    B[2::3, 3] = coords[:, 1]; B[2::3, 4] = -coords[:, 0]
+    B[constrained] = 0.0
+    return B
+
+
+def tentative_prolongation(agg: np.ndarray, na: int, dof_ptr: np.ndarray, B: np.ndarray):
+    """Per aggregate a (nodes with agg == a; ids >= na are left out): B restricted to the aggregate's dofs = U S V^T;
+    the columns of U with a singular value above 1e-8 of the largest are the aggregate's columns of P0, S V^T its rows
+    of the next level's near-null space.  ``dof_ptr[i] .. dof_ptr[i + 1]`` are the dofs of node i.
+    Returns P0 (scipy CSR), the next B, and the column offsets of the aggregates (the next level's dof_ptr)."""
     import scipy.sparse as sp
     order = np.argsort(agg, kind="stable")
     start = np.searchsorted(agg[order], np.arange(na + 1))
-    rows, cols, vals = [], [], []
+    rows, cols, vals, Bc, col_ptr = [], [], [], [], [0]
     nc = 0
     for a in range(na):
         nodes = order[start[a]:start[a + 1]]
-        if nodes.size == 0:
-            continue
-        d = coords[nodes] - coords[nodes].mean(axis=0)
-        B = np.zeros((3 * nodes.size, 6))
-        B[0::3, 0] = 1.0; B[1::3, 1] = 1.0; B[2::3, 2] = 1.0
-        B[0::3, 4] = d[:, 2]; B[0::3, 5] = -d[:, 1]
-        B[1::3, 3] = -d[:, 2]; B[1::3, 5] = d[:, 0]
-        B[2::3, 3] = d[:, 1]; B[2::3, 4] = -d[:, 0]
-        dofs = (3 * nodes[:, None] + np.arange(3)).reshape(-1)
-        B[constrained[dofs]] = 0.0
-        U, sv, _ = np.linalg.svd(B, full_matrices=False)
-        k = int((sv > 1e-8 * sv[0]).sum()) if sv[0] > 0.0 else 0
-        for j in range(k):
-            rows.append(dofs); cols.append(np.full(dofs.size, nc + j)); vals.append(U[:, j])
-        nc += k
+        dofs = np.concatenate([np.arange(dof_ptr[i], dof_ptr[i + 1]) for i in nodes]) if nodes.size else np.zeros(0, dtype=np.int64)
+        if dofs.size:
+            U, sv, Vt = np.linalg.svd(B[dofs], full_matrices=False)
+            k = int((sv > 1e-8 * sv[0]).sum()) if sv[0] > 0.0 else 0
+            for j in range(k):
+                rows.append(dofs); cols.append(np.full(dofs.size, nc + j)); vals.append(U[:, j])
+            if k:
+                Bc.append(sv[:k, None] * Vt[:k])
+            nc += k
+        col_ptr.append(nc)
     if nc == 0:
         raise ValueError("the aggregation left no coarse degree of freedom (is every dof constrained?)")
-    P0 = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(constrained.size, nc))
+    P0 = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(B.shape[0], nc))
     P0.eliminate_zeros()
-    return P0
+    return P0, np.concatenate(Bc, axis=0), np.asarray(col_ptr, dtype=np.int64)
+
+
+def rigid_body_prolongation(agg: np.ndarray, na: int, coords: np.ndarray, constrained: np.ndarray):
+    """Tentative prolongation of level 0 (scipy CSR, 3 * nnodes rows): per aggregate the orthonormalised rigid-body modes."""
+    return tentative_prolongation(agg, na, 3 * np.arange(coords.shape[0] + 1, dtype=np.int64), rigid_body_modes(coords, constrained))[0]
+
+
+class _Level:
+    """One transfer of the hierarchy: A (n x n, values change per Newton step) -> A_next = P^T A P (nc x nc)."""
+    def __init__(self):
+        self.A = self.P = self.Pt = self.T = self.Anext = None
+        self.n = self.nc = 0
+        self.dense_next = False
+        self.info = {}
+        # smoother data of THIS level's matrix (levels >= 1 only; level 0 is smoothed by the solver)
+        self.v = {}
+        self.x0 = None
+        self.emax = 1.0
 
 
 class AggregationAMG:
-    """Two-level smoothed aggregation under an `AssembledLevel` (see the module docstring)."""
+    """Smoothed-aggregation hierarchy under an `AssembledLevel` (see the module docstring)."""
 
-    def __init__(self, asm, prolongator_damping: float = 0.66, verbose: bool = False, max_coarse_dofs: int = 4096):
-        self.asm, self.ceed = asm, asm.ceed
-        self.damping, self.verbose, self.max_coarse_dofs = prolongator_damping, verbose, max_coarse_dofs
-        self.P = self.Pt = self.T = self.Ac = None
+    def __init__(self, asm, prolongator_damping: float = 0.66, verbose: bool = False, max_coarse_dofs: int = 1500,
+                 max_levels: int = 6, smooth_its: int = 3, smooth_ratio: float = 10.0):
+        self.asm, self.ceed, self.L = asm, asm.ceed, asm.ceed.L
+        self.damping, self.verbose, self.max_coarse_dofs, self.max_levels = prolongator_damping, verbose, max_coarse_dofs, max_levels
+        self.smooth_its, self.smooth_ratio = smooth_its, smooth_ratio
+        self.levels: list[_Level] = []
         self.rc = self.xc = None
         self.nc = 0
-        self.setup_seconds = 0.0
+        self._scal = None
         self.info = {}
 
-    # ---- once per solve: aggregates, prolongation, term lists ------------------------------------------------------
+    # two-level accessors (tests, older callers)
+    @property
+    def P(self): return self.levels[0].P if self.levels else None
+    @property
+    def Pt(self): return self.levels[0].Pt if self.levels else None
+    @property
+    def T(self): return self.levels[0].T if self.levels else None
+    @property
+    def Ac(self): return self.levels[0].Anext if self.levels else None
+
+    # ---- once per solve: aggregates, prolongations, product patterns -------------------------------------------------
+    def _transfer(self, A_csr, A_host, dof_ptr, B, free_node, dense_limit):
+        """One level: aggregate the node graph of A (nodes = runs of dofs given by dof_ptr; nodes with free_node False are
+        left out), tentative + smoothed prolongation, the two products.  Returns the _Level, the next B and dof_ptr."""
+        import scipy.sparse as sp
+        c = self.ceed
+        n = A_host.shape[0]
+        nn = dof_ptr.size - 1
+        node_of = np.searchsorted(dof_ptr, np.arange(n), side="right") - 1
+        a_row = np.repeat(np.arange(n, dtype=np.int64), np.diff(A_host.indptr))
+        G = sp.csr_matrix((np.ones(a_row.size), (node_of[a_row], node_of[A_host.indices])), shape=(nn, nn)).tocsr()
+        fn = np.nonzero(free_node)[0]
+        Gf = G[fn][:, fn].tocsr()
+        agg_f, na = aggregate_nodes(Gf.indptr, Gf.indices)
+        agg = np.full(nn, na, dtype=np.int64)          # left-out nodes: a dummy aggregate without columns
+        agg[fn] = agg_f
+        P0, Bn, col_ptr = tentative_prolongation(agg, na, dof_ptr, B)
+        # smoothed prolongation from the current (first) Jacobian: P = (I - w D^-1 A) P0, w = damping * 4/3 / lambda_max
+        diag = A_host.diagonal()
+        dinv = np.where(diag != 0.0, 1.0 / np.where(diag != 0.0, diag, 1.0), 0.0)
+        x = np.random.default_rng(77).uniform(-1.0, 1.0, n) * (np.abs(B).sum(axis=1) > 0.0)
+        lam = 1.0
+        for _ in range(30):                      # (sums, not BLAS norms: a threaded BLAS call leaves its pool spinning)
+            y = dinv * (A_host @ x)
+            lam = float(np.sqrt(np.square(y).sum() / np.square(x).sum()))
+            x = y / np.sqrt(np.square(y).sum())
+        lam *= 1.05
+        P = (P0 - (self.damping * 4.0 / 3.0 / lam) * (sp.diags(dinv) @ (A_host @ P0))).tocsr()
+        P.sort_indices()
+        Pt = P.T.tocsr()
+        Pt.sort_indices()
+        nc = P.shape[1]
+        lv = _Level()
+        lv.A, lv.n, lv.nc = A_csr, n, nc
+        lv.P = cd.Csr.rect(c, n, nc, P.indptr, P.indices, P.data)
+        lv.Pt = cd.Csr.rect(c, nc, n, Pt.indptr, Pt.indices, Pt.data)
+        lv.dense_next = nc <= dense_limit
+        # Galerkin product with fixed patterns: T = A P (A varies), A_next = P^T T (T varies)
+        lv.T = cd.Csr.product(A_csr, lv.P, variable=0)
+        lv.Anext = cd.Csr.product(lv.Pt, lv.T, variable=1, dense=lv.dense_next)
+        lv.info = dict(rows=int(n), aggregates=int(na), coarse_dofs=int(nc), nodes_per_aggregate=float(fn.size) / max(na, 1),
+                       prolongation_entries_per_row=float(P.nnz) / n, galerkin_entries=int(lv.T.nnz), lambda_max=lam,
+                       next_is_dense=bool(lv.dense_next))
+        return lv, Bn, col_ptr
+
     def build(self):
         import scipy.sparse as sp
         t0 = time.perf_counter()
         asm, c = self.asm, self.ceed
         n = asm.nrows
-        lv = asm.p.levels[asm.level]
-        constrained = lv.mask != 0
-        rowptr, cols = asm.rowptr, asm.cols
-        A = sp.csr_matrix((asm.csr.values(c), cols, rowptr), shape=(n, n))
-        a_row = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr))
-        # node graph without the fully constrained nodes (their rows are identity rows)
+        lvl = asm.p.levels[asm.level]
+        constrained = lvl.mask != 0
+        A_host = sp.csr_matrix((asm.csr.values(c), asm.cols, asm.rowptr), shape=(n, n))
         nn = n // 3
-        node_free = ~constrained.reshape(nn, 3).all(axis=1)
-        G = sp.csr_matrix((np.ones(a_row.size), (a_row // 3, cols // 3)), shape=(nn, nn)).tocsr()
-        fn = np.nonzero(node_free)[0]
-        Gf = G[fn][:, fn].tocsr()
-        agg_f, na = aggregate_nodes(Gf.indptr, Gf.indices)
-        agg = np.full(nn, na, dtype=np.int64)          # constrained nodes: a dummy aggregate without columns
-        agg[fn] = agg_f
-        P0 = rigid_body_prolongation(agg, na, lv.dofmap.node_coords, constrained)
-        # smoothed prolongation from the current (first) Jacobian: P = (I - w D^-1 A) P0, w = damping * 4/3 / lambda_max
-        dinv = 1.0 / A.diagonal()
-        x = np.random.default_rng(77).uniform(-1.0, 1.0, n) * ~constrained
-        lam = 1.0
-        for _ in range(30):                      # (sums, not BLAS norms: a threaded BLAS call leaves its pool spinning)
-            y = dinv * (A @ x)
-            lam = float(np.sqrt(np.square(y).sum() / np.square(x).sum()))
-            x = y / np.sqrt(np.square(y).sum())
-        lam *= 1.05
-        P = (P0 - (self.damping * 4.0 / 3.0 / lam) * (sp.diags(dinv) @ (A @ P0))).tocsr()
-        P.sort_indices()
-        nc = P.shape[1]
-        if nc > self.max_coarse_dofs:
-            # two levels only: the coarsest matrix is inverted densely every Newton step (n^3: 1.3 ms at 1 080 rows, ~0.1 s at
-            # 4 096); a mesh this large needs a third level (not built) -- the Chebyshev coarse solve takes any size
-            raise ValueError(f"the aggregation leaves {nc} coarse dofs (limit {self.max_coarse_dofs}: the coarsest level is inverted "
-                             f"densely); use coarse='assembled' for this mesh or raise max_coarse_dofs")
-        Pt = P.T.tocsr()
-        Pt.sort_indices()
-        self.P = cd.Csr.rect(c, n, nc, P.indptr, P.indices, P.data)
-        self.Pt = cd.Csr.rect(c, nc, n, Pt.indptr, Pt.indices, Pt.data)
-        # Galerkin product with fixed patterns: T = A P (A varies), A_c = P^T T (T varies), A_c stored dense
-        self.T = cd.Csr.product(asm.csr, self.P, variable=0)
-        self.Ac = cd.Csr.product(self.Pt, self.T, variable=1, dense=True)
-        self.rc, self.xc = c.vector(nc).set_value(0.0), c.vector(nc).set_value(0.0)
-        self.nc = nc
-        self.info = dict(aggregates=int(na), coarse_dofs=int(nc), nodes_per_aggregate=float(fn.size) / max(na, 1),
-                         prolongation_entries_per_row=float(P.nnz) / n, galerkin_entries=int(self.T.nnz),
-                         lambda_max=lam, build_seconds=time.perf_counter() - t0)
+        dof_ptr = 3 * np.arange(nn + 1, dtype=np.int64)
+        B = rigid_body_modes(lvl.dofmap.node_coords, constrained)
+        free_node = ~constrained.reshape(nn, 3).all(axis=1)       # fully constrained nodes have identity rows
+        A_csr = asm.csr
+        self.levels = []
+        while True:
+            last_allowed = len(self.levels) + 2 >= self.max_levels
+            lv, B, dof_ptr = self._transfer(A_csr, A_host, dof_ptr, B, free_node,
+                                            dense_limit=self.max_coarse_dofs if not last_allowed else 2 ** 30)
+            self.levels.append(lv)
+            if lv.dense_next:
+                break
+            if lv.nc > 0.7 * lv.n:
+                raise ValueError(f"aggregation stalls ({lv.n} -> {lv.nc} rows): no hierarchy for this matrix")
+            # the next level's matrix on the host (for its aggregates and its prolongator smoothing), from the device product
+            lv.T.update(); lv.Anext.update()
+            nr, ncol, nz, rp, cl = lv.Anext.pattern()
+            A_host = sp.csr_matrix((lv.Anext.values(c), cl, rp), shape=(nr, ncol))
+            A_csr = lv.Anext
+            free_node = np.ones(dof_ptr.size - 1, dtype=bool)
+            # work vectors and the start vector of the eigenvalue estimate of the new level
+            for k in ("x", "b", "r", "d", "t", "z", "dinv"):
+                lv.v[k] = c.vector(lv.nc).set_value(0.0)
+            x0 = np.random.default_rng(4321 + len(self.levels)).uniform(-1.0, 1.0, lv.nc)
+            lv.x0 = c.vector(lv.nc).set_array(x0 / np.sqrt(np.square(x0).sum()))
+        last = self.levels[-1]
+        self.rc, self.xc = c.vector(last.nc).set_value(0.0), c.vector(last.nc).set_value(0.0)
+        self.nc = self.levels[0].nc
+        self.info = dict(levels=len(self.levels) + 1, rows=[self.levels[0].n] + [l.nc for l in self.levels],
+                         aggregates=self.levels[0].info["aggregates"], coarse_dofs=self.levels[0].nc,
+                         nodes_per_aggregate=self.levels[0].info["nodes_per_aggregate"],
+                         per_level=[l.info for l in self.levels], build_seconds=time.perf_counter() - t0)
         if self.verbose:
             print("AggregationAMG:", self.info, flush=True)
 
-    # ---- every Newton step: the Galerkin matrix of the current Jacobian and its inverse ----------------------------
+    # ---- every Newton step: the Galerkin matrices of the current Jacobian, smoother bounds, the inverse -------------
     def setup(self):
-        if self.P is None:
+        if not self.levels:
             self.build()
-        self.T.update()
-        self.Ac.update()
-        self.Ac.invert_dense_spd()
+        for i, lv in enumerate(self.levels):
+            lv.T.update()
+            lv.Anext.update()
+            if lv.dense_next:
+                lv.Anext.invert_dense_spd()
+            else:
+                lv.Anext.diagonal(lv.v["dinv"])
+                lv.v["dinv"].reciprocal()
+                lv.emax = self._estimate_emax(lv)
 
-    # ---- the coarse correction of one cycle: x += P A_c^-1 P^T r ---------------------------------------------------
+    def _estimate_emax(self, lv, steps: int = 10) -> float:
+        """Largest eigenvalue of D^-1 A_next: the Lanczos tridiagonal of `steps` Jacobi-PCG steps, scalars on the device
+        (the same recurrence as solver.NewtonPMG._lanczos_device)."""
+        lib, chk, v = self.L.lib, self.L.chk, lv.v
+        r, z, pv, Ap = v["r"], v["z"], v["d"], v["t"]
+        if self._scal is None:
+            self._scal = self.ceed.vector(8 + 2 * 16)
+        sc = self._scal
+        sc.set_value(0.0)
+        one, neg = C.c_double(1.0), C.c_double(-1.0)
+        chk(lib.CeedXVectorAXPBY(r.h, one, lv.x0.h, C.c_double(0.0)))
+        chk(lib.CeedXVectorPointwiseMult(z.h, r.h, v["dinv"].h))
+        chk(lib.CeedXVectorAXPBY(pv.h, one, z.h, C.c_double(0.0)))
+        chk(lib.CeedXVectorDotTo(r.h, z.h, None, sc.h, 0))
+        for j in range(steps):
+            rz, rz_new, ja, jb = (0, 3, 8 + 2 * j, 9 + 2 * j) if j % 2 == 0 else (3, 0, 8 + 2 * j, 9 + 2 * j)
+            lv.Anext.apply(pv, Ap)
+            chk(lib.CeedXVectorDotTo(pv.h, Ap.h, None, sc.h, 1))
+            chk(lib.CeedXScalarDivide(sc.h, ja, rz, 1, one))
+            chk(lib.CeedXVectorAXPBYScalars(r.h, sc.h, ja, neg, Ap.h, -1, one))
+            chk(lib.CeedXVectorPointwiseMult(z.h, r.h, v["dinv"].h))
+            chk(lib.CeedXVectorDotTo(r.h, z.h, None, sc.h, rz_new))
+            chk(lib.CeedXScalarDivide(sc.h, jb, rz_new, rz, one))
+            chk(lib.CeedXVectorAXPBYScalars(pv.h, sc.h, -1, one, z.h, jb, one))
+        s = sc.to_numpy()
+        alphas, betas = [], []
+        for j in range(steps):
+            if not (s[8 + 2 * j] > 0.0) or not np.isfinite(s[9 + 2 * j]):
+                break
+            alphas.append(float(s[8 + 2 * j])); betas.append(float(s[9 + 2 * j]))
+        k = len(alphas)
+        if not k:
+            return 1.0
+        T = np.zeros((k, k))
+        for j in range(k):
+            T[j, j] = 1.0 / alphas[j] + (betas[j - 1] / alphas[j - 1] if j else 0.0)
+            if j + 1 < k:
+                T[j, j + 1] = T[j + 1, j] = np.sqrt(max(betas[j], 0.0)) / alphas[j]
+        return float(np.linalg.eigvalsh(T).max())
+
+    # ---- the cycle ------------------------------------------------------------------------------------------------------
+    def _chebyshev(self, lv, b, x, zero_guess):
+        """Chebyshev-Jacobi sweep on lv.Anext (the matrix of the level BELOW transfer lv), bounds [emax / ratio, 1.1 emax]."""
+        lib, chk, v = self.L.lib, self.L.chk, lv.v
+        lmin, lmax = lv.emax / self.smooth_ratio, 1.1 * lv.emax
+        theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+        sigma = theta / delta
+        rho = 1.0 / sigma
+        r, d, t = v["r"], v["d"], v["t"]
+        if zero_guess:
+            chk(lib.CeedXVectorChebyshevStart(x.h, d.h, r.h, b.h, None, v["dinv"].h, C.c_double(1.0 / theta), 1))
+        else:
+            lv.Anext.apply(x, t)
+            chk(lib.CeedXVectorChebyshevStart(x.h, d.h, r.h, b.h, t.h, v["dinv"].h, C.c_double(1.0 / theta), 0))
+        for _ in range(1, self.smooth_its):
+            lv.Anext.apply(d, t)
+            rho_new = 1.0 / (2.0 * sigma - rho)
+            chk(lib.CeedXVectorChebyshevUpdate(x.h, d.h, r.h, t.h, v["dinv"].h, C.c_double(2.0 * rho_new / delta), C.c_double(rho_new * rho), 0))
+            rho = rho_new
+
+    def _cycle(self, i):
+        """Solve approximately A_{i} x = b on the level below transfer i - 1 (its vectors live in levels[i - 1].v)."""
+        up = self.levels[i - 1]             # the transfer that produced this level: its matrix is up.Anext
+        b, x = up.v["b"], up.v["x"]
+        lv = self.levels[i]                 # the transfer from this level to the next
+        lib, chk = self.L.lib, self.L.chk
+        self._chebyshev(up, b, x, True)
+        up.Anext.apply(x, up.v["t"])
+        chk(lib.CeedXVectorWAXPBY(up.v["z"].h, C.c_double(1.0), b.h, C.c_double(-1.0), up.v["t"].h))
+        if lv.dense_next:
+            lv.Pt.apply(up.v["z"], self.rc)
+            lv.Anext.apply(self.rc, self.xc)
+            lv.P.apply(self.xc, up.v["z"])
+        else:
+            lv.Pt.apply(up.v["z"], lv.v["b"])
+            self._cycle(i + 1)
+            lv.P.apply(lv.v["x"], up.v["z"])
+        chk(lib.CeedXVectorAXPBY(x.h, C.c_double(1.0), up.v["z"].h, C.c_double(1.0)))
+        self._chebyshev(up, b, x, False)
+
+    # ---- the coarse correction of level 0 (called by the solver between its own smoothing sweeps): x += P (...) P^T r
     def restrict(self, r: cd.Vector):
-        self.Pt.apply(r, self.rc)
+        l0 = self.levels[0]
+        l0.Pt.apply(r, self.rc if l0.dense_next else l0.v["b"])
 
     def solve_coarsest(self):
-        self.Ac.apply(self.rc, self.xc)
+        l0 = self.levels[0]
+        if l0.dense_next:
+            l0.Anext.apply(self.rc, self.xc)
+        else:
+            self._cycle(1)
 
     def prolong(self, z: cd.Vector):
-        self.P.apply(self.xc, z)
+        l0 = self.levels[0]
+        l0.P.apply(self.xc if l0.dense_next else l0.v["x"], z)
 
     def destroy(self):
-        for o in (self.Ac, self.T, self.Pt, self.P, self.rc, self.xc):
+        for lv in reversed(self.levels):
+            for o in [lv.Anext, lv.T, lv.Pt, lv.P, lv.x0] + list(lv.v.values()):
+                if o is not None:
+                    o.destroy()
+        for o in (self.rc, self.xc, self._scal):
             if o is not None:
                 o.destroy()
-        self.P = self.Pt = self.T = self.Ac = self.rc = self.xc = None
-
+        self.levels, self.rc, self.xc, self._scal = [], None, None, None

@@ -116,7 +116,28 @@ def test_aggregates_cover_the_graph_and_rigid_body_modes_are_reproduced():
         assert np.abs(P0 @ (P0.T @ u) - u).max() < 1e-12
 
 
-def hierarchy_on_fixture(ceed):
+def test_near_null_space_is_carried_down_the_levels():
+    """B = P0 B1 = P0 P1 B2 exactly: the SVD factors of each aggregate's block split it into the prolongation's columns and
+    the next level's near-null space, level after level (aggregates of aggregates)."""
+    from ceedpetscsolid_amd.amg import rigid_body_modes, tentative_prolongation
+    from ceedpetscsolid_amd.mesh import build_dofmap
+    dm = build_dofmap(hollow_cylinder_mesh(2, 8, 6), 1)
+    off = dm.elem_nodes.astype(np.int64)
+    r = np.repeat(off, 8, axis=1).reshape(-1); c = np.tile(off, (1, 8)).reshape(-1)
+    G = sp.csr_matrix((np.ones(r.size), (r, c)), shape=(dm.nnodes, dm.nnodes)).tocsr()
+    agg, na = aggregate_nodes(G.indptr, G.indices)
+    con = np.zeros(3 * dm.nnodes, dtype=bool); con[:30] = True           # a few constrained dofs: their rows of B are zero
+    B0 = rigid_body_modes(dm.node_coords, con)
+    P0, B1, ptr1 = tentative_prolongation(agg, na, 3 * np.arange(dm.nnodes + 1), B0)
+    assert ptr1.size == na + 1 and ptr1[-1] == P0.shape[1] == B1.shape[0]
+    assert np.abs(P0 @ B1 - B0).max() < 1e-12
+    agg2 = np.arange(na) // 4
+    P1, B2, ptr2 = tentative_prolongation(agg2, int(agg2.max()) + 1, ptr1, B1)
+    assert np.abs(P1 @ B2 - B1).max() < 1e-12 and np.abs(P0 @ (P1 @ B2) - B0).max() < 1e-12
+    assert abs(P1.T @ P1 - sp.identity(P1.shape[1])).max() < 1e-12
+
+
+def hierarchy_on_fixture(ceed, **kw):
     mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_672e_4ss_us.npz"))
     p = SolidProblem(ceed, mesh, 2, "hyperSS", nu=0.3, E=1e3, bc_sides=[998, 999])
     U, R = ceed.vector(p.lsize()), ceed.vector(p.lsize())
@@ -124,7 +145,7 @@ def hierarchy_on_fixture(ceed):
     u = 0.02 * np.stack([np.sin(X[:, 1]) * X[:, 2], np.cos(X[:, 0]) * X[:, 2], np.sin(X[:, 0] + X[:, 1])], axis=1).reshape(-1)
     U.set_array(u * (p.levels[p.fine].mask == 0)); p.form_residual(U, R)
     a = AssembledLevel(p, 0); a.assemble()
-    amg = AggregationAMG(a); amg.setup()
+    amg = AggregationAMG(a, **kw); amg.setup()
     return p, a, amg
 
 
@@ -160,6 +181,32 @@ def test_solve_with_the_aggregation_coarse_solve_on_oracle(oracle):
     assert st.coarse_its < st_ref.coarse_its / 4
 
 
+def test_three_levels_on_oracle(oracle):
+    """A dense-level limit below the first coarse level's size adds a level: 3 000 -> 192 -> 18 rows on the fixture.  The
+    second Galerkin matrix is P1^T A1 P1 of the FIRST one, its smoother bound is estimated per set-up, and the solve with
+    the three-level cycle as coarse solver takes about as many iterations as with two levels."""
+    p, a, amg = hierarchy_on_fixture(oracle, max_coarse_dofs=60)
+    assert amg.info["levels"] == 3 and amg.info["rows"][1] == 192 and amg.info["rows"][2] <= 60
+    l0, l1 = amg.levels
+    A0, P0 = to_scipy(a.csr), to_scipy(l0.P)
+    A1 = to_scipy(l0.Anext)
+    assert abs(A1 - P0.T @ A0 @ P0).max() < 1e-10 * abs(A0).max()
+    P1 = to_scipy(l1.P)
+    A2 = (P1.T @ A1 @ P1).toarray()
+    assert np.abs(to_scipy(l1.Anext).toarray() @ A2 - np.eye(l1.nc)).max() < 1e-9
+    lam = np.linalg.eigvalsh(np.diag(1 / np.sqrt(A1.diagonal())) @ A1.toarray() @ np.diag(1 / np.sqrt(A1.diagonal()))).max()
+    assert 0.7 * lam < l0.emax < 1.05 * lam                 # 10 Lanczos steps from a random start: a lower bound, close
+    mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_672e_4ss_us.npz"))
+    its = []
+    for mc in (1500, 60):
+        pr = SolidProblem(oracle, mesh, 2, "hyperSS", nu=0.3, E=1e3, bc_sides=[998, 999])
+        s = NewtonPMG(pr, clamp=CLAMP, coarse="amg", amg_max_coarse_dofs=mc)
+        st = s.solve(1)
+        assert st.converged
+        its.append(st.ksp_its)
+    assert its[1] <= 1.3 * its[0]
+
+
 # ---- the device against the oracle ------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_products_follow_the_variable_operand_on_device(gpu):
@@ -187,6 +234,22 @@ def test_hierarchy_on_device_matches_oracle(oracle, gpu):
         m.restrict(c.vector(n).set_array(r)); m.solve_coarsest(); m.prolong(z)
         out.append(z.to_numpy())
     assert rel_err(out[1], out[0]) < 1e-9
+
+
+@pytest.mark.gpu
+def test_three_level_cycle_on_device_matches_oracle(oracle, gpu):
+    (po, ao, mo), (pg, ag, mg) = hierarchy_on_fixture(oracle, max_coarse_dofs=60), hierarchy_on_fixture(gpu, max_coarse_dofs=60)
+    assert mo.info["rows"] == mg.info["rows"] and mo.info["levels"] == 3
+    assert rel_err(mg.levels[0].Anext.values(), mo.levels[0].Anext.values()) < 1e-11
+    assert abs(mg.levels[0].emax - mo.levels[0].emax) < 1e-9 * mo.levels[0].emax
+    n = ao.nrows
+    r = np.random.default_rng(9).standard_normal(n) * (po.levels[0].mask == 0)
+    out = []
+    for c, m in ((oracle, mo), (gpu, mg)):
+        z = c.vector(n)
+        m.restrict(c.vector(n).set_array(r)); m.solve_coarsest(); m.prolong(z)
+        out.append(z.to_numpy())
+    assert rel_err(out[1], out[0]) < 1e-8
 
 
 @pytest.mark.gpu
