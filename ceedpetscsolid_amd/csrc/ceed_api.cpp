@@ -175,6 +175,7 @@ struct GatedMap {
 struct PipeMap {
   bool built = false;
   int nseg = 0, req_seg = 0, E = 0, waves = 0, nrows = 0;
+  int build_id = 0;                        // bumped by every (re)build: operators cache per-row flags in this row order
   const void *base = nullptr;              // the CsrMap it was derived from
   std::vector<int> elem_bound, row_bound;  // nseg + 1 each
   std::vector<uint32_t> h_node_off;        // re-ordered (for the per-operator Dirichlet flags)
@@ -252,6 +253,7 @@ struct CeedOperator_private {
   unsigned char *d_node_flags_shell = nullptr;  // per node of the restriction's shell map (direct-store mode)
   unsigned char *d_node_flags_gated = nullptr;  // per row of the restriction's gated map
   unsigned char *d_node_flags_pipe = nullptr;   // per row of the restriction's pipelined map
+  int pipe_flags_id = 0;                        // PipeMap::build_id the flags were made for
   uint32_t *d_off_paired = nullptr;             // offsets with the Dirichlet flags AND the pair-merge bits (whole applies of the pencil kernel)
   std::vector<unsigned char> h_mask;      // copy of the output mask (node flags are derived lazily)
   int mask_mode = 0;
@@ -1161,6 +1163,7 @@ static int build_pipe(CeedElemRestriction r, const CsrMap &M, int E, int per_ele
   };
   CHK(up(&G.d_rowptr, rp2)); CHK(up(&G.d_cols, cols2)); CHK(up(&G.d_node_off, no2));
   G.built = true;
+  G.build_id++;
   return 0;
 }
 static int ceed_need_evec(Ceed c, size_t len) {
@@ -1546,7 +1549,13 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
         CHK(build_pipe(r, *M, pencil_group_elems(ai.basis->Q1d), per_elem, std::max(c->pipe_segments, 0), waves, r->pipe));
         if (r->pipe.nseg >= 2) PM = &r->pipe;
       }
+      if (PM && op->d_node_flags_pipe && op->pipe_flags_id != PM->build_id) {     // the map was rebuilt (another operator's wave count): new row order
+        HIPCHK(hipStreamSynchronize(s));
+        (void)hipFree(op->d_node_flags_pipe);
+        op->d_node_flags_pipe = nullptr;
+      }
       if (PM && !op->d_node_flags_pipe && !op->h_mask.empty()) {
+        op->pipe_flags_id = PM->build_id;
         std::vector<unsigned char> fl((size_t)PM->nrows, 0);
         for (int i = 0; i < PM->nrows; i++)
           for (int cc = 0; cc < r->ncomp && cc < 3; cc++)
