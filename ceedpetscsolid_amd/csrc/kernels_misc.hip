@@ -1,6 +1,7 @@
 // kernels_misc.hip -- geometry set-up, p-multigrid transfer, diagonal assembly,
 // restriction and vector utilities, and the (P,Q,qf) dispatch tables.
 #include <algorithm>
+#include <cstring>
 #include "kernels_common.hpp"
 #include "qfunctions_device.hpp"
 
@@ -240,18 +241,121 @@ __global__ __launch_bounds__(Geom<Q>::TPE) void k_diag(const BasisTables tab, co
     }
   }
 }
+// The same diagonal, sum-factorised.  diag_c(n) = sum_q sum_{d,d2} g_d(n,q) D^c_{d d2}(q) g_d2(n,q) with g_d a product of
+// 1-D factors, so each of the 18 tensors S^c_pair(q) (pair = (d,d2), d <= d2; off-diagonal pairs hold D_{d d2} + D_{d2 d})
+// is contracted direction by direction with the PRODUCT tables BB, BG, GG (table_x(i,a) = X_d(i,a) X_d2(i,a), X = G in its
+// own direction, B otherwise): 18 * (P Q^2 + P^2 Q + P^3) * Q FMAs per element instead of P^3 * Q^3 * 60 (25x fewer at
+// P = Q = 5); what remains is the nine physics evaluations per point that probe D.
+template <int P, int Q, int QF>
+__global__ __launch_bounds__(Geom<Q>::TPE) void k_diag_sf(const BasisTables tab, const DiagArgs a) {
+  using G = Geom<Q>;
+  constexpr int Q3 = G::Q3, P3 = P * P * P, TPE = G::TPE, NT = 18;
+  constexpr int PQQ = P * Q * Q, PPQ = P * P * Q, S0 = Q3 > PPQ ? Q3 : PPQ;
+  constexpr bool ST_IN = QFTraits<QF>::state_in;
+  extern __shared__ double dyn[];
+  double *sT = dyn;                  // [3][Q * P]: BB, BG, GG
+  double *s0 = sT + 3 * Q * P;       // [NT][Q3] the tensors, later [NT][P * P * Q]
+  double *s1 = s0 + NT * S0;         // [NT][P * Q * Q]
+  const int q = threadIdx.x, e = blockIdx.x;
+  for (int i = q; i < Q * P; i += TPE) {
+    const double bb = tab.interp[i], gg = tab.grad[i];
+    sT[i] = bb * bb; sT[Q * P + i] = bb * gg; sT[2 * Q * P + i] = gg * gg;
+  }
+  if (q < Q3) {
+    double qd[10], st[9], dv[9], sto[9], ug[9], D[3][3][3];   // D[c][dout][din]
+    const double *qp = a.qdata + (size_t)e * 10 * Q3 + q;
+#pragma unroll
+    for (int c = 0; c < 10; c++) qd[c] = qp[c * Q3];
+    if constexpr (ST_IN) {
+      const double *sp = a.state_in + (size_t)e * 9 * Q3 + q;
+#pragma unroll
+      for (int c = 0; c < 9; c++) st[c] = sp[c * Q3];
+    }
+#pragma unroll
+    for (int din = 0; din < 3; din++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int s = 0; s < 9; s++) ug[s] = (s == din * 3 + c) ? 1. : 0.;
+        qf_point<QF>(Phys{a.nu, a.E, a.lambda, a.TwoMu}, ug, qd, st, dv, sto);
+#pragma unroll
+        for (int dout = 0; dout < 3; dout++) D[c][dout][din] = dv[dout * 3 + c];
+      }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      s0[(c * 6 + 0) * Q3 + q] = D[c][0][0];
+      s0[(c * 6 + 1) * Q3 + q] = D[c][1][1];
+      s0[(c * 6 + 2) * Q3 + q] = D[c][2][2];
+      s0[(c * 6 + 3) * Q3 + q] = D[c][0][1] + D[c][1][0];
+      s0[(c * 6 + 4) * Q3 + q] = D[c][0][2] + D[c][2][0];
+      s0[(c * 6 + 5) * Q3 + q] = D[c][1][2] + D[c][2][1];
+    }
+  }
+  __syncthreads();
+  // table kind of pair p in direction dir: (d == dir) + (d2 == dir)  (0 BB, 1 BG, 2 GG)
+  auto kind = [](int p, int dir) {
+    const int d = p < 3 ? p : (p == 5 ? 1 : 0), d2 = p < 3 ? p : (p == 3 ? 1 : 2);
+    return (d == dir) + (d2 == dir);
+  };
+  // x: U1[t][k][j][a] = sum_i T(i,a) S[t][k][j][i]
+  for (int o = q; o < NT * PQQ; o += TPE) {
+    const int t = o / PQQ, r = o % PQQ, aa = r % P, kj = r / P;
+    const double *T = sT + kind(t % 6, 0) * Q * P, *src = s0 + t * Q3 + kj * Q;
+    double v = 0.;
+#pragma unroll
+    for (int i = 0; i < Q; i++) v += T[i * P + aa] * src[i];
+    s1[o] = v;
+  }
+  __syncthreads();
+  // y: U2[t][k][b][a] = sum_j T(j,b) U1[t][k][j][a]
+  for (int o = q; o < NT * PPQ; o += TPE) {
+    const int t = o / PPQ, r = o % PPQ, aa = r % P, bb = (r / P) % P, k = r / (P * P);
+    const double *T = sT + kind(t % 6, 1) * Q * P, *src = s1 + t * PQQ + k * Q * P + aa;
+    double v = 0.;
+#pragma unroll
+    for (int j = 0; j < Q; j++) v += T[j * P + bb] * src[j * P];
+    s0[o] = v;
+  }
+  __syncthreads();
+  // z, and the sum over the pairs: one node per thread
+  if (q < P3) {
+    const int ab = q % (P * P), nc = q / (P * P);
+    double acc[3] = {0., 0., 0.};
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+      for (int p = 0; p < 6; p++) {
+        const double *T = sT + kind(p, 2) * Q * P, *src = s0 + (c * 6 + p) * PPQ + ab;
+        double v = 0.;
+#pragma unroll
+        for (int k = 0; k < Q; k++) v += T[k * P + nc] * src[k * P * P];
+        acc[c] += v;
+      }
+    const uint32_t off = a.offsets[(size_t)e * P3 + q];
+    const uint32_t base = off & OFF_MASK, fl = a.mask_out ? (off >> OFF_FLAG_SHIFT) : 0u;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      if (a.evec) a.evec[((size_t)e * P3 + q) * 3 + c] = ((fl >> c) & 1u) ? 0. : acc[c];  // summed by launch_assemble()
+      else if (!((fl >> c) & 1u)) atomic_add_f64(a.diag + base + c, acc[c]);
+    }
+  }
+}
 template <int P, int Q, int QF>
 static hipError_t diag_t(const BasisTables &t, const DiagArgs &a, hipStream_t s) {
   using G = Geom<Q>;
   if (a.nelem <= 0) return hipSuccess;
-  const size_t lds = sizeof(double) * (2 * Q * P + 27 * G::Q3);
+  static const bool direct = getenv("CEED_MI355X_DIAG") && !strcmp(getenv("CEED_MI355X_DIAG"), "direct");   // A/B: the unfactorised kernel
+  constexpr int PQQ = P * Q * Q, PPQ = P * P * Q, S0 = G::Q3 > PPQ ? G::Q3 : PPQ;
+  const size_t lds = direct ? sizeof(double) * (2 * Q * P + 27 * G::Q3) : sizeof(double) * (3 * Q * P + 18 * (S0 + PQQ));
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t er = hipFuncSetAttribute((const void *)k_diag<P, Q, QF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t er = direct ? hipFuncSetAttribute((const void *)k_diag<P, Q, QF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                           : hipFuncSetAttribute((const void *)k_diag_sf<P, Q, QF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (er != hipSuccess) return er;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_diag<P, Q, QF>), dim3(a.nelem), dim3(G::TPE), lds, s, t, a);
+  if (direct) hipLaunchKernelGGL((k_diag<P, Q, QF>), dim3(a.nelem), dim3(G::TPE), lds, s, t, a);
+  else hipLaunchKernelGGL((k_diag_sf<P, Q, QF>), dim3(a.nelem), dim3(G::TPE), lds, s, t, a);
   return hipGetLastError();
 }
 hipError_t launch_diag(int P, int Q, int qf, const BasisTables &t, const DiagArgs &a, hipStream_t s,
