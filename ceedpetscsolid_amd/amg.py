@@ -127,10 +127,10 @@ class AggregationAMG:
     """Smoothed-aggregation hierarchy under an `AssembledLevel` (see the module docstring)."""
 
     def __init__(self, asm, prolongator_damping: float = 0.66, verbose: bool = False, max_coarse_dofs: int = 1500,
-                 max_levels: int = 6, smooth_its: int = 3, smooth_ratio: float = 10.0):
+                 max_levels: int = 6, smooth_its: int = 3, smooth_ratio: float = 10.0, coarse_cycles: int = 1):
         self.asm, self.ceed, self.L = asm, asm.ceed, asm.ceed.L
         self.damping, self.verbose, self.max_coarse_dofs, self.max_levels = prolongator_damping, verbose, max_coarse_dofs, max_levels
-        self.smooth_its, self.smooth_ratio = smooth_its, smooth_ratio
+        self.smooth_its, self.smooth_ratio, self.coarse_cycles = smooth_its, smooth_ratio, coarse_cycles
         self.levels: list[_Level] = []
         self.rc = self.xc = None
         self.nc = 0
@@ -316,19 +316,20 @@ class AggregationAMG:
         b, x = up.v["b"], up.v["x"]
         lv = self.levels[i]                 # the transfer from this level to the next
         lib, chk = self.L.lib, self.L.chk
-        self._chebyshev(up, b, x, True)
-        up.Anext.apply(x, up.v["t"])
-        chk(lib.CeedXVectorWAXPBY(up.v["z"].h, C.c_double(1.0), b.h, C.c_double(-1.0), up.v["t"].h))
-        if lv.dense_next:
-            lv.Pt.apply(up.v["z"], self.rc)
-            lv.Anext.apply(self.rc, self.xc)
-            lv.P.apply(self.xc, up.v["z"])
-        else:
-            lv.Pt.apply(up.v["z"], lv.v["b"])
-            self._cycle(i + 1)
-            lv.P.apply(lv.v["x"], up.v["z"])
-        chk(lib.CeedXVectorAXPBY(x.h, C.c_double(1.0), up.v["z"].h, C.c_double(1.0)))
-        self._chebyshev(up, b, x, False)
+        for rep in range(self.coarse_cycles):      # coarse_cycles = 2: two cycles of this level per visit (a W-cycle of the hierarchy)
+            self._chebyshev(up, b, x, rep == 0)
+            up.Anext.apply(x, up.v["t"])
+            chk(lib.CeedXVectorWAXPBY(up.v["z"].h, C.c_double(1.0), b.h, C.c_double(-1.0), up.v["t"].h))
+            if lv.dense_next:
+                lv.Pt.apply(up.v["z"], self.rc)
+                lv.Anext.apply(self.rc, self.xc)
+                lv.P.apply(self.xc, up.v["z"])
+            else:
+                lv.Pt.apply(up.v["z"], lv.v["b"])
+                self._cycle(i + 1)
+                lv.P.apply(lv.v["x"], up.v["z"])
+            chk(lib.CeedXVectorAXPBY(x.h, C.c_double(1.0), up.v["z"].h, C.c_double(1.0)))
+            self._chebyshev(up, b, x, False)
 
     # ---- the coarse correction of level 0 (called by the solver between its own smoothing sweeps): x += P (...) P^T r
     def restrict(self, r: cd.Vector):

@@ -78,7 +78,7 @@ class NewtonPMG:
     def __init__(self, prob: SolidProblem, clamp: Optional[Dict[int, dict]] = None, mms: bool = False, forcing=None,
                  halo=None, smooth_its: int = 3, coarse_rtol: float = 1e-3, coarse_maxit: int = 200,
                  coarse: str = "cg", coarse_cheb_its: int = 40, coarse_cheb_ratio: float = 100.0, graph: bool = False,
-                 amg_smooth_its: int = 3, amg_smooth_ratio: float = 10.0, amg_max_coarse_dofs: int = 1500,
+                 amg_smooth_its: int = 3, amg_smooth_ratio: float = 10.0, amg_max_coarse_dofs: int = 1500, amg_coarse_cycles: int = 1,
                  ksp_rtol: float = 1e-10, snes_rtol: float = 1e-8, snes_maxit: int = 50, verbose: bool = False):
         """``clamp``: {side_set_id: dict(translate=(..), axis=(..), angle_over_pi=..)} as
         -bc_clamp_<id>_translate / _rotate (cloptions.c:86-131); ids present in the problem's Dirichlet
@@ -112,7 +112,7 @@ class NewtonPMG:
                     raise ValueError("coarse='amg' is a single-rank coarse solve (the aggregates do not cross partitions yet)")
                 from .amg import AggregationAMG
                 self.amg = AggregationAMG(self.asm, verbose=verbose, max_coarse_dofs=amg_max_coarse_dofs,
-                                          smooth_its=amg_smooth_its, smooth_ratio=amg_smooth_ratio)
+                                          smooth_its=amg_smooth_its, smooth_ratio=amg_smooth_ratio, coarse_cycles=amg_coarse_cycles)
         self._pc_graph, self._pc_graph_io, self._pc_graph_counts, self._pc_warm = None, None, (0, 0), False
         self.ksp_rtol, self.snes_rtol, self.snes_maxit, self.verbose = ksp_rtol, snes_rtol, snes_maxit, verbose
         self.nlev = len(prob.levels)

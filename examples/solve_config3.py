@@ -33,6 +33,7 @@ ap.add_argument("--coarse-cheb-its", type=int, default=40)
 ap.add_argument("--coarse-cheb-ratio", type=float, default=100.0)
 ap.add_argument("--amg-smooth-its", type=int, default=3)
 ap.add_argument("--amg-smooth-ratio", type=float, default=10.0)
+ap.add_argument("--amg-coarse-cycles", type=int, default=1, help="cycles of an intermediate level of the aggregation hierarchy per visit (2: a W-cycle)")
 ap.add_argument("--amg-max-coarse", type=int, default=1500, help="rows up to which a level of the aggregation hierarchy is stored dense and inverted")
 ap.add_argument("--coarse-maxit", type=int, default=200)
 ap.add_argument("--coarse-rtol", type=float, default=1e-3)
@@ -68,7 +69,7 @@ tr = tuple(float(t) for t in args.translate.split(","))
 solver = NewtonPMG(prob, clamp={s: (dict(translate=tr) if s == 998 else dict()) for s in bc_sides}, halo=halos, verbose=args.verbose and rank == 0,
                    coarse_maxit=args.coarse_maxit, coarse_rtol=args.coarse_rtol, coarse=args.coarse, graph=args.graph,
                    coarse_cheb_its=args.coarse_cheb_its, coarse_cheb_ratio=args.coarse_cheb_ratio,
-                   amg_smooth_its=args.amg_smooth_its, amg_smooth_ratio=args.amg_smooth_ratio, amg_max_coarse_dofs=args.amg_max_coarse)
+                   amg_smooth_its=args.amg_smooth_its, amg_smooth_ratio=args.amg_smooth_ratio, amg_max_coarse_dofs=args.amg_max_coarse, amg_coarse_cycles=args.amg_coarse_cycles)
 t_setup = time.perf_counter() - t0
 st = solver.solve(args.increments)
 u = solver.U.to_numpy().reshape(-1, 3)
