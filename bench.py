@@ -36,8 +36,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from ceedpetscsolid_amd import ceed as cd  # noqa: E402
-from ceedpetscsolid_amd.halo import (HaloExchange, checked_rccl_halo, interface_elements, part_box, part_cylinder,  # noqa: E402
-                                     slab_box, slab_cylinder)
+from ceedpetscsolid_amd.halo import (HaloExchange, RcclHalo, checked_rccl_halo, interface_elements, part_box, part_cylinder,  # noqa: E402
+                                     slab_box, slab_cylinder, virtual_world)
 from ceedpetscsolid_amd.mesh import reorder_elements_first  # noqa: E402
 from ceedpetscsolid_amd.harness import SolidApp  # noqa: E402
 from ceedpetscsolid_amd.solid import SolidProblem, smooth_displacement  # noqa: E402
@@ -154,6 +154,11 @@ def main():
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed applies for this long before --warmup: the first ~20 ms after an idle period run at a "
                          "transient clock (per-dispatch trace in profiles/r02_dispatch_series.txt); reported as prewarm_ms")
+    ap.add_argument("--emulate-rank", type=int, default=-1, metavar="K",
+                    help="ONE GPU, no torch.distributed: run rank K's share of the --of N strong-scaling job -- its real sub-mesh, the "
+                         "split-phase apply exactly as at N > 1, and the library's RCCL exchange on a one-rank communicator whose "
+                         "neighbour lists have the TRUE sizes, sent to this rank itself (everything one GPU can tell about the N-GPU regime)")
+    ap.add_argument("--of", type=int, default=8, metavar="N")
     ap.add_argument("--calibrate-traffic", action="store_true",
                     help="also launch k_axpby over a 1 GiB vector (known byte count) for PMC calibration")
     args = ap.parse_args()
@@ -183,7 +188,17 @@ def main():
 
     # ---- workload ---------------------------------------------------------
     strong = args.scaling == "strong"
-    if args.workload == "cylinder":
+    emu = args.emulate_rank >= 0
+    vw = None
+    if emu:
+        if world != 1 or args.workload == "mesh" or not 0 <= args.emulate_rank < args.of:
+            sys.exit("--emulate-rank K --of N runs on one GPU without torch.distributed (cylinder or box workload)")
+        part = (lambda r: part_cylinder(r, args.of, args.nr, args.nth, args.nz)) if args.workload == "cylinder" else \
+               (lambda r: part_box(r, args.of, args.nr, args.nth, args.nz))
+        mesh = part(args.emulate_rank)
+        vw = virtual_world(args.emulate_rank, args.of, mesh, part, args.degree)
+        bc = [s for s in ((998, 999) if args.workload == "cylinder" else (1, 2)) if s in mesh.side_sets]
+    elif args.workload == "cylinder":
         mesh = part_cylinder(rank, world, args.nr, args.nth, args.nz) if strong else slab_cylinder(rank, world, args.nr, args.nth, args.nz)
         bc = [s for s in (998, 999) if s in mesh.side_sets]
     elif args.workload == "mesh":   # one unstructured mesh, z-slab partition of its elements over the ranks (strong scaling)
@@ -195,8 +210,8 @@ def main():
     else:
         mesh = part_box(rank, world, args.nr, args.nth, args.nz) if strong else slab_box(rank, world, args.nr, args.nth, args.nz)
         bc = [s for s in (1, 2) if s in mesh.side_sets]
-    lead = interface_elements(mesh)                    # collective; all False on one rank
-    overlap = world > 1 and not args.no_overlap and lead.any() and not lead.all()
+    lead = interface_elements(mesh, virtual=vw)        # collective; all False on one rank
+    overlap = (world > 1 or emu) and not args.no_overlap and lead.any() and not lead.all()
     if overlap:
         mesh = reorder_elements_first(mesh, lead)      # interface-touching elements lead (split-phase apply)
     # host side = the C++ harness (csrc/solid_harness.cpp): SetupLibceedFineLevel / SetupLibceedLevel /
@@ -204,13 +219,15 @@ def main():
     prob = SolidApp(ceed, mesh, args.degree, args.problem, nu=args.nu, E=args.E, bc_sides=bc, multigrid="none")
     dofmap, mask = prob.dofmaps[prob.fine], prob.masks[prob.fine]
     n = prob.lsize()
-    halo = HaloExchange(mesh, dofmap, device=dev)
+    halo = HaloExchange(mesh, dofmap, device=dev, virtual=vw)
     # the exchange itself: behind the C ABI over RCCL on a GPU node; the torch path on gloo (single-GPU rehearsal) or on request
     use_rccl = world > 1 and args.halo == "rccl" and dist.get_backend() == "nccl"
     chalo, halo_note = None, None
     if use_rccl:   # brought up with a time limit and checked against the torch exchange; falls back on every rank if it fails on any
         chalo, halo_note = checked_rccl_halo(ceed, halo, coord_hash_vector(dofmap.node_coords, np.zeros(n, dtype=np.uint8)), dev)
         use_rccl = chalo is not None
+    if emu:   # one-rank communicator, every neighbour list exchanged with this rank itself
+        chalo, halo_note, use_rccl = RcclHalo(ceed, halo, emulate_self=True), "emulated rank: self-exchange of the true neighbour lists", True
     free = (mask == 0).astype(np.float64)
     n_global = halo.global_count(free)
 
@@ -229,11 +246,13 @@ def main():
         op.set_overlap_split(int(lead.sum()), halo.interface_dof_mask())
 
     def step():
-        if overlap:   # interface elements -> start the RCCL exchange -> interior elements under it -> add
+        if overlap and chalo:   # ONE library call: interface elements, the RCCL exchange started, interior elements beside it, arrivals added
+            op.apply_with_halo(X, Y, chalo)
+        elif overlap:           # torch exchange (gloo rehearsal): the same split, driven from here
             op.apply_phase(X, Y, 0)
-            chalo.start(Y) if chalo else halo.start(yt)
+            halo.start(yt)
             op.apply_phase(X, Y, 1)
-            chalo.finish(Y) if chalo else halo.finish(yt)
+            halo.finish(yt)
         else:
             prob.apply_jacobian(prob.fine, X, Y)   # ApplyJacobian_Ceed: k_fused_pencil + k_assemble on `stream`
             chalo.add(Y) if chalo else halo.add(yt)   # interface sum (no-op at N = 1)
@@ -277,9 +296,11 @@ def main():
 
     # the exchange alone (outside the timed region): mean of 20 back-to-back interface sums
     halo_us = None
-    if world > 1:
+    if world > 1 or emu:
         ykeep = yt.clone()
-        torch.cuda.synchronize(); dist.barrier()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         th = time.perf_counter()
         for _ in range(20):
             chalo.add(Y) if chalo else halo.add(yt)
@@ -321,7 +342,7 @@ def main():
                        "partition": ((("z-layers of ONE mesh" if args.workload != "box" else "blocks %dx%dx%d of ONE box" % __import__("ceedpetscsolid_amd.halo", fromlist=["block_grid"]).block_grid(world)) if strong else "one such mesh per GPU (z-slabs)")
                                      + "; halo sum " + ("overlapped with interior elements" if overlap else "after the apply")
                                      + (" through CeedXHalo* (RCCL group of ncclSend/ncclRecv, pack / unpack-add kernels)" if use_rccl else " through torch.distributed P2P"))
-                                    if world > 1 else "single GPU",
+                                    if (world > 1 or emu) else "single GPU",
                        "halo_exchange_us_alone": halo_us, "halo_note": halo_note, "multi_gpu_measured": (None if world == 1 else "this run")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -338,7 +359,12 @@ def main():
                                         "one CeedOperatorApply = %d segments of consecutive elements, each a fused launch followed by the k_assemble of the rows it completes, alternating between %d streams so that the rows of a segment are summed beside the next fused kernel; kernel_avg_us is the hipEvent time of the WHOLE apply on the operator's stream (fork to join), not a sum of per-kernel durations, which overlap (profiles/README.md)" % (li["segments"], li["streams"]))),
                          "peak_measured_copy_GBs": 6290.0},
         }
-        if not args.no_cpu_baseline and world == 1 and args.workload == "cylinder":
+        if emu:
+            out["emulated_rank"] = {"rank": args.emulate_rank, "of": args.of, "lead_elements": int(lead.sum()),
+                                    "neighbour_dofs": [int(nb.dof_idx.numel()) for nb in halo.neigh],
+                                    "us_per_apply_incl_exchange": 1e6 * elapsed / args.steps,
+                                    "note": "value = dofs this rank OWNS x steps / time: one rank's share of the N-rank job, NOT the job's rate"}
+        if not args.no_cpu_baseline and world == 1 and args.workload == "cylinder" and not emu:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, args.nr, args.nth)
             except Exception as e:  # the baseline is informational; never hide the GPU number

@@ -63,7 +63,7 @@ class CeedLib:
         "CeedOperatorLinearAssembleDiagonal", "CeedOperatorDestroy",
         "CeedXSetErrorReturn", "CeedXLastError", "CeedXSetStream", "CeedXSynchronize",
         "CeedXOperatorGetKernelName", "CeedXOperatorSetDirichletMask",
-        "CeedXOperatorSetTiming", "CeedXOperatorGetTiming", "CeedXOperatorSetDirichletMaskMode", "CeedXOperatorGetGatedStats", "CeedXOperatorGetLaunchInfo",
+        "CeedXOperatorSetTiming", "CeedXOperatorGetTiming", "CeedXOperatorSetDirichletMaskMode", "CeedXOperatorGetLaunchInfo", "CeedXOperatorApplyWithHalo", "CeedXCommAllReduce",
         "CeedXCommGetUniqueId", "CeedXCommInit", "CeedXCommDestroy", "CeedXHaloCreate", "CeedXHaloStart", "CeedXHaloFinish", "CeedXHaloDestroy",
         "CeedXOperatorSetFineScale", "CeedXOperatorSetOverlapSplit", "CeedXOperatorApplyPhase",
         "CeedXVectorPointwiseMult", "CeedXVectorAXPBY", "CeedXVectorDot", "CeedXVectorChebyshevUpdate",
@@ -518,11 +518,10 @@ class Operator:
         self.L.chk(self.L.lib.CeedXOperatorGetLaunchInfo(self.h, out))
         return dict(segments=out[0], streams=out[1], assemble_launches=out[2], last_segment_elements=out[3])
 
-    def gated_stats(self) -> dict:
-        """CeedXOperatorGetGatedStats: how much of the restriction transpose ran beside the fused kernel."""
-        out = (C.c_longlong * 5)()
-        self.L.chk(self.L.lib.CeedXOperatorGetGatedStats(self.h, out))
-        return dict(items=out[0], rows=out[1], cut_rows=out[2], tail_items=out[3], applies=out[4])
+    def apply_with_halo(self, vin: "Vector", vout: "Vector", halo):
+        """CeedXOperatorApplyWithHalo: the (split-phase) apply and the interface sum of its output in one call; `halo` is a
+        halo.RcclHalo or a raw CeedXHalo handle."""
+        self.L.chk(self.L.lib.CeedXOperatorApplyWithHalo(self.h, vin.h, vout.h, getattr(halo, "h", halo)))
 
     def destroy(self):
         if self.h:

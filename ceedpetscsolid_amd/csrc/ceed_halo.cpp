@@ -1,0 +1,211 @@
+// ceed_halo.cpp -- the interface sum between element partitions over RCCL (CeedXComm*, CeedXHalo*): the library's
+// replacement of DMLocalToGlobal(ADD_VALUES) + DMGlobalToLocal across the GPUs of one node (src/matops.c:33,57,126,153,
+// 171,199,238) and of the MPI reductions behind VecDot / VecNorm (CeedXCommAllReduce).
+//
+// RCCL is bound at first use with dlopen: a C host gets /opt/rocm's librccl, a Python host the copy torch has already
+// loaded (one RCCL per process, like the HIP runtime: see ceed.py).  No link-time dependency for single-GPU users.
+#include <dlfcn.h>
+
+#include "ceed_impl.hpp"
+
+using namespace cps;
+
+extern int (*g_rccl_comm_destroy)(void *);   // ceed_core.cpp: the Ceed's destructor ends its communicator through this
+
+namespace {
+typedef struct { char internal[128]; } rccl_unique_id;
+struct Rccl {
+  void *h = nullptr;
+  int (*GetUniqueId)(rccl_unique_id *) = nullptr;
+  int (*CommInitRank)(void **, int, rccl_unique_id, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+const int RCCL_FLOAT64 = 8;   // ncclFloat64 (rccl.h)
+const int RCCL_SUM = 0;       // ncclSum
+int rccl_load() {
+  if (g_rccl.h) return 0;
+  const char *names[] = {"librccl.so.1", "librccl.so"};
+  for (int pass = 0; pass < 2 && !g_rccl.h; pass++)      // an already loaded copy first (RTLD_NOLOAD)
+    for (const char *n : names)
+      if (!g_rccl.h) g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+  if (!g_rccl.h) return ceed_error("the halo exchange needs RCCL (librccl.so.1): %s", dlerror());
+  auto sym = [](const char *n) { return dlsym(g_rccl.h, n); };
+  g_rccl.GetUniqueId = (int (*)(rccl_unique_id *))sym("ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void **, int, rccl_unique_id, int))sym("ncclCommInitRank");
+  g_rccl.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
+  g_rccl_comm_destroy = g_rccl.CommDestroy;
+  g_rccl.GroupStart = (int (*)())sym("ncclGroupStart");
+  g_rccl.GroupEnd = (int (*)())sym("ncclGroupEnd");
+  g_rccl.Send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))sym("ncclSend");
+  g_rccl.Recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))sym("ncclRecv");
+  g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))sym("ncclAllReduce");
+  g_rccl.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Send ||
+      !g_rccl.Recv || !g_rccl.AllReduce || !g_rccl.GetErrorString) { g_rccl.h = nullptr; return ceed_error("librccl lacks a point-to-point entry point"); }
+  return 0;
+}
+}  // namespace
+#define RCCLCHK(x) do { int r_ = (x); if (r_ != 0) return ceed_error("%s failed: %s", #x, g_rccl.GetErrorString(r_)); } while (0)
+
+extern "C" int CeedXCommGetUniqueId(Ceed, char id[128]) {
+  CHK(rccl_load());
+  rccl_unique_id u;
+  RCCLCHK(g_rccl.GetUniqueId(&u));
+  memcpy(id, u.internal, 128);
+  return 0;
+}
+extern "C" int CeedXCommInit(Ceed ceed, int nranks, int rank, const char id[128]) {
+  if (ceed->comm) return ceed_error("this Ceed already has a communicator");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return ceed_error("CeedXCommInit: rank %d of %d", rank, nranks);
+  CHK(rccl_load());
+  rccl_unique_id u;
+  memcpy(u.internal, id, 128);
+  HIPCHK(hipSetDevice(ceed->device));   // (the calling thread's current device may not be the Ceed's)
+  RCCLCHK(g_rccl.CommInitRank(&ceed->comm, nranks, u, rank));
+  ceed->comm_rank = rank; ceed->comm_size = nranks;
+  if (!ceed->comm_stream) {
+    // The exchange's kernels are queued while the fused kernel's waves hold the chip: on a stream of the HIGHEST priority
+    // its workgroups are placed first whenever a slot frees (CEED_MI355X_COMM_PRIO=0: default priority, A/B).
+    int lo = 0, hi = 0;
+    if (ceed->opt.comm_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+      HIPCHK(hipStreamCreateWithPriority(&ceed->comm_stream, hipStreamNonBlocking, hi));
+    else HIPCHK(hipStreamCreateWithFlags(&ceed->comm_stream, hipStreamNonBlocking));
+  }
+  return 0;
+}
+extern "C" int CeedXCommDestroy(Ceed ceed) {
+  if (ceed->comm) { (void)hipStreamSynchronize(ceed->comm_stream); (void)g_rccl.CommDestroy(ceed->comm); ceed->comm = nullptr; }
+  return 0;
+}
+// Sum of `n` entries of a device vector over all ranks, in place, on the Ceed's stream (the MPI_Allreduce behind VecDot /
+// VecNorm, src/matops.c:292 and the Krylov norms): the scalars of a recurrence stay on the device.  One rank: nothing.
+extern "C" int CeedXCommAllReduce(Ceed ceed, CeedVector v, CeedInt first, CeedInt n) {
+  if (first < 0 || n < 0 || first + n > v->length) return ceed_error("CeedXCommAllReduce: entries [%d, %d) of %d", first, first + n, v->length);
+  if (!ceed->comm || ceed->comm_size == 1 || n == 0) return 0;
+  double *p;
+  CHK(vec_dev(v, true, &p));
+  RCCLCHK(g_rccl.AllReduce(p + first, p + first, (size_t)n, RCCL_FLOAT64, RCCL_SUM, ceed->comm, ceed->stream));
+  return 0;
+}
+
+static void halo_free(CeedXHalo H) {
+  if (H->d_idx) (void)hipFree(H->d_idx);
+  if (H->send) (void)hipFree(H->send);
+  if (H->recv) (void)hipFree(H->recv);
+  for (uint32_t *p : {H->d_dst, H->d_uptr, H->d_uslot}) if (p) (void)hipFree(p);
+  if (H->packed) (void)hipEventDestroy(H->packed);
+  if (H->arrived) (void)hipEventDestroy(H->arrived);
+  ceed_unref(H->ceed);
+  delete H;
+}
+static int halo_build(CeedXHalo H, CeedInt nneigh, const int *neigh_rank, const CeedInt *count, const CeedInt *const *index) {
+  Ceed ceed = H->ceed;
+  std::vector<uint32_t> idx;
+  for (int k = 0; k < nneigh; k++) {
+    if (neigh_rank[k] < 0 || neigh_rank[k] >= ceed->comm_size || count[k] < 0) return ceed_error("CeedXHaloCreate: bad neighbour %d", k);
+    HaloNeighbour nb;
+    nb.rank = neigh_rank[k]; nb.n = count[k]; nb.offset = (int)idx.size();
+    for (int i = 0; i < nb.n; i++) {
+      if (index[k][i] < 0) return ceed_error("CeedXHaloCreate: negative index");
+      idx.push_back((uint32_t)index[k][i]);
+      H->lsize_min = std::max(H->lsize_min, index[k][i] + 1);
+    }
+    H->nb.push_back(nb);
+  }
+  H->total = (int)idx.size();
+  // arrivals by destination entry, each entry's slots in neighbour-list order (slots ascend with the neighbour)
+  std::vector<uint32_t> order(idx.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return idx[a] < idx[b]; });
+  std::vector<uint32_t> dst, uptr(1, 0u), uslot;
+  for (size_t i = 0; i < order.size(); i++) {
+    if (i == 0 || idx[order[i]] != idx[order[i - 1]]) { if (i) uptr.push_back((uint32_t)uslot.size()); dst.push_back(idx[order[i]]); }
+    uslot.push_back(order[i]);
+  }
+  uptr.push_back((uint32_t)uslot.size());
+  if (dst.empty()) uptr.assign(1, 0u);
+  H->ndst = (int)dst.size();
+  auto up = [](uint32_t **d, const std::vector<uint32_t> &v) -> int {
+    HIPCHK(hipMalloc((void **)d, sizeof(uint32_t) * (v.size() ? v.size() : 1)));
+    if (!v.empty()) HIPCHK(hipMemcpy(*d, v.data(), sizeof(uint32_t) * v.size(), hipMemcpyHostToDevice));
+    return 0;
+  };
+  CHK(up(&H->d_idx, idx)); CHK(up(&H->d_dst, dst)); CHK(up(&H->d_uptr, uptr)); CHK(up(&H->d_uslot, uslot));
+  HIPCHK(hipMalloc((void **)&H->send, sizeof(double) * (idx.size() ? idx.size() : 1)));
+  HIPCHK(hipMalloc((void **)&H->recv, sizeof(double) * (idx.size() ? idx.size() : 1)));
+  HIPCHK(hipEventCreateWithFlags(&H->packed, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&H->arrived, hipEventDisableTiming));
+  return 0;
+}
+// Neighbour lists: `index[k]` holds the `count[k]` L-vector entries shared with rank `neigh_rank[k]`, in an order both
+// sides agree on (halo.py sorts them by partition-independent node keys).  Entries are unique within one list.
+extern "C" int CeedXHaloCreate(Ceed ceed, CeedInt nneigh, const int *neigh_rank, const CeedInt *count,
+                               const CeedInt *const *index, CeedXHalo *halo) {
+  if (nneigh > 0 && !ceed->comm) return ceed_error("CeedXHaloCreate: call CeedXCommInit first");
+  CeedXHalo H = new CeedXHalo_private;
+  H->ceed = ceed; ceed_ref(ceed);
+  const int ierr = halo_build(H, nneigh, neigh_rank, count, index);
+  if (ierr) { halo_free(H); return ierr; }   // nothing of a half-built exchange survives an error return
+  *halo = H;
+  return 0;
+}
+// pack on `pack_stream` (the stream that produced y), then all sends and receives of this rank as ONE RCCL group on the
+// communicator's stream; H->arrived is recorded behind them.  Recordable into a hipGraph: the communicator's stream joins
+// the capture through the `packed` event and is joined back by whoever waits for `arrived`.
+int halo_pack_and_send(CeedXHalo H, const double *py, hipStream_t pack_stream) {
+  Ceed c = H->ceed;
+  HIPCHK(launch_halo_pack(H->d_idx, H->total, py, H->send, pack_stream));
+  HIPCHK(hipEventRecord(H->packed, pack_stream));
+  HIPCHK(hipStreamWaitEvent(c->comm_stream, H->packed, 0));
+  RCCLCHK(g_rccl.GroupStart());
+  for (HaloNeighbour &nb : H->nb) {
+    RCCLCHK(g_rccl.Send(H->send + nb.offset, (size_t)nb.n, RCCL_FLOAT64, nb.rank, c->comm, c->comm_stream));
+    RCCLCHK(g_rccl.Recv(H->recv + nb.offset, (size_t)nb.n, RCCL_FLOAT64, nb.rank, c->comm, c->comm_stream));
+  }
+  RCCLCHK(g_rccl.GroupEnd());
+  HIPCHK(hipEventRecord(H->arrived, c->comm_stream));
+  return 0;
+}
+HaloUnpackArgs halo_unpack_args(CeedXHalo H) { return HaloUnpackArgs{H->d_dst, H->d_uptr, H->d_uslot, H->recv, H->ndst}; }
+// Start: pack on the Ceed's stream, then the RCCL group on the communicator's stream -- the Ceed's stream is free for
+// the interior elements meanwhile (CeedXOperatorApplyPhase 1).
+extern "C" int CeedXHaloStart(CeedXHalo H, CeedVector y) {
+  if (H->in_flight) return ceed_error("CeedXHaloStart: an exchange is already in flight");
+  if (H->nb.empty()) return 0;
+  if (y->length < H->lsize_min) return ceed_error("CeedXHaloStart: vector shorter than the halo's indices");
+  double *py;
+  CHK(vec_dev(y, false, &py));
+  CHK(halo_pack_and_send(H, py, H->ceed->stream));
+  H->in_flight = true;
+  return 0;
+}
+// Finish: the Ceed's stream waits for the arrivals and adds them, per entry in neighbour-list order (a node shared by
+// three ranks gets its two additions in the same order every time: the sum is reproducible).
+extern "C" int CeedXHaloFinish(CeedXHalo H, CeedVector y) {
+  if (H->nb.empty()) return 0;
+  if (!H->in_flight) return ceed_error("CeedXHaloFinish without CeedXHaloStart");
+  Ceed c = H->ceed;
+  double *py;
+  CHK(vec_dev(y, true, &py));
+  HIPCHK(hipStreamWaitEvent(c->stream, H->arrived, 0));
+  HIPCHK(launch_halo_unpack_add(halo_unpack_args(H), py, c->stream));
+  H->in_flight = false;
+  return 0;
+}
+extern "C" int CeedXHaloDestroy(CeedXHalo *halo) {
+  if (!halo || !*halo) return 0;
+  CeedXHalo H = *halo;
+  (void)hipStreamSynchronize(H->ceed->stream);
+  if (H->ceed->side_stream) (void)hipStreamSynchronize(H->ceed->side_stream);
+  if (H->ceed->comm_stream) (void)hipStreamSynchronize(H->ceed->comm_stream);
+  halo_free(H);
+  *halo = nullptr;
+  return 0;
+}

@@ -1,10 +1,10 @@
-// kernel_fused_pencil.hpp -- second-generation fused operator kernel: PENCIL PER LANE.
+// kernel_fused_pencil.hpp -- the fused operator kernel: PENCIL PER LANE.
 //
-// Same job as kernel_fused_grad.hpp (the whole CeedOperatorApply of the residual /
-// Jacobian operators, setuplibceed.c:517-542, :817-839, in one launch) with a different
-// mapping of the 1-D contractions onto the wave.
+// The whole CeedOperatorApply of the residual / Jacobian operators (setuplibceed.c:517-542, :817-839) in one launch:
+// gather, interp, grad, QFunction, grad^T, interp^T, element results to y / the shell E-vector.
 //
-// Why.  The row kernel gives every lane one OUTPUT point of a contraction, so the Q lanes
+// Why pencils.  The first-generation kernel of round 1 (one OUTPUT point of a contraction per lane; removed from the
+// tree in round 3, last present at commit 14cd5f8) gave every lane one output point, so the Q lanes
 // that share an input row each read the whole row from LDS (Q-fold redundant LDS reads) and
 // per-lane coefficient rows also come from LDS: ~71 % LDS-pipe busy, LDS bound.  Here a lane
 // owns a whole PENCIL (one line of the element along the contraction direction, one
@@ -220,23 +220,18 @@ CPS_DEV void pencil_pass(ktab_t table, const ldsp_t (&addr)[R], int lane, int nt
 #ifndef CPS_PENCIL_NSET
 #define CPS_PENCIL_NSET 2   // q-point register sets: 2 = every round's data is requested two rounds ahead
 #endif                      // (198 VGPRs with the hyperFS tangent; 1 set: 4-6 % slower; 3 sets: no gain)
-#ifndef CPS_PENCIL_MINW5
-#define CPS_PENCIL_MINW5 CPS_PENCIL_MINW   // tuning hook: Q = 5 only
-#endif
-constexpr int pencil_minw(int Q) { return Q == 5 ? CPS_PENCIL_MINW5 : CPS_PENCIL_MINW; }
+constexpr int pencil_minw(int) { return CPS_PENCIL_MINW; }
 #ifndef CPS_PENCIL_NSET_BIGQ
 #define CPS_PENCIL_NSET_BIGQ 1   // Q >= 6: the split-table passes keep all rounds' pencils in VGPRs; a second q-point set
 #endif                           // would push the hyperFS tangent past 256 VGPRs (26 spilled to scratch)
-// FOLD: the folded assembly (FusedGradArgs::as_rowptr) is compiled in -- an instantiation of its own (GEO and EO forms only),
-// so that the default kernel keeps its 203 registers (249 with the stages).
-template <int P, int Q, int QF, bool GEO, bool EO, bool FOLD = false>
-#ifndef CPS_WG4
-#define CPS_WG4 0   // experiment (tools/variants): 256-thread workgroups of four waves, two barriers per group (timing of the lockstep)
-#endif
-__global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pencil(const BasisTables tab_, const FusedGradArgs a) {
+// GEO: the geometric factors are recomputed per point from the element's trilinear map (FusedGradArgs::geo) instead of read.
+// The 1-D tables are applied in even-odd form wherever that form exists (pencil_even_odd(Q): 4 <= Q <= 7).
+template <int P, int Q, int QF, bool GEO>
+__global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const BasisTables tab_, const FusedGradArgs a) {
   static_assert(offsetof(BasisTables, interp) == 0 && offsetof(BasisTables, colo) == 8 * MAXN1D * MAXN1D &&
                 offsetof(BasisTables, grad) == 16 * MAXN1D * MAXN1D, "kernarg layout of the tables");
   (void)tab_;  // first kernel argument: lives at offset 0 of the kernarg segment, read through kt below
+  constexpr bool EO = pencil_even_odd(Q);
   const ktab_t kt = (ktab_t)__builtin_amdgcn_kernarg_segment_ptr();
   const ktab_t ktB = kt, ktD = kt + MAXN1D * MAXN1D, ktG = kt + 2 * MAXN1D * MAXN1D;
   // the six products' tables: plain (B, D, G read forward or transposed) or their even-odd forms (FusedGradArgs::eo)
@@ -249,18 +244,14 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
   constexpr int BI = 8, BJ = 8 * SJ, BK = 8 * SK, BC = 8 * SC;        // byte strides
   constexpr int oA = 0, oBX = 8 * G::ARR, oBZ = 16 * G::ARR;         // byte offsets of the arrays
   constexpr bool ST_IN = QFTraits<QF>::state_in, ST_OUT = QFTraits<QF>::state_out;
-#ifdef CPS_QPAD   // experiment (tools/variants, TIMING ONLY): stored-state runs padded to whole 128-byte lines
-  constexpr int QS = (Q3 + 15) / 16 * 16;
-#else
   constexpr int QS = Q3;
-#endif
   static_assert(P <= Q, "interpolation to at least as many points as nodes");
   // re-read the launch arguments at every use (kargs_fresh) where that frees the SGPR file of spills: Q <= 5.  At
   // Q >= 6 one coefficient table alone (2 Q^2 SGPRs) overflows it and the extra scalar-load waits only cost (measured).
   constexpr bool KA = Q <= 5;
 
-  __shared__ __attribute__((aligned(16))) double slab[(CPS_WG4 ? 4 : 1) * (E * SE + G::GEO)];
-  const ldsp_t lds0 = (lds_double *)slab + (CPS_WG4 ? (threadIdx.x >> 6) * (E * SE + G::GEO) : 0);
+  __shared__ __attribute__((aligned(16))) double slab[E * SE + G::GEO];
+  const ldsp_t lds0 = (lds_double *)slab;
   constexpr bool geo = GEO;   // recompute the geometric factors per point instead of reading qdata (FusedGradArgs::geo set)
   const int lane = threadIdx.x & 63;
 #ifndef CPS_NO_STAGGER
@@ -273,211 +264,18 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
   if ((a.nelem + E - 1) / E >= 4 * (int)gridDim.x)
     for (int i = 0; i < (int)((blockIdx.x * 2654435761u) >> 28) * 2; i++) __builtin_amdgcn_s_sleep(8);
 #endif
-#ifdef CPS_SETPRIO   // experiment (tools/variants): static priority for every other workgroup of an XCD (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-  if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(CPS_SETPRIO);
-#endif
 
   // ---- work list of this wave -----------------------------------------------------------------------
-  // The groups are cut into 8 contiguous chunks, one per XCD (neighbouring elements share their nodes through one L2).
-  // Static schedule (a.queue == null): block b serves chunk b % 8 (blocks b and b + 8 share an XCD under the round-robin
-  // placement), group = chunk begin + wave rank + k * waves per chunk.  Dynamic schedule (a.queue): the wave reads the XCD
-  // it really runs on (HW_REG_XCC_ID) and takes that chunk's groups in order from a ticket counter (one returning
-  // atomic per group, issued a whole group ahead of its use); a wave whose chunk has run dry goes on with the
-  // following chunks (work stealing, tail balance), so every group is taken whatever the placement.
+  // The groups are cut into 8 contiguous chunks, one per XCD (neighbouring elements share their nodes through one L2):
+  // block b serves chunk b % 8 (blocks b and b + 8 share an XCD under the round-robin placement), group = chunk begin +
+  // wave rank + k * waves per chunk.  (A dynamic per-XCD ticket schedule was built and measured in round 2: not faster on
+  // large launches, slower on small ones; removed in round 3.)
   const int ngroups = (a.nelem + E - 1) / E;
-  const bool dyn = a.queue != nullptr;
-  const int vblock = CPS_WG4 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : (int)blockIdx.x, vgrid = CPS_WG4 ? (int)gridDim.x * 4 : (int)gridDim.x;
-  const int nxcd = (dyn || gridDim.x % 8 == 0) ? 8 : 1;
-  // (CPS_WG4: the four waves of a workgroup take four CONSECUTIVE groups of the workgroup's chunk -- one block of 8 elements)
-  const int wrank = CPS_WG4 ? (int)(blockIdx.x / nxcd) * 4 + (int)(threadIdx.x >> 6) : vblock / nxcd, wper = vgrid / nxcd;
-  const int gend = dyn ? 0 : min(ngroups, (int)(blockIdx.x % nxcd + 1) * ((ngroups + nxcd - 1) / nxcd));   // static schedule only
-  // dynamic schedule: all the wave keeps is  home XCD | chunk it takes from << 4 | chunks it has moved on << 8  (everything
-  // else is re-derived from the launch arguments where it is used: the scalar register file is full, see the table passes)
-  int xs = 0;
-  if (dyn) { xs = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); xs |= xs << 4; }   // hwreg(HW_REG_XCC_ID, 0, 4)
-  auto chunk_groups = [&]() { return (((kargs_fresh<true>()->nelem + E - 1) / E) + 7) >> 3; };   // groups per chunk (uniform)
-  // next group of this wave, or -1: `n` tickets (1 or 2) of the current chunk; when that chunk has run dry, ONE load looks
-  // at all eight ticket counters (lane l reads chunk l's) and the wave moves on to the next chunk that still has groups --
-  // or leaves: a wave at the end of a launch costs one atomic and one load, not a round of eight returning atomics
-  // (which made every SMALL launch ~10 us longer: config 3's 16 000 applies of 50 us).
-  auto take = [&](int n, int &second) -> int {
-    second = -1;
-#pragma unroll 1
-    for (int tries = 0; tries < 10; tries++) {
-      const kargs_t ka = kargs_fresh<true>();
-      const int ng = (ka->nelem + E - 1) / E, ch = (ng + 7) >> 3, x = (xs >> 4) & 7;
-      unsigned t = 0;
-      if (lane == 0) t = atomicAdd(ka->queue + x * QUEUE_STRIDE, (unsigned)n);
-      const int g = x * ch + (int)__builtin_amdgcn_readfirstlane(t), gend_x = min(ng, (x + 1) * ch);
-      if (g < gend_x) {
-        if (n == 2 && g + 1 < gend_x) second = g + 1;
-        return g;
-      }
-      // this chunk is exhausted: which chunks still have groups?
-      const unsigned hv = lane < 8 ? __hip_atomic_load(ka->queue + lane * QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      const unsigned left = (unsigned)(__ballot(lane < 8 && (int)hv < min(ng, (lane + 1) * ch) - lane * ch) & 0xFFull);
-      if (!left) return -1;
-      const unsigned rot = ((left >> (x + 1)) | (left << (7 - x))) & 0xFFu;   // bit i: chunk (x + 1 + i) % 8 has groups left
-      const int nx = (x + 1 + __builtin_ctz(rot)) & 7;
-      xs = (xs & 15) | (nx << 4) | (((xs >> 8) + 1) << 8);
-    }
-    return -1;
-  };
-  // Completion signal of the gated / folded assembly (FusedGradArgs::done): one add to the counter of group g's bucket -- in
-  // its upper half if the group was taken from another XCD's chunk -- once the group's stores have been acknowledged
-  // (s_waitcnt vmcnt(0): L1 is write-through, the acknowledgement comes from the XCD's L2).  Issued for the PREVIOUS group
-  // just before the physics of the current one, where every older memory operation has landed anyway (the physics needs
-  // the prefetched state), so the wait costs nothing; once more after the loop.
-  // (compiled in up to Q = 5: from Q = 6 the passes keep all rounds' pencils in registers and the stages' 40 would spill)
-  const bool fold = FOLD && Q <= 5 && dyn && a.as_rowptr != nullptr;
-  auto bucket_size = [&](int c, int b) {   // groups in bucket b of chunk c
-    const kargs_t ka = kargs_fresh<true>();
-    const int ng = (ka->nelem + E - 1) / E, ch = (ng + 7) >> 3, cg = max(0, min(ng - c * ch, ch));
-    return max(0, min(1 << ka->bucket_shift, cg - (b << ka->bucket_shift)));
-  };
-  // sig_idx (out): index of the counter that was bumped, -1 none; sig_old (out, lane 0): its value before (folded assembly)
-  auto signal_done = [&](int g, int &sig_idx, unsigned &sig_old) {
-    const kargs_t ka = kargs_fresh<true>();
-    unsigned *dn = ka->done;
-    sig_idx = -1;
-    if (dn && g >= 0) {
-      const int ch = chunk_groups();
-      int c = 0;
-#pragma unroll
-      for (int i = 1; i < 8; i++) c += (g >= i * ch) ? 1 : 0;
-      const int sig = c * ka->nb + ((g - c * ch) >> ka->bucket_shift);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (fold) {
-        if (lane == 0) sig_old = atomicAdd(dn + sig, c == (xs & 15) ? 1u : GatedCtrl::FOREIGN);
-        sig_idx = sig;
-      } else if (lane == 0) atomicAdd(dn + sig, c == (xs & 15) ? 1u : GatedCtrl::FOREIGN);
-    }
-  };
-  // Folded assembly: the frontier of chunk c (buckets [0, f) complete and run by the chunk's own XCD) is moved by the wave
-  // whose signal completed a bucket; 64 buckets are probed at once, one per lane.  READY = items that may be summed; its
-  // top bit says that the frontier has met a bucket with foreign groups and will not move again.
-  auto advance_frontier = [&](int sig_idx, unsigned sig_old) {
-    if (sig_idx < 0) return;
-    const kargs_t ka = kargs_fresh<true>();
-    const int nb = ka->nb, c = sig_idx / nb, b = sig_idx - c * nb;
-    const unsigned old = (unsigned)__builtin_amdgcn_readfirstlane(sig_old);
-    // total arrivals (own + foreign) of the bucket after this wave's add
-    if ((int)((old & 0xFFFFu) + (old >> 16)) + 1 != bucket_size(c, b)) return;
-    unsigned *ctrl = ka->queue;
-    unsigned f = (unsigned)__builtin_amdgcn_readfirstlane(__hip_atomic_load(ctrl + GatedCtrl::FRONT + c * QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const unsigned f0 = f;
-    bool stop = false;
-#pragma unroll 1
-    for (int it = 0; it < 8 && f < (unsigned)nb; it++) {
-      const unsigned fb = f + (unsigned)lane;
-      const bool in = fb < (unsigned)nb;
-      const unsigned d = in ? __hip_atomic_load(ka->done + c * nb + fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      const int bs = bucket_size(c, in ? (int)fb : 0);
-      const unsigned long long clean = __ballot(in && d == (unsigned)bs);
-      const unsigned long long dirty = __ballot(in && d >= GatedCtrl::FOREIGN && (int)((d & 0xFFFFu) + (d >> 16)) == bs);
-      const int run = clean == ~0ull ? 64 : __builtin_ctzll(~clean);
-      f += (unsigned)run;
-      if (run < 64) { stop = (dirty >> run) & 1ull; break; }
-    }
-    if (lane == 0) {
-      if (f > f0) {
-        atomicMax(ctrl + GatedCtrl::FRONT + c * QUEUE_STRIDE, f);
-        atomicMax(ctrl + GatedCtrl::READY + c * QUEUE_STRIDE, ka->as_bucket_items[c * nb + (int)f - 1]);
-      }
-      if (stop) atomicOr(ctrl + GatedCtrl::READY + c * QUEUE_STRIDE, GatedCtrl::STOP);
-    }
-  };
-  // ---- folded assembly: one item of the home chunk per element group, in four stages -----------------------------------
-  // Carried from group to group: as_item and the ticket register only.  The rows' registers (FoldRows) live inside ONE
-  // group's iteration -- row pointers across the physics (8 VGPRs), columns and values only behind it.
-  constexpr int AR = GATED_ITEM_ROWS / 64;   // rows per lane
-  struct FoldRows { bool go; unsigned rdy; uint32_t r0, r1, k0[AR], k1[AR], no[AR], cc[AR][4], fl[AR]; double v[AR][4][3]; };
-  int as_item = -1;          // item (index within the home chunk) this wave holds; -1 none, -2 the chunk has no more, -3 ticket requested
-  unsigned as_tkv = 0;       // lane 0: the requested ticket
-  auto as_request = [&]() {   // next item's ticket (returns under other work)
-    if (lane == 0) as_tkv = atomicAdd(kargs_fresh<true>()->queue + GatedCtrl::AHEAD + (xs & 15) * QUEUE_STRIDE, 1u);
-    as_item = -3;
-  };
-  auto as_take = [&]() {   // read a requested ticket
-    if (as_item == -3) {
-      const kargs_t ka = kargs_fresh<true>();
-      const int h = xs & 15;
-      as_item = (int)__builtin_amdgcn_readfirstlane(as_tkv);
-      if (as_item >= ka->as_item_begin[h + 1] - ka->as_item_begin[h]) as_item = -2;
-    }
-  };
-  auto as_stage0 = [&](FoldRows &fr) {   // top of a group: the item's row range and the READY word are requested
-    fr.go = false;
-    if (!fold) return;
-    as_take();
-    const kargs_t ka = kargs_fresh<true>();
-    const int h = xs & 15;
-    const uint32_t *ir = ka->as_item_row + ka->as_item_begin[h] + max(as_item, 0);
-    fr.r0 = ir[0]; fr.r1 = ir[1];
-    fr.rdy = __hip_atomic_load(ka->queue + GatedCtrl::READY + h * QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  // Stages 1-4 are BRANCH-FREE: when the wave has no ready item they run all the same on row 0 with every lane inactive
-  // (a handful of loads that hit in cache, no stores).  Loads behind a wave-uniform branch would leave the number of
-  // outstanding memory operations unknown at the join, and the compiler's counted s_waitcnt of the prefetch pipeline
-  // (q-point refills, next group's x) would turn into waits for everything: measured +13 % on the whole kernel.
-  auto as_stage1 = [&](FoldRows &fr, bool drain = false) {   // before the physics: is the item ready?  then row pointers, node offsets, flags
-    const kargs_t ka = kargs_fresh<true>();
-    const unsigned rdy = (unsigned)__builtin_amdgcn_readfirstlane(fr.rdy) & ~GatedCtrl::STOP;
-    fr.go = fold && as_item >= 0 && rdy > (unsigned)as_item && (drain || !(ka->as_dbg & 2));
-    const uint32_t r = fr.r0 + (uint32_t)lane;
-    const bool act = fr.go && r < fr.r1;
-    const uint32_t ri = act ? r : 0u;
-    fr.k0[0] = ka->as_rowptr[ri];
-    fr.k1[0] = ka->as_rowptr[ri + 1];
-    fr.no[0] = ka->as_node_off[ri];
-    fr.fl[0] = (uint32_t)ka->as_flags[ri] | (act ? 0u : 0x100u);   // bit 8: inactive lane
-  };
-  auto as_stage2 = [&](FoldRows &fr) {   // after the physics: the (up to four) contributors' columns
-    const uint32_t *cols = kargs_fresh<true>()->as_cols;
-    const uint32_t last = max(fr.k1[0], fr.k0[0] + 1u) - 1u;
-#pragma unroll
-    for (int m = 0; m < 4; m++) fr.cc[0][m] = cols[min(fr.k0[0] + (uint32_t)m, last)];
-  };
-  auto as_stage3 = [&](FoldRows &fr) {   // after the k-transpose: their values (plain loads: see assemble_row in kernels_misc.hip)
-    const double *ev = kargs_fresh<true>()->evec;
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-      const double *p = ev + fr.cc[0][m];
-#pragma unroll
-      for (int d = 0; d < 3; d++) fr.v[0][m][d] = p[d];
-    }
-  };
-  auto as_stage4 = [&](FoldRows &fr) {   // after the group's own stores: sums in contributor (= element) order, y
-    const kargs_t ka = kargs_fresh<true>();
-    double s0 = 0., s1 = 0., s2 = 0.;
-#pragma unroll
-    for (int m = 0; m < 4; m++) {   // rows of an item have at most four contributors (the others are k_assemble_tail's)
-      const bool in = fr.k0[0] + (uint32_t)m < fr.k1[0];
-      s0 += in ? fr.v[0][m][0] : 0.; s1 += in ? fr.v[0][m][1] : 0.; s2 += in ? fr.v[0][m][2] : 0.;
-    }
-    if (!(fr.fl[0] & 0x100u)) {
-      double *dst = ka->y + (fr.no[0] & OFF_MASK);
-      dst[0] = (fr.fl[0] & 1u) ? 0. : s0; dst[1] = (fr.fl[0] & 2u) ? 0. : s1; dst[2] = (fr.fl[0] & 4u) ? 0. : s2;
-    }
-    if (fr.go) {
-      if (lane == 0) (ka->queue + GatedCtrl::item_done(ka->nb))[ka->as_item_begin[xs & 15] + as_item] = 1u;
-      as_request();
-    }
-  };
-  int grp, g_q1 = -1, g_prev = -1;   // current group; dynamic: the group after it (taken one group ahead), the one before it
-  if (dyn) {
-    int dummy;
-    grp = take(1, dummy);
-    if (grp < 0) return;
-    // The second ticket (the group whose data this wave prefetches) only after every wave of the launch has had the time
-    // to take its FIRST one (a 2 048-block grid starts within ~1.2 us): taken back to back, the early waves held two
-    // groups each and half the grid found none -- a launch of about as many groups as waves took twice as long
-    // (54 instead of 26 us at 2 200 groups).
-    __builtin_amdgcn_s_sleep(48);
-    g_q1 = take(1, dummy);
-  }
-  else { grp = (int)(blockIdx.x % nxcd) * ((ngroups + nxcd - 1) / nxcd) + wrank; if (grp >= gend) return; }
-  if (fold) as_request();
+  const int nxcd = gridDim.x % 8 == 0 ? 8 : 1;
+  const int wrank = (int)blockIdx.x / nxcd, wper = (int)gridDim.x / nxcd;
+  const int gend = min(ngroups, (int)(blockIdx.x % nxcd + 1) * ((ngroups + nxcd - 1) / nxcd));
+  int grp = (int)(blockIdx.x % nxcd) * ((ngroups + nxcd - 1) / nxcd) + wrank;
+  if (grp >= gend) return;
 
   // ---- loop-invariant lane -> work maps -----------------------------------------------------
   // pencil passes: task t = lane + 64 r over (element, component, b, a), a fastest; address of the
@@ -530,7 +328,7 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
     const int t = lane + 64 * r, el = t / P3, n = t % P3;
     aNd[r] = lds0 + (el * SE + (n / (P * P)) * SK + ((n / P) % P) * SJ + n % P);
     if (a.direct && node_is_element_interior(n, P)) nd_interior |= 1u << r;
-    // [element][shell rank or node][3], the element blocks a.evec_stride doubles apart (whole cache lines for the gated assembly)
+    // [element][shell rank or node][3], the element blocks a.evec_stride doubles apart
     ev_idx[r / 2] |= (uint32_t)(min(el, E - 1) * a.evec_stride + (a.direct ? node_shell_rank(n, P) : n) * 3) << (16 * (r % 2));
   }
   // element-in-group of owner slot t, recomputed where needed (a few compares) instead of held in
@@ -542,7 +340,7 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
     return el;
   };
 
-  // ---- global-memory side: clamped, unconditional loads (as in the row kernel) ------------------
+  // ---- global-memory side: clamped, unconditional loads ------------------------------------------
   // Addressing: a wave-uniform 64-bit base per group (SGPRs) plus a 32-bit per-lane index inside the
   // group's block.  Lanes of a dead element (only in the last, partial group) read the group's last
   // live element instead.
@@ -556,11 +354,6 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
     const size_t e0 = (size_t)(ka->elem_begin + g * E);
     const double *qb = ka->qdata + e0 * (10 * Q3);
     const uint32_t vo = (uint32_t)(el * (10 * Q3) + q);
-#ifdef CPS_ABLATE_QDATA  // timing-only build: no q-point stream (WRONG results)
-    for (int c = 0; c < 10; c++) qdv[c] = (c == 1 || c == 5 || c == 9 || c == 0) ? 1.0 + 1e-3 * q : 1e-3 * c;
-    for (int c = 0; c < 9; c++) stv[c] = 1e-3 * (c + lane);
-    return;
-#endif
     if (!geo) {
 #pragma unroll
       for (int c = 0; c < 10; c++) qdv[c] = (qb + c * Q3)[vo];
@@ -586,10 +379,9 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
   auto load_x = [&](const uint32_t *o, double (*xv)[3]) {
     const kargs_t kx = kargs_fresh<KA>();
     const double *xb = kx->x;
-    const uint32_t omask = kx->pairs ? PAIR_OFF_MASK : OFF_MASK;   // (pair merge: two more flag bits ride in the offsets)
 #pragma unroll
     for (int r = 0; r < RN; r++) {
-      const uint32_t base = o[r] & omask;
+      const uint32_t base = o[r] & OFF_MASK;
 #pragma unroll
       for (int c = 0; c < 3; c++) xv[r][c] = xb[base + c];
     }
@@ -603,19 +395,9 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
   for (int t = 0; t < NSET; t++) load_point(qd[t], st[t], grp, t);
 
   for (;;) {
-    const int grp_nx = dyn ? g_q1 : grp + wper;
-    const bool more = dyn ? grp_nx >= 0 : grp_nx < gend;  // wave-uniform
+    const int grp_nx = grp + wper;
+    const bool more = grp_nx < gend;  // wave-uniform
     const int g_nx = more ? grp_nx : grp;
-    if (dyn && more) { int dummy; g_q1 = take(1, dummy); }   // the group after the next: its ticket returns under this group's work
-    FoldRows fr;        // (this iteration only)
-    int sig_idx = -1;   // the completion counter bumped in this iteration, its value before (lane 0)
-    unsigned sig_old = 0;
-    as_stage0(fr);
-    uint32_t pair_e = 0xFFFFu;   // this group's pair entry of this lane (used after the last pass)
-    if constexpr (E == 2) {
-      const kargs_t kp = kargs_fresh<KA>();
-      if (kp->pairs && lane < PAIR_MAX) pair_e = (kp->pairs + (size_t)grp * PAIR_MAX)[lane]   /* whole applies only: elem_begin == 0 */;
-    }
     load_offsets(g_nx, off_nx);
     constexpr int RG = (E * GEO_NCOEF + 63) / 64;
     double gcoef[RG];    // this group's element-map coefficients, lane + 64 i; into LDS right before the physics
@@ -644,7 +426,6 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
       }
     }
 
-#ifndef CPS_ABLATE_PASSES  // (CPS_ABLATE_*: timing-only diagnostic builds for tools/ablate_run.sh, WRONG results, never shipped)
     // ---- B: nodes -> points, in place -----------------------------------------------------------------
     pencil_pass<P, Q, P, false, BI, oA, oA, +1, EO>(tBf, aIP, lane, E * T_IP);   // F1: along i at nodal (j, k)
     pencil_pass<P, Q, P, false, BJ, oA, oA, +1, EO>(tBf, aJP, lane, E * T_JP);   // F2: along j at (i', nodal k)
@@ -692,7 +473,6 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
     // ---- collocated gradient on the quadrature points -----------------------------------------------------
     pencil_pass<Q, Q, Q, false, BI, oA, oBX, -1, EO>(tDf, aIQ, lane, E * T_IQ);  // F4: d/dx: A -> BX
     pencil_pass<Q, Q, Q, false, BJ, oA, oA, -1, EO>(tDf, aJQ, lane, E * T_JQ);   // F5: d/dy: A -> A in place
-#endif
 
     if (geo) {
 #pragma unroll
@@ -700,8 +480,6 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
         if (lane + 64 * i < E * GEO_NCOEF)
           *(ldsp_t)((volatile __attribute__((address_space(3))) char *)lds0 + oGC + (lane + 64 * i) * 8) = gcoef[i];
     }
-    if (dyn) { signal_done(g_prev, sig_idx, sig_old); g_prev = -1; }
-    if (fold) as_stage1(fr);
     // ---- physics: point owners, one round at a time; ug[d*3+c] from (BX, A, BZ), dv back in place ----
 #pragma unroll
     for (int r = 0; r < RQ; r++) {
@@ -738,11 +516,7 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
         for (int c = 0; c < 10; c++) qdl[c] = qd[r % NSET][c];
       }
       if (live) {
-#ifdef CPS_ABLATE_QF
-        for (int c = 0; c < 9; c++) { dv[c] = ug[c] * qdl[c] + (ST_IN ? st[r % NSET][c] : qdl[9]); sto[c] = dv[c]; }
-#else
         qf_point<QF>(Phys{ka->nu, ka->E, ka->lambda, ka->TwoMu}, ug, qdl, st[r % NSET], dv, sto);
-#endif
         if constexpr (ST_OUT) {
           double *sb = ka->state_out + (size_t)(ka->elem_begin + grp * E) * (9 * QS);
           const uint32_t vs = (uint32_t)(pel * (9 * QS) + pq);
@@ -763,8 +537,6 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
       }
     }
 
-    if (fold) { advance_frontier(sig_idx, sig_old); as_stage2(fr); }
-#ifndef CPS_ABLATE_PASSES
     // ---- gradient^T --------------------------------------------------------------------------------------
     pencil_pass<Q, Q, Q, true, BI, oBX, oBX, -1, EO>(tDt, aIQ, lane, E * T_IQ);  // B1: W1 = Dx^T g0, BX in place
     {  // B2: W2 = W1 + Dy^T g1, A in place.  Two inputs per task: software-pipelined over the rounds
@@ -845,33 +617,13 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
       }
       }
     }
-#endif
-    if (fold) as_stage3(fr);
     load_x(off_nx, xin);  // next group's x (its offsets landed long ago): issued this late so its 6 RN registers
                           // are not live across the physics and the register-hungry passes; B4, B5, the
                           // final store and the next gather's address work hide most of its latency
     // ---- B^T: points -> nodes ---------------------------------------------------------------------------
-#ifndef CPS_ABLATE_PASSES
     pencil_pass<Q, P, P, true, BJ, oA, oA, +1, EO>(tBt, aJP, lane, E * T_JP);    // B4: along j
     pencil_pass<Q, P, P, true, BI, oA, oA, +1, EO>(tBt, aIP, lane, E * T_IP);    // B5: along i
-#endif
-#if CPS_WG4
-    __syncthreads();
-#endif
-    // ---- pair merge: the nodes the group's two elements share are summed in LDS (into the first element's slot) ------------
-    if constexpr (E == 2) {
-      if (kargs_fresh<KA>()->pairs) {
-        if (lane < PAIR_MAX && pair_e != 0xFFFFu) {
-          const int n0 = (int)(pair_e & 0xFFu), n1 = (int)(pair_e >> 8);
-          const ldsp_t a0 = lds0 + ((n0 / (P * P)) * SK + ((n0 / P) % P) * SJ + n0 % P);
-          const ldsp_t a1 = lds0 + (SE + (n1 / (P * P)) * SK + ((n1 / P) % P) * SJ + n1 % P);
-          const double s0 = lds_rd<oA + 0 * BC>(a0) + lds_rd<oA + 0 * BC>(a1), s1 = lds_rd<oA + 1 * BC>(a0) + lds_rd<oA + 1 * BC>(a1),
-                       s2 = lds_rd<oA + 2 * BC>(a0) + lds_rd<oA + 2 * BC>(a1);
-          lds_wr<oA + 0 * BC>(a0, s0); lds_wr<oA + 1 * BC>(a0, s1); lds_wr<oA + 2 * BC>(a0, s2);
-        }
-      }
-    }
-    // ---- final: node owners -> E-vector (plain coalesced stores) or f64 atomics ---------------------------
+    // ---- final: node owners -> y (element-interior nodes) / shell E-vector (plain coalesced stores) ------------------
     {
       double v[RN][3];
 #pragma unroll
@@ -882,73 +634,25 @@ __global__ __launch_bounds__(CPS_WG4 ? 256 : 64, pencil_minw(Q)) void k_fused_pe
       const kargs_t ka = kargs_fresh<KA>();
 #pragma unroll
       for (int r = 0; r < RN; r++) {
-        const int nel = el_of(lane + 64 * r, P3), nn = lane + 64 * r - nel * P3;
+        const int nel = el_of(lane + 64 * r, P3);
         if (pencil_ok(lane, r, E * P3) && grp * E + nel < ka->nelem) {
-          const bool paired = ka->pairs != nullptr;
-          if (paired && (off[r] & PAIR_SKIP)) continue;   // merged into the group's other element (pair merge)
-          const bool interior = ((nd_interior >> r) & 1u) || (paired && (off[r] & PAIR_DIRECT));
-          if (ka->evec && interior) {  // no contributor outside this wave: the node's final value goes straight to y
-            const uint32_t base = off[r] & (paired ? PAIR_OFF_MASK : OFF_MASK);
+          if ((nd_interior >> r) & 1u) {  // no contributor outside this wave: the node's final value goes straight to y
+            const uint32_t base = off[r] & OFF_MASK;
             const uint32_t fl = ka->mask_out ? (off[r] >> OFF_FLAG_SHIFT) : 0u;
             double *yb = ka->y;
             yb[base] = (fl & 1u) ? 0. : v[r][0]; (yb + 1)[base] = (fl & 2u) ? 0. : v[r][1]; (yb + 2)[base] = (fl & 4u) ? 0. : v[r][2];
-          }
-          if (ka->evec && !interior) {
+          } else {
             double *eb = ka->evec + (size_t)(ka->elem_begin + grp * E) * ka->evec_stride;
             const uint32_t ve = (r % 2) ? (ev_idx[r / 2] >> 16) : (ev_idx[r / 2] & 0xFFFFu);
-#ifndef CPS_ABLATE_STORE
             eb[ve] = v[r][0]; (eb + 1)[ve] = v[r][1]; (eb + 2)[ve] = v[r][2];
-#else
-            if (v[r][0] == 1.2345e-300) eb[ve] = v[r][1] + v[r][2];
-#endif
-          } else if (!ka->evec) {
-            const uint32_t base = off[r] & OFF_MASK;
-            const uint32_t fl = ka->mask_out ? (off[r] >> OFF_FLAG_SHIFT) : 0u;
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-              if (!((fl >> c) & 1u)) atomic_add_f64(ka->y + base + c, v[r][c]);
           }
         }
       }
     }
-#if CPS_WG4
-    __syncthreads();
-#endif
-    if (fold) as_stage4(fr);
-    g_prev = grp;
     if (!more) break;
     grp = grp_nx;
 #pragma unroll
     for (int r = 0; r < RN; r++) off[r] = off_nx[r];
-  }
-  {
-    int sig_idx = -1;
-    unsigned sig_old = 0;
-    if (dyn) signal_done(g_prev, sig_idx, sig_old);
-    if (fold) advance_frontier(sig_idx, sig_old);
-  }
-  if (fold && !(a.as_dbg & 1)) {
-    // ---- drain: the items of the home chunk that are still to be summed; READY is written by few and read here past L1.
-    // Every wait is bounded; what is given up here (frontier stopped by foreign groups, time-out) is k_assemble_tail's.
-    const int nit = a.as_item_begin[(xs & 15) + 1] - a.as_item_begin[xs & 15];
-#pragma unroll 1
-    for (int n = 0; n <= nit; n++) {
-      if (as_item == -1) as_request();
-      as_take();
-      if (as_item < 0) break;
-      bool ok = false;
-#pragma unroll 1
-      for (int spins = 0; spins <= a.as_max_spins; spins++) {
-        const unsigned r = (unsigned)__builtin_amdgcn_readfirstlane(__hip_atomic_load(a.queue + GatedCtrl::READY + (xs & 15) * QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if ((r & ~GatedCtrl::STOP) > (unsigned)as_item) { ok = true; break; }
-        if (r & GatedCtrl::STOP) break;
-        __builtin_amdgcn_s_sleep(64);
-      }
-      if (!ok) break;
-      FoldRows fr;
-      as_stage0(fr); fr.rdy = ~GatedCtrl::STOP;
-      as_stage1(fr, true); as_stage2(fr); as_stage3(fr); as_stage4(fr);
-    }
   }
 }
 
@@ -957,35 +661,25 @@ template <int P, int Q> constexpr int pencil_waves_per_cu() {
   return by_lds < 1 ? 1 : (by_lds > 4 * pencil_minw(Q) ? 4 * pencil_minw(Q) : by_lds);  // 8 waves per CU = 2 per SIMD at <= 256 VGPRs
 }
 
+// Launch shape.  Default: a PERSISTENT grid -- as many one-wave workgroups as the device holds at once (CUs x waves per
+// CU), each walking its strided list of groups with the next group's data requested a group ahead.  `a.wave_groups` > 0
+// (host-side hint, small launches): every wave is given at most that many groups instead and the grid grows accordingly
+// (rounded to whole XCD sets) -- workgroups beyond the resident set are dispatched as earlier ones retire, which balances
+// a launch of a few rounds and gives co-scheduled kernels (the halo exchange's) a slot at every retirement.
 template <int P, int Q, int QF>
 hipError_t launch_fused_pencil_t(const BasisTables &t, const FusedGradArgs &a, hipStream_t s) {
   using G = PencilGeom<P, Q>;
-  if (a.nelem <= 0) return hipSuccess;
+  if (a.nelem <= 0 && !a.query_waves) return hipSuccess;
   const int ngroups = (a.nelem + G::E - 1) / G::E;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-    ncu = prop.multiProcessorCount;
-  }
-  static int wpc = 0;  // tuning hook: CEED_MI355X_PENCIL_WAVES=<persistent waves per CU>
-  if (!wpc) { const char *e = getenv("CEED_MI355X_PENCIL_WAVES"); wpc = e && atoi(e) > 0 ? atoi(e) : -1; }
-  int grid = ncu * (wpc > 0 ? wpc : pencil_waves_per_cu<P, Q>());
-  if (a.query_waves) { *a.query_waves = CPS_WG4 ? (grid / 32) * 32 : grid; return hipSuccess; }
+  const int ncu = device_cu_count();
+  if (ncu <= 0) return hipErrorUnknown;
+  const int resident = ncu * (a.waves_per_cu > 0 ? a.waves_per_cu : pencil_waves_per_cu<P, Q>());
+  if (a.query_waves) { *a.query_waves = resident; return hipSuccess; }
+  int grid = resident;
+  if (a.wave_groups > 0) grid = ((ngroups + a.wave_groups - 1) / a.wave_groups + 7) / 8 * 8;
   if (grid > ngroups) grid = ngroups;
-  if (CPS_WG4) grid = (grid / 32) * 8;   // workgroups of four waves, a multiple of 8
-  if constexpr (Q <= 5) {
-    if (a.geo && a.eo_ok && a.as_rowptr) {
-      hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true, true, true>), dim3(grid), dim3(CPS_WG4 ? 256 : 64), 0, s, t, a);
-      return hipGetLastError();
-    }
-  }
-  // (a.as_rowptr set but no folded instantiation for this form: the kernel sums nothing and k_assemble_tail sums every item)
-  if (a.geo && a.eo_ok) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true, true>), dim3(grid), dim3(CPS_WG4 ? 256 : 64), 0, s, t, a);
-  else if (a.geo) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true, false>), dim3(grid), dim3(CPS_WG4 ? 256 : 64), 0, s, t, a);
-  else if (a.eo_ok) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, false, true>), dim3(grid), dim3(CPS_WG4 ? 256 : 64), 0, s, t, a);
-  else hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, false, false>), dim3(grid), dim3(CPS_WG4 ? 256 : 64), 0, s, t, a);
+  if (a.geo) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true>), dim3(grid), dim3(64), 0, s, t, a);
+  else hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, false>), dim3(grid), dim3(64), 0, s, t, a);
   return hipGetLastError();
 }
 

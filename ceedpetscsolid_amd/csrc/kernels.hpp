@@ -26,7 +26,6 @@ enum QFKind : int {
 };
 
 constexpr int MAXN1D = 8;  // largest P or Q supported by the kernel tables
-constexpr int QUEUE_STRIDE = 32;  // uints between the per-XCD ticket counters of the dynamic schedule (one 128-B line each)
 constexpr int EO_TAB = 36;  // doubles per even-odd table (see FusedGradArgs::eo)
 
 // 1-D tables handed to kernels by value: they live in the kernarg segment; the pencil kernel reads them from
@@ -43,69 +42,49 @@ struct BasisTables {
 // top bits (set by CeedXOperatorSetDirichletMask); plain offsets have none.
 constexpr uint32_t OFF_MASK = 0x1FFFFFFFu;
 constexpr int OFF_FLAG_SHIFT = 29;
-constexpr uint32_t PAIR_OFF_MASK = 0x07FFFFFFu, PAIR_SKIP = 1u << 27, PAIR_DIRECT = 1u << 28;   // FusedGradArgs::pairs
-constexpr int PAIR_MAX = 32;
+
+// Even-odd form of the 1-D products (FusedGradArgs::eo): used wherever the form exists -- the bases of this ABI are built
+// on Gauss / Gauss-Lobatto points (CeedBasisCreateTensorH1Lagrange), whose tables are centro-(anti)symmetric.  Below 4 x 4
+// the additions cost what the halved products save (measured -1.6 % at Q = 3); at Q = 8 an even-odd table (36
+// coefficients) no longer fits the 60 SGPRs a pass has for its table.
+constexpr bool pencil_even_odd(int Q) { return Q >= 4 && Q <= 7; }
 
 struct FusedGradArgs {
   const uint32_t *offsets;  // [nelem][P^3] (flagged)
   const double *x;          // active input L-vector, interlaced [node][3]
-  double *y;                // active output L-vector (pre-zeroed; atomically accumulated)
+  double *y;                // active output L-vector: element-interior nodes are stored here directly (direct)
   const double *qdata;      // [nelem][10][Q^3]
   const double *state_in;   // [nelem][9][Q^3] or null
   double *state_out;        // [nelem][9][Q^3] or null
   int nelem;                // elements processed by this launch ...
-  int elem_begin;           // ... starting at this element (split-phase apply)
+  int elem_begin;           // ... starting at this element (segments of a pipelined apply, split-phase apply)
   int mask_in, mask_out;    // honour the Dirichlet flags on gather / scatter
   double nu, E, lambda, TwoMu;
-  unsigned long long *stamps;  // diagnostic builds only (-DCPS_STAMPS): 8 s_memtime stamps per wave
-  double *evec;                // if set: element results go here ([elem][P^3][3], plain coalesced stores)
-                               // and launch_assemble() sums them into y; else f64 atomics straight into y
-  int evec_stride;            // doubles between the E-vector blocks of consecutive elements: 3 * nodes per block, or that
-                               // rounded up to whole 128-byte lines (gated assembly: a line then belongs to ONE element)
-  int variant;                // host-side dispatch only: 0 = row kernel (kernel_fused_grad.hpp),
-                               // 1 = pencil kernel (kernel_fused_pencil.hpp)
-  const double *geo;          // pencil kernel: if set, [nelem][GEO_NCOEF] trilinear-map coefficients of the elements
-                               // (launch_geo_coeffs); the kernel then RECOMPUTES qdata = SetupGeo(x) at every point
-                               // (27 FMAs + adjugate) instead of streaming its 80 bytes per point from HBM
+  double *evec;               // element results ([elem][shell node or node][3], plain coalesced stores); launch_assemble()
+                               // sums them into y per node in element order
+  int evec_stride;            // doubles between the E-vector blocks of consecutive elements: 3 * nodes per block
+  const double *geo;          // if set, [nelem][GEO_NCOEF] trilinear-map coefficients of the elements (launch_geo_coeffs);
+                               // the kernel then RECOMPUTES qdata = SetupGeo(x) at every point (27 FMAs + adjugate) instead
+                               // of streaming its 80 bytes per point from HBM
   double qref[MAXN1D], qwt[MAXN1D];  // 1-D quadrature points / weights of the geometry (used with geo)
-  // Even-odd form of the 1-D tables (pencil kernel, EO instantiation).  The tables of symmetric point sets are
+  // Even-odd form of the 1-D tables (pencil_even_odd(Q)).  The tables of symmetric point sets are
   // centro-symmetric (interp: M[N-1-i][K-1-j] = M[i][j]) or centro-antisymmetric (derivatives), so with
   // xe = x_j + x_{K-1-j}, xo = x_j - x_{K-1-j} an N x K product costs ~N K / 2 FMAs + N + K adds instead of N K FMAs.
   // eo[t]: t = 0 B, 1 B^T, 2 D, 3 D^T, 4 G, 5 G^T; per table Me[r][j] at r * (K/2) + j, Mo at 16 + r * (K/2) + j, the
-  // middle column at 32 + r (r < (N+1)/2, j < K/2); built and checked by the host (eo_ok).
+  // middle column at 32 + r (r < (N+1)/2, j < K/2); built and checked by the host when the operator is planned.
   double eo[6][EO_TAB];
-  int eo_ok;
-  unsigned *queue;            // pencil kernel: if set, per-XCD ticket counters (8 x QUEUE_STRIDE, zero at launch) -> groups are
-                               // taken dynamically by the XCD a wave really runs on (see the kernel's work list)
-  unsigned *done;             // with queue: completion counters for the gated assembly (GatedCtrl layout): a wave that has
-                               // finished a group -- its E-vector stores acknowledged by L2 -- adds 1 to the counter of the
-                               // group's bucket, done[chunk * nb + ((group - chunk begin) >> bucket_shift)]; a group taken from
-                               // another XCD's chunk adds GatedCtrl::FOREIGN instead (its stores sit in another L2)
-  int nb, bucket_shift;       // buckets per chunk, log2(groups per bucket)
-  // PAIR MERGE (pencil kernel, E = 2 elements per wave, direct mode): the nodes the two elements of a group share (a face,
-  // when consecutive elements are neighbours) are summed in LDS before anything is stored.  pairs[group][PAIR_MAX]: local node
-  // of the first element | local node of the second << 8, 0xFFFF = none.  The offsets then carry two more bits per node
-  // (lsize < 2^27): PAIR_SKIP on the second element's copy (nothing is stored for it), PAIR_DIRECT on the first element's
-  // when the node has no other contributor (its sum is final: straight to y, like an element-interior node).
-  const uint16_t *pairs;
-  // FOLDED assembly (as_rowptr set; needs queue and done): the waves of the pencil kernel sum the rows of the re-ordered
-  // transpose map themselves -- one item (<= GATED_ITEM_ROWS rows of one bucket of the wave's own XCD's chunk) per element
-  // group, its four dependent load levels (item, row pointers, columns, E-vector values) issued at four points of the
-  // group's passes so that none of them is waited for -- and whoever completes a bucket moves the chunk's frontier and
-  // publishes the number of items that may be summed (GatedCtrl::READY).  What is left when a wave runs out of groups is
-  // summed in a drain loop; cut rows and abandoned items are k_assemble_tail's.  One launch does the whole apply but those.
-  const uint32_t *as_rowptr, *as_cols, *as_node_off, *as_item_row, *as_bucket_items;
-  const unsigned char *as_flags;
-  int as_item_begin[9];
-  int as_max_spins;
-  int as_dbg;                 // bring-up (CEED_MI355X_FOLD_DBG): 1 no drain loop, 2 no in-loop stages (all in the drain loop)
-  int direct;                 // pencil kernel + evec: results at ELEMENT-INTERIOR nodes (0 < i,j,k < P-1; one contributor,
-                               // verified on the host) are stored straight into y and skip the E-vector round trip; the
-                               // E-vector then is [elem][shell node][3] and the transpose map handed to launch_assemble()
-                               // holds the shell nodes only, its columns being positions e * element_shell_size(P) + rank
-  int *query_waves;           // host side only (last member: the kernels' view of the struct is unchanged): if set, the
-                               // launcher stores the number of persistent waves a full launch has and launches nothing
+  int direct;                 // results at ELEMENT-INTERIOR nodes (0 < i,j,k < P-1; one contributor, verified on the
+                               // host) are stored straight into y and skip the E-vector round trip; the E-vector then is
+                               // [elem][shell node][3] and the transpose map handed to launch_assemble() holds the shell
+                               // nodes only, its columns being positions e * element_shell_size(P) + rank
+  // ---- host side only (behind everything the kernels read) ----
+  int wave_groups;            // > 0: every wave is given at most this many groups (grid = groups / wave_groups) instead of
+                               // the persistent grid (launch_fused_pencil_t)
+  int waves_per_cu;           // > 0: persistent waves per CU (tuning hook CEED_MI355X_PENCIL_WAVES)
+  int *query_waves;           // if set, the launcher stores the number of persistent waves a full launch has and launches nothing
 };
+// compute units of the current device (one device per process: cached)
+int device_cu_count();
 // element-interior test shared by the kernel and the host-side map builder
 #ifdef __HIPCC__
 __host__ __device__
@@ -156,8 +135,8 @@ struct TransferArgs {
   const double *scale_f;  // optional per-dof scale on the fine side (multiplicity^-1), or null
   int nelem;
   int mask_in, mask_out;
-  double *evec;           // if set: element results go here ([elem][output nodes][3], masked entries as zeros) and
-                          // launch_assemble() sums them into y in element order; else f64 atomics into y
+  double *evec;           // element results ([elem][output nodes][3], masked entries as zeros); launch_assemble() sums
+                          // them into y in element order
 };
 
 // x_c(xi) = a0 + a[c][0] xi + a[c][1] eta + a[c][2] zeta + a[c][3] xi eta + a[c][4] xi zeta + a[c][5] eta zeta + a[c][6] xi eta zeta
@@ -178,7 +157,7 @@ struct DiagArgs {
   const double *qdata, *state_in;
   int nelem, mask_out;
   double nu, E, lambda, TwoMu;
-  double *evec;  // if set: element contributions go here ([elem][P^3][3]) and launch_assemble() sums them; else atomics
+  double *evec;  // element contributions ([elem][P^3][3]); launch_assemble() sums them
 };
 
 // Each returns hipSuccess or the launch error; `name` receives a static string
@@ -193,60 +172,18 @@ hipError_t launch_setup_geo(int Q, const BasisTables &t, const SetupGeoArgs &a, 
 hipError_t launch_diag(int P, int Q, int qf, const BasisTables &t, const DiagArgs &a, hipStream_t s,
                        const char **name);
 
-// ---- gated assembly (the restriction transpose under the fused kernel) ------------------------------------------------
-// The pencil kernel's element groups are cut into 8 chunks (one per XCD) and each chunk into buckets of 2^bucket_shift
-// groups.  The rows of the transpose map are re-ordered by (chunk, bucket of the row's LAST contributor); rows whose
-// contributors lie in two chunks are the CUT rows at the end.  k_assemble_gated runs BESIDE the fused kernel on a second
-// stream: its waves read the XCD they run on.  ONE wave per XCD (the gatekeeper: first ticket) watches the chunk's bucket
-// counters, advances the completion frontier and publishes the number of items that may be summed in the chunk's READY
-// word; the others take that chunk's items (<= GATED_ITEM_ROWS rows of one bucket) in order, wait until READY has passed
-// their item and sum its rows.  (Every waiting wave polling the counters itself -- words the fused kernel's atomics
-// hit -- more than doubled the fused kernel's time; READY is written by one wave and only read by the rest.)  Producer and consumer share one
-// L2, so the E-vector entries are read with L1-bypassing loads and no cache maintenance.  k_assemble_tail then sums,
-// after both, the cut rows and every item the gated kernel did not finish (buckets with groups stolen by another XCD,
-// waves that never became resident) and resets the control block.  Correctness never depends on co-residency or on
-// the placement of workgroups: only the speed does.
-constexpr int GATED_ITEM_ROWS = 64;    // rows per item of the FOLDED form: one per lane of the wave that sums it (two per lane: the 48 value
-                                       // registers spilled); the gated form uses items of GATED_ITEM_ROWS_BESIDE rows
-constexpr int GATED_ITEM_ROWS_BESIDE = 256;
-struct GatedCtrl {   // uint32 offsets into the control block (zero before the first launch; the tail kernel re-zeroes it)
-  static constexpr int QUEUE = 0, AHEAD = 8 * QUEUE_STRIDE, READY = 16 * QUEUE_STRIDE, FRONT = 24 * QUEUE_STRIDE, DONE = 32 * QUEUE_STRIDE;
-  static constexpr unsigned STOP = 0x80000000u;   // READY word: the gatekeeper has given up (foreign groups ahead, time-out)
-  static constexpr unsigned FOREIGN = 0x10000u;   // a group run by another XCD counts in the upper half of its bucket's counter
-  static constexpr int item_done(int nb) { return DONE + 8 * nb; }
-  static constexpr int stats(int nb, int nitems) { return DONE + 8 * nb + nitems; }   // [0] items the tail kernel had to sum, [1] applies
-  static constexpr int size(int nb, int nitems) { return DONE + 8 * nb + nitems + 4; }
-};
-struct GatedAsmArgs {
-  const uint32_t *rowptr, *cols, *node_off;  // re-ordered transpose map; cols = DOUBLE index of a contributor's first component in the E-vector
-  const unsigned char *flags;                // per re-ordered row, or null
-  const double *evec;
-  double *y;
-  unsigned *ctrl;                            // GatedCtrl
-  const uint32_t *item_row;                  // [nitems + 1] first row of every item (items of chunk c: item_begin[c] .. item_begin[c+1])
-  const uint32_t *item_bucket;               // [nitems] bucket (within its chunk) an item waits for
-  const uint32_t *bucket_groups;             // [8 * nb] groups in every bucket
-  const uint32_t *bucket_items;              // [8 * nb] items of the chunk that wait for this bucket or an earlier one
-  int item_begin[9];
-  int nb, nitems, nrows_local, nrows;        // rows [nrows_local, nrows) are the cut rows
-  int max_spins;                             // bound of the gated kernel's wait for one bucket (then the tail kernel takes over)
-  int item_rows;                             // rows per item at most (64 or 256): the tail kernel's block size
-  int dbg;                                   // bring-up switches (CEED_MI355X_GATED_KDBG): 1 L1-bypassing E-vector loads, 2 no frontier wait, 4 static items
-};
-hipError_t launch_assemble_gated(const GatedAsmArgs &a, int waves_per_cu, hipStream_t s);
-hipError_t launch_assemble_tail(const GatedAsmArgs &a, hipStream_t s);
 // elements per wave (= per group) of the pencil kernel, PencilGeom<P, Q>::E: 3 Q^2 pencils per element and pass against 64
 // lanes and the 9 Q^3-double LDS slab per element
-#ifndef CPS_PENCIL_E5
-#define CPS_PENCIL_E5 2
-#endif
-constexpr int pencil_group_elems(int Q) { return Q <= 2 ? 8 : (Q <= 4 ? 4 : (Q == 5 ? CPS_PENCIL_E5 : 1)); }
+constexpr int pencil_group_elems(int Q) { return Q <= 2 ? 8 : (Q <= 4 ? 4 : (Q == 5 ? 2 : 1)); }
 
 // Deterministic, atomic-free E^T: y[node_off[r] + c] (+)= sum over the node's contributors, in element
 // order, of E[3 * cols[k] + c] (cols[k] = e * P3 + n).  `flags` (one byte per node, bit c = component c constrained) may be null.
+// `unpack` (may be null): the arrivals of a halo exchange, added to y by extra workgroups of the SAME launch (one launch
+// less on the critical path of a split-phase apply): y[dst[u]] += recv[slot[k]], k in [ptr[u], ptr[u+1]), in list order.
+struct HaloUnpackArgs { const uint32_t *dst, *ptr, *slot; const double *recv; int n; };
 hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off,
-                           const unsigned char *flags, const double *evec, double *y, int nnodes, int P3,
-                           int add, hipStream_t s, unsigned *queue_reset = nullptr, int max_blocks = 0);   // queue_reset: the pencil kernel's ticket counters, zeroed for its next launch; max_blocks: cap on the grid (pipelined assembly)
+                           const unsigned char *flags, const double *evec, double *y, int nnodes,
+                           int add, hipStream_t s, int max_blocks = 0, const HaloUnpackArgs *unpack = nullptr);   // max_blocks: cap on the grid (pipelined assembly)
 
 // Coordinate-driven set-up operators (kernels_coord.hip): opSetupForce and opTrue of setuplibceed.c:555-623.
 struct CoordOpArgs {
@@ -277,10 +214,11 @@ struct EnergyOpArgs {
 };
 hipError_t launch_energy_op(const EnergyOpArgs &a, hipStream_t s);
 
-// Interface-dof halo exchange (CeedXHalo*, the L-vector sum of src/matops.c:57 across GPUs): pack the entries shared with
-// one neighbour into its send buffer; add a neighbour's received entries (indices unique per neighbour: no atomics).
+// Interface-dof halo exchange (CeedXHalo*, the L-vector sum of src/matops.c:57 across GPUs).  ONE launch packs the entries
+// of all neighbour lists into the (contiguous) send buffer; ONE launch adds all arrivals: a thread per distinct destination
+// entry adds that entry's arrivals in neighbour-list order (no atomics; the sum is reproducible).
 hipError_t launch_halo_pack(const uint32_t *idx, int n, const double *y, double *buf, hipStream_t s);
-hipError_t launch_halo_unpack_add(const uint32_t *idx, int n, const double *buf, double *y, hipStream_t s);
+hipError_t launch_halo_unpack_add(const HaloUnpackArgs &u, double *y, hipStream_t s);
 
 // Assembled coarse-level operator (kernels_csr.hip).
 hipError_t launch_csr_sum(const uint32_t *slotptr, const uint32_t *perm, const double *coo, double *vals, int nnz,

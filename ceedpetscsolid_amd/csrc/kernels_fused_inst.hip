@@ -6,7 +6,6 @@
 // (cloptions.c:195-225): the fine level has P = Q (qextra = 0), coarse levels
 // use degrees 1, 2, 4 (logarithmic) with the FINE quadrature (setuplibceed.c:757).
 // Residual kernels (which write the stored state) only exist on the fine level.
-#include "kernel_fused_grad.hpp"
 #include "kernel_fused_pencil.hpp"
 
 #ifndef CPS_Q
@@ -20,16 +19,10 @@ namespace cps {
 #define CPS_STR_(x) #x
 #define CPS_STR(x) CPS_STR_(x)
 
-template <int P, int QF>
-static hipError_t go(const BasisTables &t, const FusedGradArgs &a, hipStream_t s) {
-  return a.variant == 1 ? launch_fused_pencil_t<P, CPS_Q, QF>(t, a, s) : launch_fused_grad_t<P, CPS_Q, QF>(t, a, s);
-}
-
 #define CPS_CASE(Pv, QFv, QFname)                                                   \
   if (P == Pv && qf == QFv) {                                                       \
-    *name = a.variant == 1 ? "fused_grad<P=" #Pv ",Q=" CPS_STR(CPS_Q) "," QFname ">/pencil"   \
-                           : "fused_grad<P=" #Pv ",Q=" CPS_STR(CPS_Q) "," QFname ">";         \
-    return go<Pv, QFv>(t, a, s);                                                    \
+    *name = "fused_grad<P=" #Pv ",Q=" CPS_STR(CPS_Q) "," QFname ">/pencil";         \
+    return launch_fused_pencil_t<Pv, CPS_Q, QFv>(t, a, s);                          \
   }
 #define CPS_JACOBIANS(Pv)              \
   CPS_CASE(Pv, QF_LINELAS, "LinElas")  \

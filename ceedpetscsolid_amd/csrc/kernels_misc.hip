@@ -131,8 +131,7 @@ __global__ __launch_bounds__(Geom<PF>::BLOCK) void k_transfer(const BasisTables 
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         const double val = a.scale_f ? v[c] * a.scale_f[base + c] : v[c];
-        if (a.evec) a.evec[((size_t)e * F3 + q) * 3 + c] = ((fl >> c) & 1u) ? 0. : val;
-        else if (!((fl >> c) & 1u)) atomic_add_f64(a.y + base + c, val);
+        a.evec[((size_t)e * F3 + q) * 3 + c] = ((fl >> c) & 1u) ? 0. : val;   // summed by launch_assemble()
       }
     }
   } else {
@@ -149,12 +148,9 @@ __global__ __launch_bounds__(Geom<PF>::BLOCK) void k_transfer(const BasisTables 
     double v[3];
     interp_transpose<PC, PF>(q, R0, R1, R2, sB, v);
     if (cnode) {
-      const uint32_t base = offc & OFF_MASK, fl = a.mask_out ? (offc >> OFF_FLAG_SHIFT) : 0u;
+      const uint32_t fl = a.mask_out ? (offc >> OFF_FLAG_SHIFT) : 0u;
 #pragma unroll
-      for (int c = 0; c < 3; c++) {
-        if (a.evec) a.evec[((size_t)e * C3 + q) * 3 + c] = ((fl >> c) & 1u) ? 0. : v[c];
-        else if (!((fl >> c) & 1u)) atomic_add_f64(a.y + base + c, v[c]);
-      }
+      for (int c = 0; c < 3; c++) a.evec[((size_t)e * C3 + q) * 3 + c] = ((fl >> c) & 1u) ? 0. : v[c];
     }
   }
 }
@@ -184,64 +180,9 @@ hipError_t launch_transfer(int Pc, int Pf, bool prolong, const BasisTables &t, c
 // Diagonal of B^T D B (matops.c:227).  D's (d,c),(d',c) entries come
 // from the Jacobian physics applied to unit reference gradients.
 // ===========================================================================
-template <int P, int Q, int QF>
-__global__ __launch_bounds__(Geom<Q>::TPE) void k_diag(const BasisTables tab, const DiagArgs a) {
-  using G = Geom<Q>;
-  constexpr int Q3 = G::Q3, P3 = P * P * P, TPE = G::TPE;
-  constexpr bool ST_IN = QFTraits<QF>::state_in;
-  extern __shared__ double dyn[];
-  double *sB = dyn, *sG = sB + Q * P, *sD = sG + Q * P;  // sD[27][Q3]: ((c*3+d)*3+d')
-  const int q = threadIdx.x, e = blockIdx.x;
-  for (int i = q; i < Q * P; i += TPE) { sB[i] = tab.interp[i]; sG[i] = tab.grad[i]; }
-  if (q < Q3) {
-    double qd[10], st[9], dv[9], sto[9], ug[9];
-    const double *qp = a.qdata + (size_t)e * 10 * Q3 + q;
-#pragma unroll
-    for (int c = 0; c < 10; c++) qd[c] = qp[c * Q3];
-    if constexpr (ST_IN) {
-      const double *sp = a.state_in + (size_t)e * 9 * Q3 + q;
-#pragma unroll
-      for (int c = 0; c < 9; c++) st[c] = sp[c * Q3];
-    }
-    for (int din = 0; din < 3; din++)
-      for (int c = 0; c < 3; c++) {
-#pragma unroll
-        for (int s = 0; s < 9; s++) ug[s] = (s == din * 3 + c) ? 1. : 0.;
-        qf_point<QF>(Phys{a.nu, a.E, a.lambda, a.TwoMu}, ug, qd, st, dv, sto);
-        for (int dout = 0; dout < 3; dout++) sD[((c * 3 + dout) * 3 + din) * Q3 + q] = dv[dout * 3 + c];
-      }
-  }
-  __syncthreads();
-  if (q < P3) {
-    const int na = q % P, nb = (q / P) % P, nc = q / (P * P);
-    double acc[3] = {0., 0., 0.};
-    for (int k = 0; k < Q; k++) {
-      const double bk = sB[k * P + nc], gk = sG[k * P + nc];
-      for (int j = 0; j < Q; j++) {
-        const double bj = sB[j * P + nb], gj = sG[j * P + nb];
-        for (int i = 0; i < Q; i++) {
-          const double bi = sB[i * P + na], gi = sG[i * P + na];
-          const double g[3] = {gi * bj * bk, bi * gj * bk, bi * bj * gk};
-          const int qq = (k * Q + j) * Q + i;
-#pragma unroll
-          for (int c = 0; c < 3; c++)
-#pragma unroll
-            for (int d = 0; d < 3; d++)
-#pragma unroll
-              for (int d2 = 0; d2 < 3; d2++) acc[c] += g[d] * sD[((c * 3 + d) * 3 + d2) * Q3 + qq] * g[d2];
-        }
-      }
-    }
-    const uint32_t off = a.offsets[(size_t)e * P3 + q];
-    const uint32_t base = off & OFF_MASK, fl = a.mask_out ? (off >> OFF_FLAG_SHIFT) : 0u;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      if (a.evec) a.evec[((size_t)e * P3 + q) * 3 + c] = ((fl >> c) & 1u) ? 0. : acc[c];  // summed by launch_assemble()
-      else if (!((fl >> c) & 1u)) atomic_add_f64(a.diag + base + c, acc[c]);
-    }
-  }
-}
-// The same diagonal, sum-factorised.  diag_c(n) = sum_q sum_{d,d2} g_d(n,q) D^c_{d d2}(q) g_d2(n,q) with g_d a product of
+// diag_c(n) = sum_q sum_{d,d2} g_d(n,q) D^c_{d d2}(q) g_d2(n,q): the tangent D probed with nine unit gradients per point.
+// (The unfactorised first version -- P^3 Q^3 60 FMAs per element, 5x slower -- left the tree in round 3.)
+// Sum-factorised: g_d is a product of
 // 1-D factors, so each of the 18 tensors S^c_pair(q) (pair = (d,d2), d <= d2; off-diagonal pairs hold D_{d d2} + D_{d2 d})
 // is contracted direction by direction with the PRODUCT tables BB, BG, GG (table_x(i,a) = X_d(i,a) X_d2(i,a), X = G in its
 // own direction, B otherwise): 18 * (P Q^2 + P^2 Q + P^3) * Q FMAs per element instead of P^3 * Q^3 * 60 (25x fewer at
@@ -332,30 +273,24 @@ __global__ __launch_bounds__(Geom<Q>::TPE) void k_diag_sf(const BasisTables tab,
         acc[c] += v;
       }
     const uint32_t off = a.offsets[(size_t)e * P3 + q];
-    const uint32_t base = off & OFF_MASK, fl = a.mask_out ? (off >> OFF_FLAG_SHIFT) : 0u;
+    const uint32_t fl = a.mask_out ? (off >> OFF_FLAG_SHIFT) : 0u;
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-      if (a.evec) a.evec[((size_t)e * P3 + q) * 3 + c] = ((fl >> c) & 1u) ? 0. : acc[c];  // summed by launch_assemble()
-      else if (!((fl >> c) & 1u)) atomic_add_f64(a.diag + base + c, acc[c]);
-    }
+    for (int c = 0; c < 3; c++) a.evec[((size_t)e * P3 + q) * 3 + c] = ((fl >> c) & 1u) ? 0. : acc[c];  // summed by launch_assemble()
   }
 }
 template <int P, int Q, int QF>
 static hipError_t diag_t(const BasisTables &t, const DiagArgs &a, hipStream_t s) {
   using G = Geom<Q>;
   if (a.nelem <= 0) return hipSuccess;
-  static const bool direct = getenv("CEED_MI355X_DIAG") && !strcmp(getenv("CEED_MI355X_DIAG"), "direct");   // A/B: the unfactorised kernel
   constexpr int PQQ = P * Q * Q, PPQ = P * P * Q, S0 = G::Q3 > PPQ ? G::Q3 : PPQ;
-  const size_t lds = direct ? sizeof(double) * (2 * Q * P + 27 * G::Q3) : sizeof(double) * (3 * Q * P + 18 * (S0 + PQQ));
+  const size_t lds = sizeof(double) * (3 * Q * P + 18 * (S0 + PQQ));
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t er = direct ? hipFuncSetAttribute((const void *)k_diag<P, Q, QF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                           : hipFuncSetAttribute((const void *)k_diag_sf<P, Q, QF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t er = hipFuncSetAttribute((const void *)k_diag_sf<P, Q, QF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (er != hipSuccess) return er;
     attr_set = true;
   }
-  if (direct) hipLaunchKernelGGL((k_diag<P, Q, QF>), dim3(a.nelem), dim3(G::TPE), lds, s, t, a);
-  else hipLaunchKernelGGL((k_diag_sf<P, Q, QF>), dim3(a.nelem), dim3(G::TPE), lds, s, t, a);
+  hipLaunchKernelGGL((k_diag_sf<P, Q, QF>), dim3(a.nelem), dim3(G::TPE), lds, s, t, a);
   return hipGetLastError();
 }
 hipError_t launch_diag(int P, int Q, int qf, const BasisTables &t, const DiagArgs &a, hipStream_t s,
@@ -370,6 +305,17 @@ hipError_t launch_diag(int P, int Q, int qf, const BasisTables &t, const DiagArg
   CPS_DG3(2, 2) CPS_DG3(2, 3) CPS_DG3(3, 3) CPS_DG3(2, 4) CPS_DG3(3, 4) CPS_DG3(4, 4)
   CPS_DG3(2, 5) CPS_DG3(3, 5) CPS_DG3(4, 5) CPS_DG3(5, 5) CPS_DG3(2, 7) CPS_DG3(3, 7) CPS_DG3(5, 7) CPS_DG3(7, 7)
   return hipErrorInvalidValue;
+}
+
+int device_cu_count() {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    ncu = prop.multiProcessorCount;
+  }
+  return ncu;
 }
 
 // ===========================================================================
@@ -441,11 +387,20 @@ __global__ void k_rstr(const uint32_t *off, size_t total, int elemsize, int ncom
 // One lane per L-node.  The E-vector is interlaced [elem][node][3] like the L-vector: a contributor is
 // 24 contiguous bytes, consecutive lanes (consecutively numbered nodes of one element) read and write
 // consecutive 24-byte rows, so the three strided 8-byte accesses of a wave cover whole cache lines.
+// Workgroups [nb_rows, gridDim.x) -- present only with `un.n` > 0 -- add the arrivals of a halo exchange instead
+// (HaloUnpackArgs: different entries of y than any row of this launch).
 __global__ void k_assemble(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off,
-                           const unsigned char *flags, const double *evec, double *y, int nnodes, int add, unsigned *queue_reset) {
-  // the fused kernel's ticket counters (dynamic schedule) are zeroed here, after it, for its next launch
-  if (queue_reset && blockIdx.x == 0 && threadIdx.x < 8) queue_reset[threadIdx.x * QUEUE_STRIDE] = 0u;
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nnodes; r += gridDim.x * blockDim.x) {
+                           const unsigned char *flags, const double *evec, double *y, int nnodes, int add, int nb_rows,
+                           const HaloUnpackArgs un) {
+  if ((int)blockIdx.x >= nb_rows) {
+    for (int u = ((int)blockIdx.x - nb_rows) * blockDim.x + threadIdx.x; u < un.n; u += ((int)gridDim.x - nb_rows) * blockDim.x) {
+      double v = y[un.dst[u]];
+      for (uint32_t k = un.ptr[u]; k < un.ptr[u + 1]; k++) v += un.recv[un.slot[k]];
+      y[un.dst[u]] = v;
+    }
+    return;
+  }
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nnodes; r += nb_rows * blockDim.x) {
     const uint32_t k0 = rowptr[r], k1 = rowptr[r + 1];
     double a0 = 0., a1 = 0., a2 = 0.;
     // four contributors per trip: the index loads, then the twelve value loads, are issued together (the
@@ -474,206 +429,25 @@ __global__ void k_assemble(const uint32_t *rowptr, const uint32_t *cols, const u
     dst[0] = a0; dst[1] = a1; dst[2] = a2;
   }
 }
-// ---- gated assembly (kernels.hpp, GatedAsmArgs) -------------------------------------------------------------------------
-// A row of the re-ordered transpose map (columns = double index of the contributor in the E-vector).
-// The E-vector values were written during this launch by other CUs of the same XCD, whose stores this CU's L1 never sees.
-// Plain loads are sound all the same: an element's E-vector block is whole 128-byte lines (FusedGradArgs::evec_stride), every
-// line is written by ONE wave before that wave signals its group, and a row is read only after all its contributors'
-// groups have been seen complete -- so no line of a block can have entered this CU's L1 (empty at kernel start) before
-// its final bytes had reached the XCD's L2.  BYPASS (A/B only): L1-bypassing loads (global_load ... sc1), which the
-// measurements price at 1.5x the kernel's time (8-byte sc1 loads, each of a node's three fetched from L2 separately).
-template <bool BYPASS>
-CPS_DEV void assemble_row(const GatedAsmArgs &a, int r) {
-  const uint32_t k0 = a.rowptr[r], k1 = a.rowptr[r + 1];
-  double a0 = 0., a1 = 0., a2 = 0.;
-  for (uint32_t k = k0; k < k1; k += 4) {   // as k_assemble: four contributors per trip, summed in element order
-    uint32_t c[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) c[j] = a.cols[k + j < k1 ? k + j : k1 - 1];
-    double v[4][3];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const double *p = a.evec + c[j];
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        if constexpr (BYPASS) v[j][d] = __hip_atomic_load(p + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else v[j][d] = p[d];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (k + j < k1) { a0 += v[j][0]; a1 += v[j][1]; a2 += v[j][2]; }
-  }
-  const unsigned fl = a.flags ? a.flags[r] : 0u;
-  double *dst = a.y + (a.node_off[r] & OFF_MASK);
-  dst[0] = (fl & 1u) ? 0. : a0; dst[1] = (fl & 2u) ? 0. : a1; dst[2] = (fl & 4u) ? 0. : a2;
-}
-// two rows at once (the second may be absent: rb < 0): both rows' dependent load levels (row pointers, columns, values)
-// are issued together, which halves the exposed latency per row of a wave that sums its rows one after the other
-CPS_DEV void assemble_rows2(const GatedAsmArgs &a, int ra, int rb) {
-  const bool two = rb >= 0;
-  const int rB = two ? rb : ra;
-  const uint32_t ka0 = a.rowptr[ra], ka1 = a.rowptr[ra + 1], kb0 = a.rowptr[rB], kb1 = two ? a.rowptr[rB + 1] : kb0;
-  const uint32_t noa = a.node_off[ra], nob = a.node_off[rB];
-  const unsigned fla = a.flags ? a.flags[ra] : 0u, flb = a.flags ? a.flags[rB] : 0u;
-  double sa[3] = {0., 0., 0.}, sb[3] = {0., 0., 0.};
-  for (uint32_t t = 0; ka0 + t < ka1 || kb0 + t < kb1; t += 4) {
-    uint32_t ca[4], cb[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      ca[j] = a.cols[min(ka0 + t + (uint32_t)j, max(ka1, ka0 + 1u) - 1u)];
-      cb[j] = a.cols[min(kb0 + t + (uint32_t)j, max(kb1, kb0 + 1u) - 1u)];
-    }
-    double va[4][3], vb[4][3];
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int d = 0; d < 3; d++) { va[j][d] = a.evec[ca[j] + d]; vb[j][d] = a.evec[cb[j] + d]; }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (ka0 + t + (uint32_t)j < ka1) { sa[0] += va[j][0]; sa[1] += va[j][1]; sa[2] += va[j][2]; }
-      if (kb0 + t + (uint32_t)j < kb1) { sb[0] += vb[j][0]; sb[1] += vb[j][1]; sb[2] += vb[j][2]; }
-    }
-  }
-  double *da = a.y + (noa & OFF_MASK);
-  da[0] = (fla & 1u) ? 0. : sa[0]; da[1] = (fla & 2u) ? 0. : sa[1]; da[2] = (fla & 4u) ? 0. : sa[2];
-  if (two) {
-    double *db = a.y + (nob & OFF_MASK);
-    db[0] = (flb & 1u) ? 0. : sb[0]; db[1] = (flb & 2u) ? 0. : sb[1]; db[2] = (flb & 4u) ? 0. : sb[2];
-  }
-}
-// Persistent single-wave workgroups beside the fused kernel.  Every wait is bounded: a wave that gives up (or never runs)
-// leaves its items to k_assemble_tail.
-__global__ __launch_bounds__(64) void k_assemble_gated(const GatedAsmArgs a) {
-  const int lane = threadIdx.x;
-  const int xcd = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);   // hwreg(HW_REG_XCC_ID, 0, 4): the chunk this wave may read
-  unsigned *ahead = a.ctrl + GatedCtrl::AHEAD + xcd * QUEUE_STRIDE, *ready = a.ctrl + GatedCtrl::READY + xcd * QUEUE_STRIDE;
-  unsigned *item_done = a.ctrl + GatedCtrl::item_done(a.nb);
-  const int ibeg = a.item_begin[xcd], iend = a.item_begin[xcd + 1];
-  if (ibeg >= iend) return;
-  // The control flow is kept wave-uniform and every loop is bounded.
-  auto peek = [](const unsigned *p) { return (unsigned)__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
-  auto ticket = [&]() { unsigned t = 0; if (lane == 0) t = atomicAdd(ahead, 1u); return (int)__builtin_amdgcn_readfirstlane(t); };
-  int tk = ticket();
-  if (tk == 0) {
-    // ---- gatekeeper of this XCD's chunk: frontier f = buckets [0, f) complete, every group of them run by this XCD.  One
-    // probe looks at 64 buckets, one per lane (L1-bypassing loads), and moves the frontier by the run of complete ones.
-    const unsigned *done = a.ctrl + GatedCtrl::DONE + xcd * a.nb;
-    const uint32_t *bgroups = a.bucket_groups + xcd * a.nb, *bitems = a.bucket_items + xcd * a.nb;
-    unsigned f = 0, pub = 0;
-    for (int spins = 0; f < (unsigned)a.nb;) {
-      const unsigned fb = f + (unsigned)lane;
-      const bool in = fb < (unsigned)a.nb;
-      const unsigned d = in ? __hip_atomic_load(done + fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      const unsigned long long clean = __ballot(in && d == bgroups[in ? fb : 0u]), taint = __ballot(in && d >= GatedCtrl::FOREIGN);
-      const int run = clean == ~0ull ? 64 : __builtin_ctzll(~clean);   // complete buckets from f on
-      if (run > 0) {
-        f += (unsigned)run;
-        pub = (unsigned)__builtin_amdgcn_readfirstlane(bitems[f - 1]);
-        if (lane == 0) *(volatile unsigned *)ready = pub;   // plain store: it stays in this XCD's L2, where the readers look
-        spins = 0;
-        continue;
-      }
-      if ((taint & 1ull) || ++spins > a.max_spins) {   // groups of bucket f ran on another XCD, or nothing moves: the tail kernel's
-        if (lane == 0) *(volatile unsigned *)ready = pub | GatedCtrl::STOP;
-        return;
-      }
-      __builtin_amdgcn_s_sleep(32);
-    }
-    return;
-  }
-  for (int n = ibeg; n < iend; n++) {   // at most the chunk's items
-    const int it = ibeg + tk - 1;
-    if (it >= iend) break;
-    if (a.dbg & 4) tk += (int)gridDim.x / 8;   // bring-up: static striding (assumes an even spread of the waves over the XCDs)
-    else tk = ticket();   // the next item's ticket returns under this item's work (an item taken and then abandoned is the tail kernel's)
-    // wait until the gatekeeper has published this item (READY: written by one wave, read here past L1)
-    bool ok = true;
-    for (int spins = 0; !(a.dbg & 2);) {
-      const unsigned r = peek(ready);
-      if ((r & ~GatedCtrl::STOP) > (unsigned)(it - ibeg)) break;
-      if ((r & GatedCtrl::STOP) || ++spins > a.max_spins) { ok = false; break; }
-      __builtin_amdgcn_s_sleep(64);                                       // ~1.7 us
-      if (a.dbg & 16) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
-    }
-    if (!ok) break;   // this item and the chunk's later ones stay undone
-    if (a.dbg & 8) continue;   // bring-up: waiting only, the rows are left to the tail kernel
-    const int r0 = (int)a.item_row[it], r1 = (int)a.item_row[it + 1];
-    if (a.dbg & 1) { for (int r = r0 + lane; r < r1; r += 64) assemble_row<true>(a, r); }
-    else {
-      for (int r = r0 + lane; r < r1; r += 128) assemble_rows2(a, r, r + 64 < r1 ? r + 64 : -1);   // two rows' load chains in flight
-    }
-    if (lane == 0) item_done[it] = 1u;
-  }
-}
-// After the fused and the gated kernel: block j < ceil(nitems / TAIL_ITEMS) looks at TAIL_ITEMS items and sums those the gated
-// kernel did not; the blocks behind sum the cut rows; the control block is zeroed for the next apply.
-constexpr int TAIL_ITEMS = 1;   // (16 per block made the tail 3x slower: the undone items sit together at the end of a chunk and were then summed one after the other)
-__global__ __launch_bounds__(GATED_ITEM_ROWS_BESIDE) void k_assemble_tail(const GatedAsmArgs a) {   // blockDim.x = a.item_rows
-  unsigned *item_done = a.ctrl + GatedCtrl::item_done(a.nb);
-  const int j = blockIdx.x, nib = (a.nitems + TAIL_ITEMS - 1) / TAIL_ITEMS;
-  if (j == 0) {
-    for (int i = threadIdx.x; i < GatedCtrl::item_done(a.nb); i += blockDim.x) a.ctrl[i] = 0u;
-    if (threadIdx.x == 0) atomicAdd(a.ctrl + GatedCtrl::stats(a.nb, a.nitems) + 1, 1u);
-  }
-  if (j < nib) {
-    const int i0 = j * TAIL_ITEMS;
-    unsigned undone = 0;   // bit k: item i0 + k was left by the gated kernel (uniform over the block)
-#pragma unroll
-    for (int k = 0; k < TAIL_ITEMS; k++)
-      if (i0 + k < a.nitems && item_done[i0 + k] == 0u) undone |= 1u << k;
-    __syncthreads();
-    if ((int)threadIdx.x < TAIL_ITEMS && i0 + (int)threadIdx.x < a.nitems) item_done[i0 + threadIdx.x] = 0u;
-    while (undone) {
-      const int k = __builtin_ctz(undone);
-      undone &= undone - 1u;
-      const int r = (int)a.item_row[i0 + k] + threadIdx.x;
-      if (r < (int)a.item_row[i0 + k + 1]) assemble_row<false>(a, r);
-      if (threadIdx.x == 0) atomicAdd(a.ctrl + GatedCtrl::stats(a.nb, a.nitems), 1u);
-    }
-  } else {
-    const int r = a.nrows_local + (j - nib) * (int)blockDim.x + threadIdx.x;
-    if (r < a.nrows) assemble_row<false>(a, r);
-  }
-}
-hipError_t launch_assemble_gated(const GatedAsmArgs &a, int waves_per_cu, hipStream_t s) {
-  if (a.nitems <= 0) return hipSuccess;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-    ncu = prop.multiProcessorCount;
-  }
-  int grid = ncu * (waves_per_cu > 0 ? waves_per_cu : 4);
-  if (grid > a.nitems + 8) grid = a.nitems + 8;   // one gatekeeper per XCD on top of the workers
-  if (grid < 8) grid = 8;   // one wave per XCD at least (placement permitting; the tail kernel covers the rest)
-  hipLaunchKernelGGL(k_assemble_gated, dim3(grid), dim3(64), 0, s, a);
-  return hipGetLastError();
-}
-hipError_t launch_assemble_tail(const GatedAsmArgs &a, hipStream_t s) {
-  const int ncut = a.nrows - a.nrows_local;
-  const int bs = a.item_rows > 0 ? a.item_rows : GATED_ITEM_ROWS;
-  int grid = (a.nitems + TAIL_ITEMS - 1) / TAIL_ITEMS + (ncut + bs - 1) / bs;
-  if (grid < 1) grid = 1;   // block 0 zeroes the control block (the fused kernel's ticket counters live there)
-  hipLaunchKernelGGL(k_assemble_tail, dim3(grid), dim3(bs), 0, s, a);
-  return hipGetLastError();
-}
 
 __global__ void k_halo_pack(const uint32_t *idx, int n, const double *y, double *buf) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) buf[i] = y[idx[i]];
 }
-__global__ void k_halo_unpack_add(const uint32_t *idx, int n, const double *buf, double *y) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[idx[i]] += buf[i];
+__global__ void k_halo_unpack_add(const HaloUnpackArgs un, double *y) {
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < un.n; u += gridDim.x * blockDim.x) {
+    double v = y[un.dst[u]];
+    for (uint32_t k = un.ptr[u]; k < un.ptr[u + 1]; k++) v += un.recv[un.slot[k]];   // neighbour-list order
+    y[un.dst[u]] = v;
+  }
 }
 hipError_t launch_halo_pack(const uint32_t *idx, int n, const double *y, double *buf, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)std::min((n + 255) / 256, 2048)), dim3(256), 0, s, idx, n, y, buf);
   return hipGetLastError();
 }
-hipError_t launch_halo_unpack_add(const uint32_t *idx, int n, const double *buf, double *y, hipStream_t s) {
-  if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_halo_unpack_add, dim3((unsigned)std::min((n + 255) / 256, 2048)), dim3(256), 0, s, idx, n, buf, y);
+hipError_t launch_halo_unpack_add(const HaloUnpackArgs &u, double *y, hipStream_t s) {
+  if (u.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_halo_unpack_add, dim3((unsigned)std::min((u.n + 255) / 256, 2048)), dim3(256), 0, s, u, y);
   return hipGetLastError();
 }
 
@@ -773,13 +547,15 @@ hipError_t launch_multiplicity(const uint32_t *off, int nelem, int elemsize, int
   return rstr(off, nelem, elemsize, ncomp, compstride, nullptr, l, 2, s);
 }
 hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off,
-                           const unsigned char *flags, const double *evec, double *y, int nnodes, int P3,
-                           int add, hipStream_t s, unsigned *queue_reset, int max_blocks) {
-  if (nnodes <= 0 && !queue_reset) return hipSuccess;
-  (void)P3;
-  unsigned grid = (unsigned)((std::max(nnodes, 1) + 255) / 256);
-  if (max_blocks > 0 && grid > (unsigned)max_blocks) grid = (unsigned)max_blocks;     // (grid-stride loop over the rows)
-  hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(256), 0, s, rowptr, cols, node_off, flags, evec, y, nnodes, add, queue_reset);
+                           const unsigned char *flags, const double *evec, double *y, int nnodes,
+                           int add, hipStream_t s, int max_blocks, const HaloUnpackArgs *unpack) {
+  const int nun = unpack ? unpack->n : 0;
+  if (nnodes <= 0 && nun <= 0) return hipSuccess;
+  unsigned nb_rows = (unsigned)((std::max(nnodes, 0) + 255) / 256);
+  if (max_blocks > 0 && nb_rows > (unsigned)max_blocks) nb_rows = (unsigned)max_blocks;     // (grid-stride loop over the rows)
+  const unsigned nb_un = (unsigned)std::min((nun + 255) / 256, 1024);
+  hipLaunchKernelGGL(k_assemble, dim3(nb_rows + nb_un), dim3(256), 0, s, rowptr, cols, node_off, flags, evec, y, nnodes, add,
+                     (int)nb_rows, unpack ? *unpack : HaloUnpackArgs{nullptr, nullptr, nullptr, nullptr, 0});
   return hipGetLastError();
 }
 hipError_t launch_dot(const double *x, const double *y, const double *w, size_t n, double *result_dev, hipStream_t s, double *out) {

@@ -242,15 +242,21 @@ static int LocalToGlobalAdd(SolidApp app, CeedInt level, CeedVector Y) {
   CHK(CeedXHaloStart(h, Y));
   return CeedXHaloFinish(h, Y);
 }
+// ApplyLocalCeedOp followed by DMLocalToGlobal(ADD_VALUES) (matops.c:46,57) as ONE library call when the level has a halo:
+// the library overlaps the exchange with the interior elements if the operator carries a split (CeedXOperatorSetOverlapSplit),
+// and otherwise applies, then exchanges -- the same numbers either way.
+static int ApplyLocalThenGlobalAdd(SolidApp app, CeedInt level, CeedOperator op, CeedVector X, CeedVector Y) {
+  CeedXHalo h = app->data[level].halo;
+  if (!h) return ApplyLocalCeedOp(app, op, X, Y);
+  return CeedXOperatorApplyWithHalo(op, X, Y, h);
+}
 // matops.c:63-79: X carries the boundary values inserted at the current load increment
 extern "C" int FormResidual_Ceed(SolidApp app, CeedVector X, CeedVector Y) {
-  CHK(ApplyLocalCeedOp(app, app->opApply, X, Y));
-  return LocalToGlobalAdd(app, app->numLevels - 1, Y);
+  return ApplyLocalThenGlobalAdd(app, app->numLevels - 1, app->opApply, X, Y);
 }
 // matops.c:98-112
 extern "C" int ApplyJacobian_Ceed(SolidApp app, CeedInt level, CeedVector X, CeedVector Y) {
-  CHK(ApplyLocalCeedOp(app, app->data[level].opJacob, X, Y));
-  return LocalToGlobalAdd(app, level, Y);
+  return ApplyLocalThenGlobalAdd(app, level, app->data[level].opJacob, X, Y);
 }
 // matops.c:115-157 (level-1 -> level)
 extern "C" int Prolong_Ceed(SolidApp app, CeedInt level, CeedVector Xc, CeedVector Yf) {

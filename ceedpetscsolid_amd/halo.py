@@ -33,14 +33,20 @@ class Neighbour:
 
 
 class HaloExchange:
-    def __init__(self, mesh: HexMesh, dm: DofMap, device="cpu", group=None):
+    def __init__(self, mesh: HexMesh, dm: DofMap, device="cpu", group=None, virtual=None):
+        """`virtual` (emulation of ONE rank of a larger job on a single process, bench.py --emulate-rank): a dict
+        {"rank": K, "world": N, "keys": {r: key bytes of rank r's nodes near the cut}} standing in for the all-gather."""
         self.group = group
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.virtual = virtual
+        if virtual is not None:
+            self.rank, self.world = int(virtual["rank"]), int(virtual["world"])
+        else:
+            self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device = torch.device(device)
         # gloo cannot move device tensors point-to-point: stage through the host (CPU tests and
         # single-GPU rehearsals only; the GPU node uses "nccl" = RCCL, device buffers end to end)
-        self.stage_host = (dist.is_initialized() and dist.get_backend(group) == "gloo" and self.device.type == "cuda")
+        self.stage_host = (virtual is None and dist.is_initialized() and dist.get_backend(group) == "gloo" and self.device.type == "cuda")
         self.dm = dm
         self.neigh: List[Neighbour] = []
         self.owner_weight = np.ones(dm.lsize)   # 1 on dofs this rank owns (lowest sharing rank)
@@ -48,9 +54,15 @@ class HaloExchange:
             return
         cand = boundary_nodes(mesh, dm)
         kb = key_bytes(dm.node_keys[cand])
-        mine = {"keys": kb.tobytes(), "n": int(cand.size), "w": int(kb.dtype.itemsize)}
-        gathered: List[Optional[dict]] = [None] * self.world
-        dist.all_gather_object(gathered, mine, group=group)
+        if virtual is not None:
+            gathered = [None] * self.world
+            for r in range(self.world):
+                okb = virtual["keys"].get(r)
+                gathered[r] = {"keys": okb.tobytes(), "n": int(okb.size), "w": int(okb.dtype.itemsize)} if okb is not None and r != self.rank else {"keys": b"", "n": 0, "w": int(kb.dtype.itemsize)}
+        else:
+            mine = {"keys": kb.tobytes(), "n": int(cand.size), "w": int(kb.dtype.itemsize)}
+            gathered: List[Optional[dict]] = [None] * self.world
+            dist.all_gather_object(gathered, mine, group=group)
         order = np.argsort(kb, kind="stable")
         kb_sorted, cand_sorted = kb[order], cand[order]
         nc = dm.ncomp
@@ -127,7 +139,7 @@ class HaloExchange:
     def global_count(self, local_mask_free: np.ndarray) -> int:
         """Number of distinct unconstrained dofs over all ranks (the reference's Ugsz)."""
         mine = float((local_mask_free * self.owner_weight).sum())
-        if self.world == 1:
+        if self.world == 1 or self.virtual is not None:   # (emulated rank: the dofs this rank OWNS)
             return int(round(mine))
         t = torch.tensor([mine], dtype=torch.float64, device="cpu" if self.stage_host else self.device)
         dist.all_reduce(t, group=self.group)
@@ -147,13 +159,22 @@ class RcclHalo:
     HaloExchange's neighbour lists; the communicator is bootstrapped like any NCCL communicator (rank 0's unique id,
     distributed here with torch.distributed -- an MPI_Bcast in the reference's world)."""
 
-    def __init__(self, ceed, halo: "HaloExchange"):
+    def __init__(self, ceed, halo: "HaloExchange", emulate_self: bool = False):
+        """emulate_self (bench.py --emulate-rank): a ONE-rank communicator; every neighbour list is sent to and received
+        from this rank itself -- the launches, buffer sizes and stream hand-overs of the real exchange on a single GPU (the
+        sums it produces are those of a vector folded onto itself, not of the partitioned problem)."""
         import ctypes as C
         self.ceed, self.L = ceed, ceed.L
         self.h = C.c_void_p()
         self.world = halo.world
         lib = self.L.lib
-        if halo.world > 1 and not getattr(ceed, "_comm_ready", False):
+        if emulate_self:
+            if not getattr(ceed, "_comm_ready", False):
+                buf = C.create_string_buffer(128)
+                self.L.chk(lib.CeedXCommGetUniqueId(ceed.h, buf))
+                self.L.chk(lib.CeedXCommInit(ceed.h, C.c_int(1), C.c_int(0), C.c_char_p(buf.raw)))
+                ceed._comm_ready = True
+        elif halo.world > 1 and not getattr(ceed, "_comm_ready", False):
             ident = [None]
             if halo.rank == 0:
                 buf = C.create_string_buffer(128)
@@ -163,7 +184,7 @@ class RcclHalo:
             self.L.chk(lib.CeedXCommInit(ceed.h, C.c_int(halo.world), C.c_int(halo.rank), C.c_char_p(ident[0])))
             ceed._comm_ready = True
         nn = len(halo.neigh)
-        ranks = (C.c_int * max(nn, 1))(*[n.rank for n in halo.neigh])
+        ranks = (C.c_int * max(nn, 1))(*[0 if emulate_self else n.rank for n in halo.neigh])
         counts = (C.c_int * max(nn, 1))(*[int(n.dof_idx.numel()) for n in halo.neigh])
         self._idx = [np.ascontiguousarray(n.dof_idx.cpu().numpy().astype(np.int32)) for n in halo.neigh]
         ptrs = (C.POINTER(C.c_int) * max(nn, 1))(*[a.ctypes.data_as(C.POINTER(C.c_int)) for a in self._idx])
@@ -236,9 +257,33 @@ def checked_rccl_halo(ceed, halo: "HaloExchange", probe: np.ndarray, device, tim
     return h, "CeedXHalo* checked against the torch exchange on a test vector at start-up"
 
 
-def interface_elements(mesh: HexMesh, group=None) -> np.ndarray:
+def virtual_world(rank: int, world: int, mesh: HexMesh, part_of, degree: int) -> dict:
+    """Stand-in for the collectives of HaloExchange / interface_elements when ONE rank of a `world`-rank job is emulated
+    on a single process: `part_of(r)` builds rank r's mesh; of every other rank only the elements that touch a vertex of
+    `mesh` are numbered (the topological keys are partition independent, so a sub-mesh gives the same keys)."""
+    from .mesh import build_dofmap, submesh
+    mine = np.unique(mesh.gid())
+    keys, verts = {}, []
+    for r in range(world):
+        if r == rank:
+            continue
+        other = part_of(r)
+        og = other.gid()
+        touch = np.isin(og, mine)
+        if not touch.any():
+            continue
+        elems = np.flatnonzero(touch[other.cells].any(axis=1))
+        sub = submesh(other, elems)
+        keys[r] = np.sort(key_bytes(build_dofmap(sub, degree, locality_order=False).node_keys))
+        verts.append(og[touch])
+    return {"rank": rank, "world": world, "keys": keys, "shared_vertices": np.unique(np.concatenate(verts)) if verts else np.zeros(0, dtype=np.int64)}
+
+
+def interface_elements(mesh: HexMesh, group=None, virtual=None) -> np.ndarray:
     """bool per element: True if the element has a vertex that another rank also holds (its nodes may
     need the halo sum).  Collective; uses global vertex ids only."""
+    if virtual is not None:
+        return np.isin(mesh.gid(), virtual["shared_vertices"])[mesh.cells].any(axis=1)
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return np.zeros(mesh.nelem, dtype=bool)
     g = mesh.gid()

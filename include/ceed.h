@@ -379,15 +379,27 @@ CEED_EXTERN int CeedXHaloCreate(Ceed ceed, CeedInt nneigh, const int *neigh_rank
 CEED_EXTERN int CeedXHaloStart(CeedXHalo halo, CeedVector y);
 CEED_EXTERN int CeedXHaloFinish(CeedXHalo halo, CeedVector y);
 CEED_EXTERN int CeedXHaloDestroy(CeedXHalo *halo);
-/* Diagnostic: the gated assembly of a residual / Jacobian operator (the      */
-/* restriction transpose run beside the fused kernel).  out[0] items of the    */
-/* transpose map, out[1] rows in them, out[2] cut rows, out[3] items summed by */
-/* the tail kernel since the last call, out[4] applies since the last call.    */
-CEED_EXTERN int CeedXOperatorGetGatedStats(CeedOperator op, long long out[5]);
+/* CeedOperatorApply of a residual / Jacobian operator AND the interface sum of  */
+/* its output in one call -- ApplyLocalCeedOp's CeedOperatorApply followed by     */
+/* DMLocalToGlobal(ADD_VALUES) (src/matops.c:46,57) on several GPUs.  With a      */
+/* split set (CeedXOperatorSetOverlapSplit) the interface-touching elements and   */
+/* the interior elements run as two launches on two streams, the exchange starts  */
+/* as soon as the interface nodes are complete and its arrivals are added by the  */
+/* launch that sums the interior rows.  Bitwise CeedOperatorApply, then           */
+/* CeedXHaloStart / Finish.  Recordable into a CeedXGraph.                        */
+CEED_EXTERN int CeedXOperatorApplyWithHalo(CeedOperator op, CeedVector in, CeedVector out,
+                                           CeedXHalo halo);
+/* Sum of entries [first, first + n) of a device vector over all ranks of the     */
+/* communicator, in place, on the Ceed's stream: the MPI_Allreduce behind VecDot  */
+/* and VecNorm (src/matops.c:292, the Krylov norms) with the scalars left on the  */
+/* device.  One rank (or no communicator): nothing happens.                       */
+CEED_EXTERN int CeedXCommAllReduce(Ceed ceed, CeedVector v, CeedInt first, CeedInt n);
 /* Diagnostic: how the last apply of a residual / Jacobian operator was        */
 /* launched.  out[0] segments (fused-kernel launches) of the apply, 1 = the    */
 /* serial form; out[1] streams they alternate between; out[2] k_assemble       */
 /* launches; out[3] elements of the last segment.                              */
+/* NOTE one device per process: the library caches device properties process-  */
+/* wide (one rank per GPU, as under mpirun / torchrun).                         */
 CEED_EXTERN int CeedXOperatorGetLaunchInfo(CeedOperator op, int out[4]);
 
 #endif /* CEED_MI355X_CEED_H */

@@ -1170,7 +1170,6 @@ int CeedXVectorAXPBYScalars(CeedVector y, CeedVector scalars, CeedInt ia, double
 int CeedXOperatorSetTiming(CeedOperator op, int enable) { (void)op; (void)enable; return 0; }
 int CeedXOperatorGetTiming(CeedOperator op, double *ms, int64_t *launches) { (void)op; *ms = 0; *launches = 0; return 0; }
 int CeedXOperatorGetLaunchInfo(CeedOperator op, int out[4]) { (void)op; out[0] = 1; out[1] = 1; out[2] = 0; out[3] = 0; return 0; }
-int CeedXOperatorGetGatedStats(CeedOperator op, long long out[5]) { (void)op; for (int i = 0; i < 5; i++) out[i] = 0; return 0; }
 /* Halo exchange: the oracle is a single-process CPU checker; the multi-rank tests exchange through torch.distributed
    (ceedpetscsolid_amd/halo.py, gloo).  Only the neighbour-free halo exists here. */
 struct CeedXHalo_private { int nneigh; };
@@ -1186,6 +1185,8 @@ int CeedXHaloCreate(Ceed ceed, CeedInt nneigh, const int *neigh_rank, const Ceed
 int CeedXHaloStart(CeedXHalo halo, CeedVector y) { (void)halo; (void)y; return 0; }
 int CeedXHaloFinish(CeedXHalo halo, CeedVector y) { (void)halo; (void)y; return 0; }
 int CeedXHaloDestroy(CeedXHalo *halo) { if (halo && *halo) { free(*halo); *halo = NULL; } return 0; }
+int CeedXOperatorApplyWithHalo(CeedOperator op, CeedVector in, CeedVector out, CeedXHalo halo) { (void)halo; return CeedOperatorApply(op, in, out, CEED_REQUEST_IMMEDIATE); }
+int CeedXCommAllReduce(Ceed ceed, CeedVector v, CeedInt first, CeedInt n) { (void)ceed; (void)v; (void)first; (void)n; return 0; }   /* one process */
 
 /* ---- assembled sparse operator (include/ceed.h, CeedXCsr*): plain CSR on the host ------------ */
 struct CeedXCsr_private {

@@ -23,7 +23,8 @@ import subprocess
 import sys
 import tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin"
+LLVM = "/opt/rocm/lib/llvm/bin"      # --llvm
+ARCH = "gfx950"                      # --arch
 TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 BAD_LDS = ("ds_read2_b64", "ds_write2_b64", "ds_read_b128", "ds_write_b128", "ds_read2st64_b64", "ds_write2st64_b64")
 
@@ -62,16 +63,17 @@ QF_NAMES = {2: "LinElas", 3: "HyperSSF", 4: "HyperSSdF", 5: "HyperFSF", 6: "Hype
 
 
 def short_name(mangled):
-    m = re.search(r"k_fused_pencilILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)E", mangled)
+    m = re.search(r"k_fused_pencilILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E", mangled)
     if not m:
         return None, 0, 0
-    P, Q, qf, geo, eo, fold = (int(x) for x in m.groups())
-    return f"k_fused_pencil<P={P},Q={Q},{QF_NAMES.get(qf, qf)},geo={geo},eo={eo}" + (",fold" if fold else "") + ">", Q, eo
+    P, Q, qf, geo = (int(x) for x in m.groups())
+    eo = 1 if 4 <= Q <= 7 else 0     # kernels.hpp, pencil_even_odd
+    return f"k_fused_pencil<P={P},Q={Q},{QF_NAMES.get(qf, qf)},geo={geo},eo={eo}>", Q, eo
 
 
 def instruction_counts(co):
     """{mangled name: {mnemonic: count}} from the disassembly."""
-    txt = run(f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", co)
+    txt = run(f"{LLVM}/llvm-objdump", "-d", f"--mcpu={ARCH}", co)
     out, cur = {}, None
     for line in txt.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
@@ -87,10 +89,14 @@ def instruction_counts(co):
 
 
 def main():
+    global LLVM, ARCH, TARGET
     ap = argparse.ArgumentParser()
     ap.add_argument("objects", nargs="+")
     ap.add_argument("--summary")
+    ap.add_argument("--arch", default=ARCH)
+    ap.add_argument("--llvm", default=LLVM)
     args = ap.parse_args()
+    LLVM, ARCH, TARGET = args.llvm, args.arch, f"hipv4-amdgcn-amd-amdhsa--{args.arch}"
     rows, bad = [], []
     with tempfile.TemporaryDirectory() as tmp:
         for obj in args.objects:
