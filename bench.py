@@ -36,7 +36,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from ceedpetscsolid_amd import ceed as cd  # noqa: E402
-from ceedpetscsolid_amd.halo import (HaloExchange, RcclHalo, checked_rccl_halo, interface_elements, part_box, part_cylinder,  # noqa: E402
+from ceedpetscsolid_amd.halo import (HaloBringUpError, HaloExchange, RcclHalo, checked_rccl_halo, interface_elements, part_box, part_cylinder,  # noqa: E402
                                      slab_box, slab_cylinder, virtual_world)
 from ceedpetscsolid_amd.mesh import reorder_elements_first  # noqa: E402
 from ceedpetscsolid_amd.harness import SolidApp  # noqa: E402
@@ -94,8 +94,10 @@ def own_floor_bytes(nelem: int, P: int, Q: int, lsize: int, state: bool) -> int:
 
 
 def cpu_baseline(args, nr, nth):
-    """The oracle (CPU restatement of the reference's /cpu/self path) on a bounded sample of the
-    same workload: a thin z-slab of the same cylinder, same degree / model / state."""
+    """The oracle (CPU restatement of the reference's /cpu/self path) on the FULL workload -- the same mesh, degree,
+    model and state, threaded over element chunks on the cores this job may use (>= 2 timed applies) -- plus a ONE-core
+    figure on a thin z-slab of the same cylinder (a full-size one-core apply would take minutes).  elasticity.c:755-764
+    is the metric: dofs / time of the operator apply."""
     import ctypes as C
     from ceedpetscsolid_amd.mesh import hollow_cylinder_mesh
     path = os.path.join(ROOT, "oracle", "liboracle_ceed.so")
@@ -103,25 +105,61 @@ def cpu_baseline(args, nr, nth):
         return None
     lib = cd.CeedLib(path)
     cores = host_cores()
-    lib.lib.OracleSetNumThreads(C.c_int(cores))
     orc = cd.Ceed(lib, "/cpu/self/oracle")
-    nz = args.cpu_sample_layers
-    mesh = hollow_cylinder_mesh(nr, nth, nz, z0=-5.0, z1=-5.0 + 10.0 * nz / args.nz)
-    p = SolidProblem(orc, mesh, args.degree, args.problem, nu=args.nu, E=args.E, bc_sides=[998], multigrid="none")
-    n = p.lsize()
-    X, Y = orc.vector(n), orc.vector(n)
-    X.set_array(p.smooth_state(0.1)); p.form_residual(X, Y)
-    X.set_array(coord_hash_vector(p.levels[p.fine].dofmap.node_coords, p.levels[p.fine].mask))
-    p.apply_jacobian(p.fine, X, Y)  # warm-up
-    t0 = time.perf_counter(); k = 0
-    while True:
-        p.apply_jacobian(p.fine, X, Y); k += 1
-        el = time.perf_counter() - t0
-        if el > args.cpu_seconds or k >= 5000:
-            break
-    return {"value": 1e-6 * p.n_free() * k / el, "unit": "MDoF/s", "cores": cores, "kind": "port",
-            "sample": f"{mesh.nelem}-element z-slab ({nr}x{nth}x{nz}) of the same cylinder, degree {args.degree} "
-                      f"{args.problem}, {k} applies in {el:.1f} s, oracle with OpenMP element chunks"}
+
+    def rate(mesh, threads, seconds, min_applies, bc):
+        lib.lib.OracleSetNumThreads(C.c_int(threads))
+        p = SolidProblem(orc, mesh, args.degree, args.problem, nu=args.nu, E=args.E, bc_sides=bc, multigrid="none")
+        n = p.lsize()
+        X, Y = orc.vector(n), orc.vector(n)
+        X.set_array(p.smooth_state(0.1)); p.form_residual(X, Y)
+        X.set_array(coord_hash_vector(p.levels[p.fine].dofmap.node_coords, p.levels[p.fine].mask))
+        p.apply_jacobian(p.fine, X, Y)  # warm-up
+        t0 = time.perf_counter(); k = 0
+        while True:
+            p.apply_jacobian(p.fine, X, Y); k += 1
+            el = time.perf_counter() - t0
+            if (el > seconds and k >= min_applies) or k >= 5000:
+                break
+        out = (1e-6 * p.n_free() * k / el, k, el, mesh.nelem)
+        p.destroy()
+        return out
+
+    full = hollow_cylinder_mesh(nr, nth, args.nz)
+    v, k, el, ne = rate(full, cores, args.cpu_seconds, 2, [998, 999])
+    nz1 = args.cpu_sample_layers
+    slab = hollow_cylinder_mesh(nr, nth, nz1, z0=-5.0, z1=-5.0 + 10.0 * nz1 / args.nz)
+    v1, k1, el1, ne1 = rate(slab, 1, 0.4 * args.cpu_seconds, 2, [998])
+    return {"value": v, "unit": "MDoF/s", "cores": cores, "kind": "port", "sample": "full",
+            "detail": f"the whole workload ({ne} elements, degree {args.degree} {args.problem}): {k} applies in {el:.1f} s, oracle with OpenMP element chunks on {cores} threads",
+            "one_core": {"value": v1, "unit": "MDoF/s", "cores": 1,
+                         "sample": f"{ne1}-element z-slab ({nr}x{nth}x{nz1}) of the same cylinder, {k1} applies in {el1:.1f} s"}}
+
+
+def valu_issue(kernel_name: str, ngroups: int, seconds: float):
+    """Share of the f64 vector pipe's issue slots the fused kernel's instruction stream needs: VALU instructions of one
+    element group (static count from the build's disassembly, tools/isa_guard.py) x groups x 4 cycles (a wave64 VALU
+    instruction occupies its SIMD's 16 lanes for 4 cycles) / (1024 SIMDs x 2.4 GHz) / time.  The kernel's binding limit
+    (VERDICT r2, weak 3): 1.0 would be a vector pipe that never idles."""
+    import re
+    m = re.match(r"fused_grad<P=(\d+),Q=(\d+),(\w+)>", kernel_name)
+    if not m:
+        return None
+    P, Q, qf = int(m.group(1)), int(m.group(2)), m.group(3)
+    geo = 2 if "affine elements" in kernel_name else (1 if "recomputed" in kernel_name else 0)
+    want = f"k_fused_pencil<P={P},Q={Q},{qf},geo={geo},eo={1 if 4 <= Q <= 7 else 0}>"
+    for path in (os.path.join(ROOT, "ceedpetscsolid_amd", "csrc", "build", "isa_summary.txt"), os.path.join(ROOT, "profiles", "r03_isa_summary.txt")):
+        if not os.path.exists(path):
+            continue
+        for line in open(path):
+            f = line.rstrip("\n").split("\t")
+            if f[0] == want:
+                valu = int(f[11])
+                t_valu = valu * ngroups * 4 / (1024 * 2.4e9)
+                return {"valu_instructions_per_group": valu, "groups": ngroups, "valu_issue_us": 1e6 * t_valu,
+                        "valu_issue_frac": t_valu / seconds, "of": "the whole apply's device time (kernel_avg_us), k_assemble included", "source": os.path.relpath(path, ROOT),
+                        "assumes": "4 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz (spec clock)"}
+    return None
 
 
 def main():
@@ -145,6 +183,9 @@ def main():
     ap.add_argument("--halo", default="rccl", choices=["rccl", "torch"],
                     help="N > 1 on the nccl backend: rccl = the library's own exchange (CeedXHalo*: pack kernel, ncclSend/ncclRecv group on "
                          "its stream, unpack-add kernel); torch = torch.distributed point-to-point + index ops (also the gloo rehearsal)")
+    ap.add_argument("--no-strict-halo", action="store_true",
+                    help="N > 1 with --halo rccl: if the library's exchange cannot be brought up, time the torch exchange instead of "
+                         "exiting non-zero (the line then says \"halo_path\": \"torch-fallback\"); strict is the default")
     ap.add_argument("--nu", type=float, default=0.3)
     ap.add_argument("--E", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -159,6 +200,8 @@ def main():
                          "split-phase apply exactly as at N > 1, and the library's RCCL exchange on a one-rank communicator whose "
                          "neighbour lists have the TRUE sizes, sent to this rank itself (everything one GPU can tell about the N-GPU regime)")
     ap.add_argument("--of", type=int, default=8, metavar="N")
+    ap.add_argument("--cold-idle-s", type=float, default=1.0,
+                    help="idle time before the COLD timing of --steps applies (reported as ms_per_step_cold; 0: skipped)")
     ap.add_argument("--calibrate-traffic", action="store_true",
                     help="also launch k_axpby over a 1 GiB vector (known byte count) for PMC calibration")
     args = ap.parse_args()
@@ -223,9 +266,18 @@ def main():
     # the exchange itself: behind the C ABI over RCCL on a GPU node; the torch path on gloo (single-GPU rehearsal) or on request
     use_rccl = world > 1 and args.halo == "rccl" and dist.get_backend() == "nccl"
     chalo, halo_note = None, None
-    if use_rccl:   # brought up with a time limit and checked against the torch exchange; falls back on every rank if it fails on any
-        chalo, halo_note = checked_rccl_halo(ceed, halo, coord_hash_vector(dofmap.node_coords, np.zeros(n, dtype=np.uint8)), dev)
+    halo_path = None if world == 1 and not emu else ("rccl" if (use_rccl or emu) else "torch")
+    if use_rccl:   # brought up with a time limit and checked against the torch exchange; a failure ends the run (exit 4) unless --no-strict-halo
+        try:
+            chalo, halo_note = checked_rccl_halo(ceed, halo, coord_hash_vector(dofmap.node_coords, np.zeros(n, dtype=np.uint8)), dev,
+                                                 strict=not args.no_strict_halo)
+        except HaloBringUpError as e:
+            print(f"[bench] rank {rank}: {e}; not timing a fallback (--no-strict-halo would)", file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            sys.exit(4)
         use_rccl = chalo is not None
+        if not use_rccl:
+            halo_path = "torch-fallback"
     if emu:   # one-rank communicator, every neighbour list exchanged with this rank itself
         chalo, halo_note, use_rccl = RcclHalo(ceed, halo, emulate_self=True), "emulated rank: self-exchange of the true neighbour lists", True
     free = (mask == 0).astype(np.float64)
@@ -257,6 +309,19 @@ def main():
             prob.apply_jacobian(prob.fine, X, Y)   # ApplyJacobian_Ceed: k_fused_pencil + k_assemble on `stream`
             chalo.add(Y) if chalo else halo.add(yt)   # interface sum (no-op at N = 1)
 
+    # cold figure (reported beside the warm one): the first --steps applies after a 1 s idle, before any pre-warm -- the
+    # clock / power transient after idle makes them ~8 % slower (profiles/r02_dispatch_series.txt)
+    ms_cold = None
+    if args.cold_idle_s > 0:
+        step(); torch.cuda.synchronize()        # one apply first: transpose maps, flags and streams are set up by it
+        time.sleep(args.cold_idle_s)
+        if world > 1:
+            dist.barrier()
+        tc = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        ms_cold = 1e3 * (time.perf_counter() - tc) / args.steps
     if args.calibrate_traffic:   # known traffic for tools/collect_traffic.py: reads 2 GiB, writes 1 GiB
         import ctypes as C
         ncal = 2 ** 27
@@ -325,8 +390,10 @@ def main():
             "value": 1e-6 * n_global * args.steps / elapsed,
             "unit": "MDoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "halo_path": halo_path,   # N > 1: "rccl" = the library's CeedXHalo* (pack kernel, RCCL group, unpack-add); "torch" on request / on gloo; "torch-fallback" only with --no-strict-halo
             "prewarm_ms": args.prewarm_ms, "prewarm_steps": prewarm_steps,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step_cold": ms_cold,   # the same loop right after a 1 s idle, before the pre-warm (rank 0's clock; not max-reduced)
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"config 4: {args.problem}, hollow cylinder {args.nr}x{args.nth}x{args.nz} = "
@@ -357,7 +424,8 @@ def main():
                          "kernels": ("k_fused_pencil (gather..physics..shell E-vector, interior nodes straight to y) + k_assemble (deterministic per-node sum of the shared nodes): "
                                      + ("the two launches of one CeedOperatorApply, timed together with hipEvents on their stream" if li["segments"] <= 1 else
                                         "one CeedOperatorApply = %d segments of consecutive elements, each a fused launch followed by the k_assemble of the rows it completes, alternating between %d streams so that the rows of a segment are summed beside the next fused kernel; kernel_avg_us is the hipEvent time of the WHOLE apply on the operator's stream (fork to join), not a sum of per-kernel durations, which overlap (profiles/README.md)" % (li["segments"], li["streams"]))),
-                         "peak_measured_copy_GBs": 6290.0},
+                         "peak_measured_copy_GBs": 6290.0,
+                         "valu_issue": valu_issue(op.kernel_name, (mesh.nelem + (2 if Q == 5 else (1 if Q >= 6 else (4 if Q >= 3 else 8))) - 1) // (2 if Q == 5 else (1 if Q >= 6 else (4 if Q >= 3 else 8))), avg_s)},
         }
         if emu:
             out["emulated_rank"] = {"rank": args.emulate_rank, "of": args.of, "lead_elements": int(lead.sum()),

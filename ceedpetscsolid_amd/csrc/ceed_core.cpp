@@ -69,6 +69,7 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   CeedOptions &o = c->opt;
   o.recompute_geo = !env_is("CEED_MI355X_GEO", "0");
   o.direct_interior = !env_is("CEED_MI355X_DIRECT", "0");
+  o.affine_geo = !env_is("CEED_MI355X_AFFINE", "0");
   if (env_is("CEED_MI355X_ASSEMBLE", "serial")) o.pipe_segments = 0;
   else { const int ps = env_int("CEED_MI355X_PIPE_SEGMENTS", 0); o.pipe_segments = ps >= 2 ? std::min(ps, 16) : -1; }
   o.pipe_blocks = env_int("CEED_MI355X_PIPE_BLOCKS", 0);
@@ -181,7 +182,11 @@ extern "C" int CeedXGraphDestroy(CeedXGraph *graph) {
   return 0;
 }
 
-void vec_drop_geo(CeedVector v) { if (v->geo) (void)hipFree(v->geo); v->geo = nullptr; v->geo_nelem = v->geo_Q = 0; }
+void vec_drop_geo(CeedVector v) {
+  if (v->geo) (void)hipFree(v->geo);
+  if (v->geo_aff) (void)hipFree(v->geo_aff);
+  v->geo = v->geo_aff = nullptr; v->geo_nelem = v->geo_Q = 0;
+}
 
 int ceed_need_evec(Ceed c, size_t len) {
   if (c->evec_len >= len) return 0;

@@ -12,15 +12,13 @@ struct CeedXCsr_private {
   uint32_t *d_rowptr = nullptr, *d_cols = nullptr, *d_slotptr = nullptr, *d_perm = nullptr, *d_unit_slot = nullptr,
            *d_diag_slot = nullptr;
   double *d_vals = nullptr;
-  // values as a fixed linear combination of another matrix's values (CeedXCsrSetSource / CeedXCsrUpdate)
-  CeedXCsr src = nullptr;
-  uint32_t *d_termptr = nullptr, *d_term_slot = nullptr;
-  double *d_term_w = nullptr, *d_gj = nullptr;
+  // values = product of two other matrices' values on this pattern (CeedXCsrCreateProduct / CeedXCsrUpdate)
+  CeedXCsr src = nullptr, src2 = nullptr;
+  double *d_gj = nullptr;
   int *d_info = nullptr;
   bool dense = false;       // full pattern, columns ascending: vals is a row-major nrows x nrows matrix
-  int refs = 1;             // a source is kept alive by the matrices combined from it
+  int refs = 1;             // an operand is kept alive by the products formed from it
   std::vector<int> h_rowptr, h_cols;      // host copy of the pattern (operand of CeedXCsrCreateProduct)
-  std::vector<double> h_vals;             // host copy of FIXED values (CeedXCsrCreateRect with values), else empty
 };
 template <class T>
 static int csr_upload(uint32_t **dst, const std::vector<T> &v) {
@@ -113,7 +111,6 @@ extern "C" int CeedXCsrCreateRect(Ceed ceed, CeedInt nrows, CeedInt ncols, const
   A->ceed = ceed; ceed_ref(ceed);
   A->nrows = nrows; A->ncols = ncols; A->nnz = nnz; A->dense = dense;
   A->h_rowptr.assign(rowptr, rowptr + nrows + 1); A->h_cols.assign(cols, cols + nnz);
-  if (vals) A->h_vals.assign(vals, vals + nnz);
   CHK(csr_upload(&A->d_rowptr, rp)); CHK(csr_upload(&A->d_cols, cl)); CHK(csr_upload(&A->d_diag_slot, diag));
   HIPCHK(hipMalloc((void **)&A->d_vals, sizeof(double) * (nnz ? nnz : 1)));
   if (vals && nnz) HIPCHK(hipMemcpy(A->d_vals, vals, sizeof(double) * nnz, hipMemcpyHostToDevice));
@@ -121,43 +118,43 @@ extern "C" int CeedXCsrCreateRect(Ceed ceed, CeedInt nrows, CeedInt ncols, const
   *csr = A;
   return 0;
 }
-// C = L R where one operand has FIXED values (given to CeedXCsrCreateRect) and the other is `variable`: its values are
-// read by every CeedXCsrUpdate(C).  The pattern of C and, per entry, the list of (slot of the variable operand, weight)
-// terms are worked out here once, row by row (Gustavson), terms of an entry ordered by slot: vals[s] = sum_k w[k] * V[slot[k]].
-// dense != 0: C gets the full pattern (entries without a term stay zero), for CeedXCsrInvertDenseSPD.
+// C = L R on fixed patterns.  The pattern of C is worked out here once, row by row (Gustavson, columns ascending; row
+// blocks on host threads); CeedXCsrUpdate(C) then recomputes its VALUES on the device from the operands' current values
+// (k_csr_spgemm: no term lists, nothing but the three patterns in memory).  `variable` names the operand whose values
+// change between updates (0 left, 1 right) -- kept for the callers' documentation: both are read at every update.
+// dense != 0: C gets the full pattern (entries the product does not reach stay zero), for CeedXCsrInvertDenseSPD.
+// R's columns must be sorted within each row (they are for every matrix this library or scipy builds).
 extern "C" int CeedXCsrCreateProduct(CeedXCsr Lm, CeedXCsr Rm, int variable, int dense, CeedXCsr *csr) {
   if (!Lm || !Rm || Lm == Rm || (variable != 0 && variable != 1)) return ceed_error("CeedXCsrCreateProduct: bad operands");
   if (Lm->ncols != Rm->nrows) return ceed_error("CeedXCsrCreateProduct: %d columns times %d rows", Lm->ncols, Rm->nrows);
-  CeedXCsr V = variable == 0 ? Lm : Rm, F = variable == 0 ? Rm : Lm;
-  if ((int)F->h_vals.size() != F->nnz) return ceed_error("CeedXCsrCreateProduct: the fixed operand must carry values from CeedXCsrCreateRect");
   const int nrows = Lm->nrows, ncols = Rm->ncols;
   if (dense && nrows != ncols) return ceed_error("CeedXCsrCreateProduct: a dense result must be square");
-  struct Term { int col, slot; double w; };
-  // row blocks in parallel on the host (the lists of a 150 000-row level are ~3e8 terms: 17 s on one thread), stitched in row order
-  struct Part { std::vector<uint32_t> len, cl, tcount, ts; std::vector<double> tw; };
+  for (int j = 0; j < Rm->nrows; j++)
+    for (int b = Rm->h_rowptr[j] + 1; b < Rm->h_rowptr[j + 1]; b++)
+      if (Rm->h_cols[b] <= Rm->h_cols[b - 1]) return ceed_error("CeedXCsrCreateProduct: the right operand's columns are not sorted in row %d", j);
+  struct Part { std::vector<uint32_t> len, cl; };
   const int nthreads = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, nrows / 256 + 1}));
   std::vector<Part> parts((size_t)nthreads);
   auto work = [&](int t) {
     Part &pt = parts[(size_t)t];
     const int r0 = (int)((long long)nrows * t / nthreads), r1 = (int)((long long)nrows * (t + 1) / nthreads);
-    std::vector<Term> row;
+    std::vector<int> mark((size_t)ncols, -1);
+    std::vector<uint32_t> row;
     for (int i = r0; i < r1; i++) {
       row.clear();
-      for (int a = Lm->h_rowptr[i]; a < Lm->h_rowptr[i + 1]; a++) {
-        const int j = Lm->h_cols[a];
-        for (int b = Rm->h_rowptr[j]; b < Rm->h_rowptr[j + 1]; b++)
-          row.push_back(variable == 0 ? Term{Rm->h_cols[b], a, F->h_vals[b]} : Term{Rm->h_cols[b], b, F->h_vals[a]});
+      if (dense) { for (int c = 0; c < ncols; c++) row.push_back((uint32_t)c); }
+      else {
+        for (int a = Lm->h_rowptr[i]; a < Lm->h_rowptr[i + 1]; a++) {
+          const int j = Lm->h_cols[a];
+          for (int b = Rm->h_rowptr[j]; b < Rm->h_rowptr[j + 1]; b++) {
+            const int c = Rm->h_cols[b];
+            if (mark[(size_t)c] != i) { mark[(size_t)c] = i; row.push_back((uint32_t)c); }
+          }
+        }
+        std::sort(row.begin(), row.end());
       }
-      std::sort(row.begin(), row.end(), [](const Term &x, const Term &y) { return x.col != y.col ? x.col < y.col : x.slot < y.slot; });
-      size_t k = 0;
-      uint32_t n_in_row = 0;
-      for (int c = 0; dense ? c < ncols : k < row.size(); c++) {
-        if (!dense) c = row[k].col;
-        uint32_t cnt = 0;
-        while (k < row.size() && row[k].col == c) { pt.ts.push_back((uint32_t)row[k].slot); pt.tw.push_back(row[k].w); k++; cnt++; }
-        pt.cl.push_back((uint32_t)c); pt.tcount.push_back(cnt); n_in_row++;
-      }
-      pt.len.push_back(n_in_row);
+      pt.cl.insert(pt.cl.end(), row.begin(), row.end());
+      pt.len.push_back((uint32_t)row.size());
     }
   };
   {
@@ -166,22 +163,17 @@ extern "C" int CeedXCsrCreateProduct(CeedXCsr Lm, CeedXCsr Rm, int variable, int
     work(0);
     for (auto &x : th) x.join();
   }
-  size_t tot_e = 0, tot_t = 0;
-  for (const Part &pt : parts) { tot_e += pt.cl.size(); tot_t += pt.ts.size(); }
-  if (tot_t >= 0x7FFFFFFFull || tot_e >= 0x7FFFFFFFull) return ceed_error("CeedXCsrCreateProduct: more than 2^31 product terms");
-  std::vector<uint32_t> rp((size_t)nrows + 1, 0u), cl, tp(1, 0u), ts;
-  std::vector<double> tw;
-  std::vector<int> h_cols;
-  cl.reserve(tot_e); h_cols.reserve(tot_e); tp.reserve(tot_e + 1); ts.reserve(tot_t); tw.reserve(tot_t);
+  size_t tot_e = 0;
+  for (const Part &pt : parts) tot_e += pt.cl.size();
+  if (tot_e >= 0x7FFFFFFFull) return ceed_error("CeedXCsrCreateProduct: more than 2^31 entries");
+  std::vector<uint32_t> rp((size_t)nrows + 1, 0u), cl;
+  cl.reserve(tot_e);
   {
     int i = 0;
     for (Part &pt : parts) {
-      for (uint32_t L : pt.len) { rp[(size_t)i + 1] = rp[(size_t)i] + L; i++; }
-      for (size_t e = 0; e < pt.cl.size(); e++) { cl.push_back(pt.cl[e]); h_cols.push_back((int)pt.cl[e]); tp.push_back(tp.back() + pt.tcount[e]); }
-      ts.insert(ts.end(), pt.ts.begin(), pt.ts.end());
-      tw.insert(tw.end(), pt.tw.begin(), pt.tw.end());
-      Part().len.swap(pt.len); std::vector<uint32_t>().swap(pt.ts); std::vector<double>().swap(pt.tw);
-      std::vector<uint32_t>().swap(pt.cl); std::vector<uint32_t>().swap(pt.tcount);
+      for (uint32_t len : pt.len) { rp[(size_t)i + 1] = rp[(size_t)i] + len; i++; }
+      cl.insert(cl.end(), pt.cl.begin(), pt.cl.end());
+      std::vector<uint32_t>().swap(pt.cl); std::vector<uint32_t>().swap(pt.len);
     }
   }
   const int nnz = (int)cl.size();
@@ -189,16 +181,14 @@ extern "C" int CeedXCsrCreateProduct(CeedXCsr Lm, CeedXCsr Rm, int variable, int
   for (int r = 0; r < nrows; r++)
     for (uint32_t k = rp[r]; k < rp[r + 1]; k++) if ((int)cl[k] == r) diag[r] = k;
   CeedXCsr A = new CeedXCsr_private;
-  A->ceed = V->ceed; ceed_ref(A->ceed);
+  A->ceed = Lm->ceed; ceed_ref(A->ceed);
   A->nrows = nrows; A->ncols = ncols; A->nnz = nnz; A->dense = dense != 0;
-  A->h_rowptr.assign(rp.begin(), rp.end()); A->h_cols.swap(h_cols);
+  A->h_rowptr.assign(rp.begin(), rp.end()); A->h_cols.assign(cl.begin(), cl.end());
   CHK(csr_upload(&A->d_rowptr, rp)); CHK(csr_upload(&A->d_cols, cl)); CHK(csr_upload(&A->d_diag_slot, diag));
-  CHK(csr_upload(&A->d_termptr, tp)); CHK(csr_upload(&A->d_term_slot, ts));
-  HIPCHK(hipMalloc((void **)&A->d_term_w, sizeof(double) * (tw.size() ? tw.size() : 1)));
-  if (!tw.empty()) HIPCHK(hipMemcpy(A->d_term_w, tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMalloc((void **)&A->d_vals, sizeof(double) * (nnz ? nnz : 1)));
   HIPCHK(hipMemset(A->d_vals, 0, sizeof(double) * (nnz ? nnz : 1)));
-  A->src = V; V->refs++;
+  A->src = Lm; Lm->refs++;
+  A->src2 = Rm; Rm->refs++;
   *csr = A;
   return 0;
 }
@@ -211,8 +201,10 @@ extern "C" int CeedXCsrGetPattern(CeedXCsr A, CeedInt *nrows, CeedInt *ncols, Ce
   return 0;
 }
 extern "C" int CeedXCsrUpdate(CeedXCsr A) {
-  if (!A->src) return ceed_error("CeedXCsrUpdate: not a product (CeedXCsrCreateProduct)");
-  HIPCHK(launch_csr_combine(A->d_termptr, A->d_term_slot, A->d_term_w, A->src->d_vals, A->d_vals, A->nnz, A->ceed->stream));
+  if (!A->src || !A->src2) return ceed_error("CeedXCsrUpdate: not a product (CeedXCsrCreateProduct)");
+  CeedXCsr Lm = A->src, Rm = A->src2;
+  HIPCHK(launch_csr_spgemm(Lm->d_rowptr, Lm->d_cols, Lm->d_vals, Rm->d_rowptr, Rm->d_cols, Rm->d_vals, A->d_rowptr, A->d_cols, A->d_vals,
+                           A->nrows, A->ceed->stream));
   return 0;
 }
 extern "C" int CeedXCsrGetValues(CeedXCsr A, CeedVector v) {
@@ -245,13 +237,14 @@ extern "C" int CeedXCsrDestroy(CeedXCsr *csr) {
   *csr = nullptr;
   if (--A->refs > 0) return 0;        // still the source of another matrix: freed with the last of those
   (void)hipStreamSynchronize(A->ceed->stream);
-  for (uint32_t *p : {A->d_rowptr, A->d_cols, A->d_slotptr, A->d_perm, A->d_unit_slot, A->d_diag_slot, A->d_termptr, A->d_term_slot})
+  for (uint32_t *p : {A->d_rowptr, A->d_cols, A->d_slotptr, A->d_perm, A->d_unit_slot, A->d_diag_slot})
     if (p) (void)hipFree(p);
-  for (double *p : {A->d_vals, A->d_term_w, A->d_gj}) if (p) (void)hipFree(p);
+  for (double *p : {A->d_vals, A->d_gj}) if (p) (void)hipFree(p);
   if (A->d_info) (void)hipFree(A->d_info);
-  CeedXCsr src = A->src;
+  CeedXCsr src = A->src, src2 = A->src2;
   ceed_unref(A->ceed);
   delete A;
   if (src) (void)CeedXCsrDestroy(&src);
+  if (src2) (void)CeedXCsrDestroy(&src2);
   return 0;
 }

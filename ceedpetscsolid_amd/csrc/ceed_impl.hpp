@@ -32,6 +32,7 @@ int ceed_error(const char *fmt, ...);
 struct CeedOptions {
   bool recompute_geo = true;     // CEED_MI355X_GEO=0: the fused kernels read qdata instead of recomputing it from the element maps
   bool direct_interior = true;   // CEED_MI355X_DIRECT=0: element-interior nodes go through the E-vector like the shared ones
+  bool affine_geo = true;        // CEED_MI355X_AFFINE=0: all-affine meshes take the general per-point recompute too
   // restriction transpose of large whole applies: pipelined in segments over two streams
   int pipe_segments = -1;        // 0: never (CEED_MI355X_ASSEMBLE=serial); -1: chosen per launch; >= 2: CEED_MI355X_PIPE_SEGMENTS
   int pipe_blocks = 0;           // CEED_MI355X_PIPE_BLOCKS: cap on the workgroups of a k_assemble that runs beside a fused kernel
@@ -97,6 +98,7 @@ struct CeedVector_private {
   // are kept here ([nelem][GEO_NCOEF], device).  The fused kernels then recompute the geometric factors instead of
   // reading them (FusedGradArgs::geo).  Dropped by any other write to the vector.
   double *geo = nullptr;
+  double *geo_aff = nullptr;   // set when EVERY element is affine: [nelem][GEO_NAFF] constant factors (FusedGradArgs::geo_aff)
   int geo_nelem = 0, geo_Q = 0;
   double geo_qref[cps::MAXN1D] = {0}, geo_qwt[cps::MAXN1D] = {0};
 };
@@ -186,6 +188,7 @@ struct CeedOperator_private {
   cps::BasisTables tables;
   double eo[6][cps::EO_TAB];          // even-odd forms of the six 1-D products (fused operators with pencil_even_odd(Q))
   std::string kernel_name;
+  int geo_mode = 0;                   // last fused launch: 0 qdata read, 1 recomputed per point, 2 affine elements
   // Dirichlet flags
   uint32_t *d_off_flagged_in = nullptr, *d_off_flagged_out = nullptr;  // same array unless transfer
   unsigned char *d_node_flags = nullptr;        // per node of the restriction's transpose map

@@ -415,6 +415,7 @@ static int fused_prepare(CeedOperator op, CeedVector in, CeedVector out, bool ad
       same_rule = qv->geo_qref[i] == ai.basis->qref1d[i] && qv->geo_qwt[i] == ai.basis->qweight1d[i];
     if (same_rule && c->opt.recompute_geo) {
       a.geo = qv->geo;
+      a.geo_aff = qv->geo_aff;
       for (int i = 0; i < ai.basis->Q1d; i++) { a.qref[i] = qv->geo_qref[i]; a.qwt[i] = qv->geo_qwt[i]; }
     }
   }
@@ -458,6 +459,7 @@ static int fused_launch(CeedOperator op, const FusedApply &F, int e0, int ne, in
   if (e == hipErrorInvalidValue && !**kname)
     return ceed_error("no fused kernel instantiated for P=%d Q=%d QFunction %s", F.b->P1d, F.b->Q1d, op->qf->name.c_str());
   HIPCHK(e);
+  op->geo_mode = F.a.geo_aff && F.a.geo ? 2 : (F.a.geo ? 1 : 0);
   return 0;
 }
 static int assemble_rows(const FusedApply &F, int row0, int nrows, hipStream_t s, int max_blocks = 0, const HaloUnpackArgs *un = nullptr) {
@@ -632,6 +634,17 @@ static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool 
       HIPCHK(hipMalloc((void **)&out->geo, sizeof(double) * GEO_NCOEF * (size_t)a.nelem));
       HIPCHK(launch_geo_coeffs(a.off_x, px, out->geo, a.nelem, s));
       out->geo_nelem = a.nelem; out->geo_Q = x.basis->Q1d;
+      if (op->ceed->opt.affine_geo) {   // all elements affine (box meshes)?  then dXdx and det J are per-ELEMENT constants
+        int *d_cnt = nullptr, cnt = 1;
+        HIPCHK(hipMalloc((void **)&out->geo_aff, sizeof(double) * GEO_NAFF * (size_t)a.nelem));
+        HIPCHK(hipMalloc((void **)&d_cnt, sizeof(int)));
+        HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(int), s));
+        HIPCHK(launch_geo_affine(out->geo, out->geo_aff, a.nelem, d_cnt, s));
+        HIPCHK(hipMemcpyAsync(&cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));      // set-up time only
+        (void)hipFree(d_cnt);
+        if (cnt != 0) { (void)hipFree(out->geo_aff); out->geo_aff = nullptr; }   // a mixed mesh takes the general recompute everywhere
+      }
       for (int i = 0; i < x.basis->Q1d && i < MAXN1D; i++) { out->geo_qref[i] = x.basis->qref1d[i]; out->geo_qwt[i] = x.basis->qweight1d[i]; }
     }
     break;
@@ -774,7 +787,13 @@ extern "C" int CeedOperatorLinearAssembleDiagonal(CeedOperator op, CeedVector as
 // ---------------------------------------------------------------------------
 // extensions
 // ---------------------------------------------------------------------------
-extern "C" int CeedXOperatorGetKernelName(CeedOperator op, const char **name) { *name = op->kernel_name.c_str(); return 0; }
+// the instantiation of the last apply; for the fused operators also how the geometric factors were obtained
+extern "C" int CeedXOperatorGetKernelName(CeedOperator op, const char **name) {
+  if (op->plan == PLAN_FUSED_GRAD && !op->kernel_name.empty() && op->kernel_name.find(" [") == std::string::npos)
+    op->kernel_name += op->geo_mode == 2 ? " [affine elements: dXdx per element]" : (op->geo_mode == 1 ? " [dXdx recomputed per point]" : " [qdata read]");
+  *name = op->kernel_name.c_str();
+  return 0;
+}
 
 static int make_flagged(CeedElemRestriction r, const unsigned char *mask, CeedInt lsize, uint32_t **dev) {
   if (lsize < r->lsize) return ceed_error("Dirichlet mask shorter than the L-vector");

@@ -224,9 +224,11 @@ constexpr int pencil_minw(int) { return CPS_PENCIL_MINW; }
 #ifndef CPS_PENCIL_NSET_BIGQ
 #define CPS_PENCIL_NSET_BIGQ 1   // Q >= 6: the split-table passes keep all rounds' pencils in VGPRs; a second q-point set
 #endif                           // would push the hyperFS tangent past 256 VGPRs (26 spilled to scratch)
-// GEO: the geometric factors are recomputed per point from the element's trilinear map (FusedGradArgs::geo) instead of read.
-// The 1-D tables are applied in even-odd form wherever that form exists (pencil_even_odd(Q): 4 <= Q <= 7).
-template <int P, int Q, int QF, bool GEO>
+// GEO = 1: the geometric factors are recomputed per point from the element's trilinear map (FusedGradArgs::geo) instead of
+// read; GEO = 2: every element of the mesh is AFFINE (a parallelepiped: the box meshes of configs 1, 2 and 5), dXdx and
+// det J are constants of the element (FusedGradArgs::geo_aff, ten doubles) and only the weight varies from point to point;
+// GEO = 0: qdata is read.  The 1-D tables are applied in even-odd form wherever that form exists (pencil_even_odd(Q)).
+template <int P, int Q, int QF, int GEO>
 __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const BasisTables tab_, const FusedGradArgs a) {
   static_assert(offsetof(BasisTables, interp) == 0 && offsetof(BasisTables, colo) == 8 * MAXN1D * MAXN1D &&
                 offsetof(BasisTables, grad) == 16 * MAXN1D * MAXN1D, "kernarg layout of the tables");
@@ -252,7 +254,8 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
 
   __shared__ __attribute__((aligned(16))) double slab[E * SE + G::GEO];
   const ldsp_t lds0 = (lds_double *)slab;
-  constexpr bool geo = GEO;   // recompute the geometric factors per point instead of reading qdata (FusedGradArgs::geo set)
+  constexpr bool geo = GEO != 0;   // the geometric factors are not read from qdata
+  constexpr int NCO = GEO == 2 ? GEO_NAFF : GEO_NCOEF;   // doubles per element kept in LDS for them
   const int lane = threadIdx.x & 63;
 #ifndef CPS_NO_STAGGER
   // Staggered start (large launches only: every wave has at least four groups): the persistent waves of a launch begin
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     const int t = min(lane + 64 * r, E * Q3 - 1), el = t / Q3, q = t % Q3;
     pqi[r] = (uint32_t)((q % Q) * 8) | ((uint32_t)(((q / Q) % Q) * 8) << 8) | ((uint32_t)((q / (Q * Q)) * 8) << 16) | ((uint32_t)el << 24);
   }
-  constexpr int oGC = E * SE * 8, oGT = oGC + E * GEO_NCOEF * 8;   // byte offsets of the coefficient / table areas
+  constexpr int oGC = E * SE * 8, oGT = oGC + E * GEO_NCOEF * 8;   // byte offsets of the coefficient / table areas (sized for GEO = 1)
   if (geo && lane < 2 * Q) {   // 1-D points then weights (written once; the LDS queue orders it before any read)
     const auto kp = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(BasisTables);
     const double v = lane < Q ? ((kargs_t)kp)->qref[lane] : ((kargs_t)kp)->qwt[lane - Q];
@@ -399,16 +402,16 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     const bool more = grp_nx < gend;  // wave-uniform
     const int g_nx = more ? grp_nx : grp;
     load_offsets(g_nx, off_nx);
-    constexpr int RG = (E * GEO_NCOEF + 63) / 64;
-    double gcoef[RG];    // this group's element-map coefficients, lane + 64 i; into LDS right before the physics
+    constexpr int RG = (E * NCO + 63) / 64;
+    double gcoef[RG];    // this group's element-map coefficients (or affine factors), lane + 64 i; into LDS right before the physics
     if (geo) {
       const kargs_t ka = kargs_fresh<KA>();
       const int nlive = nlive_of(ka->nelem, grp);
-      const double *gb = ka->geo + (size_t)(ka->elem_begin + grp * E) * GEO_NCOEF;
+      const double *gb = (GEO == 2 ? ka->geo_aff : ka->geo) + (size_t)(ka->elem_begin + grp * E) * NCO;
 #pragma unroll
       for (int i = 0; i < RG; i++) {
-        const int t = min(lane + 64 * i, E * GEO_NCOEF - 1), el = min(t / GEO_NCOEF, nlive - 1);
-        gcoef[i] = gb[(uint32_t)(el * GEO_NCOEF + t % GEO_NCOEF)];
+        const int t = min(lane + 64 * i, E * NCO - 1), el = min(t / NCO, nlive - 1);
+        gcoef[i] = gb[(uint32_t)(el * NCO + t % NCO)];
       }
     }
 
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     if (geo) {
 #pragma unroll
       for (int i = 0; i < RG; i++)
-        if (lane + 64 * i < E * GEO_NCOEF)
+        if (lane + 64 * i < E * NCO)
           *(ldsp_t)((volatile __attribute__((address_space(3))) char *)lds0 + oGC + (lane + 64 * i) * 8) = gcoef[i];
     }
     // ---- physics: point owners, one round at a time; ug[d*3+c] from (BX, A, BZ), dv back in place ----
@@ -494,7 +497,15 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
         ug[6] = lds_rd<oBZ + 0 * BC>(aPt[r]); ug[7] = lds_rd<oBZ + 1 * BC>(aPt[r]); ug[8] = lds_rd<oBZ + 2 * BC>(aPt[r]);
       }
       double qdl[10];
-      if (geo) {  // SetupGeo (common.h:47-101) recomputed at this point from the element's trilinear map
+      if constexpr (GEO == 2) {  // affine element: dXdx and det J are the element's, the weight the point's (common.h:47-101)
+        const uint32_t pk = pqi[r];
+        const auto lb = (volatile __attribute__((address_space(3))) char *)lds0;
+        const ldsp_t ti = (ldsp_t)(lb + oGT + (pk & 0xFFu)), tj = (ldsp_t)(lb + oGT + ((pk >> 8) & 0xFFu)),
+                     tk = (ldsp_t)(lb + oGT + ((pk >> 16) & 0xFFu)), cf = (ldsp_t)(lb + oGC + (pk >> 24) * (GEO_NAFF * 8));
+        qdl[0] = ti[Q] * tj[Q] * tk[Q] * cf[0];
+#pragma unroll
+        for (int c = 1; c < 10; c++) qdl[c] = cf[c];
+      } else if (geo) {  // SetupGeo (common.h:47-101) recomputed at this point from the element's trilinear map
         const uint32_t pk = pqi[r];
         const auto lb = (volatile __attribute__((address_space(3))) char *)lds0;
         const ldsp_t ti = (ldsp_t)(lb + oGT + (pk & 0xFFu)), tj = (ldsp_t)(lb + oGT + ((pk >> 8) & 0xFFu)),
@@ -678,8 +689,9 @@ hipError_t launch_fused_pencil_t(const BasisTables &t, const FusedGradArgs &a, h
   int grid = resident;
   if (a.wave_groups > 0) grid = ((ngroups + a.wave_groups - 1) / a.wave_groups + 7) / 8 * 8;
   if (grid > ngroups) grid = ngroups;
-  if (a.geo) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, true>), dim3(grid), dim3(64), 0, s, t, a);
-  else hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, false>), dim3(grid), dim3(64), 0, s, t, a);
+  if (a.geo && a.geo_aff) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, 2>), dim3(grid), dim3(64), 0, s, t, a);
+  else if (a.geo) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, 1>), dim3(grid), dim3(64), 0, s, t, a);
+  else hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, 0>), dim3(grid), dim3(64), 0, s, t, a);
   return hipGetLastError();
 }
 

@@ -66,6 +66,9 @@ struct FusedGradArgs {
   const double *geo;          // if set, [nelem][GEO_NCOEF] trilinear-map coefficients of the elements (launch_geo_coeffs);
                                // the kernel then RECOMPUTES qdata = SetupGeo(x) at every point (27 FMAs + adjugate) instead
                                // of streaming its 80 bytes per point from HBM
+  const double *geo_aff;      // set (with geo) only when EVERY element is affine: [nelem][GEO_NAFF] = {det J, dXdx[9]} of the
+                               // element (launch_geo_affine) -- the kernel then multiplies det J by the point's weight and
+                               // reads the nine factors instead of forming J, its adjugate and a reciprocal at every point
   double qref[MAXN1D], qwt[MAXN1D];  // 1-D quadrature points / weights of the geometry (used with geo)
   // Even-odd form of the 1-D tables (pencil_even_odd(Q)).  The tables of symmetric point sets are
   // centro-symmetric (interp: M[N-1-i][K-1-j] = M[i][j]) or centro-antisymmetric (derivatives), so with
@@ -143,6 +146,11 @@ struct TransferArgs {
 // on [-1,1]^3: the 7 coefficients per component that the Jacobian d x / d xi needs, [c][m] per element.
 constexpr int GEO_NCOEF = 21;
 hipError_t launch_geo_coeffs(const uint32_t *off_x, const double *xcoord, double *geo, int nelem, hipStream_t s);
+// Affine elements (the 12 coefficients of the xi eta ... terms vanish to 1e-14 of the linear ones: parallelepipeds).  For
+// every element {det J, dXdx[9]} -- SetupGeo's output at ANY of its points but for the quadrature weight -- goes to
+// aff[e][GEO_NAFF]; *n_not_affine (device, zeroed by the caller) counts the elements that are NOT affine.
+constexpr int GEO_NAFF = 10;
+hipError_t launch_geo_affine(const double *geo, double *aff, int nelem, int *n_not_affine, hipStream_t s);
 
 struct SetupGeoArgs {
   const uint32_t *off_x;  // [nelem][8]
@@ -226,8 +234,9 @@ hipError_t launch_csr_sum(const uint32_t *slotptr, const uint32_t *perm, const d
 hipError_t launch_csr_spmv(const uint32_t *rowptr, const uint32_t *cols, const double *vals, const double *x, double *y,
                            int nrows, hipStream_t s);
 hipError_t launch_csr_diag(const uint32_t *diag_slot_of_row, const double *vals, double *d, int nrows, hipStream_t s);
-hipError_t launch_csr_combine(const uint32_t *termptr, const uint32_t *src_slot, const double *w, const double *src, double *vals,
-                              int nnz, hipStream_t s);
+hipError_t launch_csr_spgemm(const uint32_t *l_rowptr, const uint32_t *l_cols, const double *l_vals, const uint32_t *r_rowptr,
+                             const uint32_t *r_cols, const double *r_vals, const uint32_t *c_rowptr, const uint32_t *c_cols, double *c_vals,
+                             int nrows, hipStream_t s);   // C = L R on fixed patterns (R's columns sorted within each row)
 hipError_t launch_dense_spd_inverse(double *A, int n, double *scratch /* 1024 doubles */, int *info, hipStream_t s);
 
 // Vector / restriction utilities.

@@ -36,24 +36,35 @@ __global__ void k_csr_diag(const uint32_t *diag_slot_of_row, const double *vals,
   }
 }
 
-// vals[s] = sum_k w[k] * src[src_slot[k]] over the terms of slot s (the host sorts the terms by slot): a sparse product
-// with one fixed factor and a fixed result pattern (T = A P, A_c = P^T T of the aggregation hierarchy).  Eight lanes per
-// slot: the 10-30 terms of a slot are read in 64-byte pieces, partial sums per lane in ascending k, then a fixed
-// three-step butterfly -- the same order every time.
-__global__ __launch_bounds__(256) void k_csr_combine(const uint32_t *termptr, const uint32_t *src_slot, const double *w,
-                                                    const double *src, double *vals, int nnz) {
-  const int sub = threadIdx.x & 7;
-  const size_t ngroups = ((size_t)gridDim.x * blockDim.x) >> 3;
-  const size_t niter = ((size_t)nnz + ngroups - 1) / ngroups;          // same trip count for all lanes (shuffles inside)
-  size_t s = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-  for (size_t it = 0; it < niter; it++, s += ngroups) {
-    double a = 0.;
-    if (s < (size_t)nnz)
-      for (uint32_t k = termptr[s] + sub, e = termptr[s + 1]; k < e; k += 8) a += w[k] * src[src_slot[k]];
-    a += __shfl_xor(a, 4, 64);
-    a += __shfl_xor(a, 2, 64);
-    a += __shfl_xor(a, 1, 64);
-    if (sub == 0 && s < (size_t)nnz) vals[s] = a;
+// C = L R on FIXED patterns, without term lists: one wave per row r of C; lane l owns the entries s = rowptr[r] + l + 64 m of
+// that row and forms  C[r, c] = sum_k L[r, k] R[k, c]  by walking L's row (wave-uniform loads) and looking c up in R's row
+// k by binary search (R's columns are sorted within a row; the rows hit are small and shared by the 64 lanes, so the
+// probes are cache hits).  The k order is the order of L's row: every entry is summed the same way every time.  Entries
+// of C's pattern that the product does not reach (a full "dense" pattern) come out as zeros.
+// Round 2 held, per entry of C, the list of (slot, weight) terms -- 12 bytes per scalar multiplication: 36 M terms on
+// config 3's mesh, 4.7e8 (5.6 GB, 6 s of host set-up) on the 44 928-hex reference cylinder, out of reach at config 4's
+// 99 000.  This form needs the patterns only.
+__global__ __launch_bounds__(256) void k_csr_spgemm(const uint32_t *l_rowptr, const uint32_t *l_cols, const double *l_vals,
+                                                   const uint32_t *r_rowptr, const uint32_t *r_cols, const double *r_vals,
+                                                   const uint32_t *c_rowptr, const uint32_t *c_cols, double *c_vals, int nrows) {
+  const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  for (int r = wave; r < nrows; r += nw) {
+    const uint32_t k0 = l_rowptr[r], k1 = l_rowptr[r + 1];
+    for (uint32_t s = c_rowptr[r] + lane; s < c_rowptr[r + 1]; s += 64) {
+      const uint32_t c = c_cols[s];
+      double acc = 0.;
+      for (uint32_t k = k0; k < k1; k++) {
+        const uint32_t j = l_cols[k];
+        uint32_t lo = r_rowptr[j], hi = r_rowptr[j + 1];
+        if (lo == hi || c < r_cols[lo] || c > r_cols[hi - 1]) continue;
+        while (hi - lo > 1) {                       // invariant: r_cols[lo] <= c
+          const uint32_t mid = (lo + hi) >> 1;
+          if (r_cols[mid] <= c) lo = mid; else hi = mid;
+        }
+        if (r_cols[lo] == c) acc += l_vals[k] * r_vals[lo];
+      }
+      c_vals[s] = acc;
+    }
   }
 }
 
@@ -162,10 +173,13 @@ hipError_t launch_csr_diag(const uint32_t *diag_slot_of_row, const double *vals,
   hipLaunchKernelGGL(k_csr_diag, grid_for((size_t)nrows, 256), dim3(256), 0, s, diag_slot_of_row, vals, d, nrows);
   return hipGetLastError();
 }
-hipError_t launch_csr_combine(const uint32_t *termptr, const uint32_t *src_slot, const double *w, const double *src, double *vals,
-                              int nnz, hipStream_t s) {
-  if (nnz <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_csr_combine, grid_for((size_t)nnz, 32), dim3(256), 0, s, termptr, src_slot, w, src, vals, nnz);
+hipError_t launch_csr_spgemm(const uint32_t *l_rowptr, const uint32_t *l_cols, const double *l_vals, const uint32_t *r_rowptr,
+                             const uint32_t *r_cols, const double *r_vals, const uint32_t *c_rowptr, const uint32_t *c_cols, double *c_vals,
+                             int nrows, hipStream_t s) {
+  if (nrows <= 0) return hipSuccess;
+  const unsigned blocks = (unsigned)std::min<size_t>(((size_t)nrows + 3) / 4, 16384);     // four rows (waves) per workgroup
+  hipLaunchKernelGGL(k_csr_spgemm, dim3(blocks), dim3(256), 0, s, l_rowptr, l_cols, l_vals, r_rowptr, r_cols, r_vals, c_rowptr, c_cols,
+                     c_vals, nrows);
   return hipGetLastError();
 }
 // scratch: GJ * GJ doubles; info: one int, zero on entry, 1-based index of the first non-positive pivot otherwise

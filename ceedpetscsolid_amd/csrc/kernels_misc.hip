@@ -81,6 +81,33 @@ hipError_t launch_geo_coeffs(const uint32_t *off_x, const double *xcoord, double
   return hipGetLastError();
 }
 
+__global__ void k_geo_affine(const double *geo, double *aff, int nelem, int *n_not_affine) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nelem) return;
+  const double *g = geo + (size_t)e * GEO_NCOEF;
+  double lin = 0., nonlin = 0., Jg[9];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+#pragma unroll
+    for (int m = 0; m < 7; m++) {
+      const double v = fabs(g[c * 7 + m]);
+      if (m < 3) lin = fmax(lin, v); else nonlin = fmax(nonlin, v);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; d++) Jg[d * 3 + c] = g[c * 7 + d];   // J[d][c] = d x_c / d xi_d, constant on the element
+  }
+  if (nonlin > 1e-14 * lin) atomicAdd(n_not_affine, 1);
+  double qd[10];
+  qf_setup_geo_rcp(Jg, 1.0, qd);     // {det J, dXdx}: the same arithmetic as the per-point recompute
+#pragma unroll
+  for (int i = 0; i < GEO_NAFF; i++) aff[(size_t)e * GEO_NAFF + i] = qd[i];
+}
+hipError_t launch_geo_affine(const double *geo, double *aff, int nelem, int *n_not_affine, hipStream_t s) {
+  if (nelem <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_geo_affine, dim3((unsigned)((nelem + 255) / 256)), dim3(256), 0, s, geo, aff, nelem, n_not_affine);
+  return hipGetLastError();
+}
+
 template <int Q>
 static hipError_t setup_geo_t(const BasisTables &t, const SetupGeoArgs &a, hipStream_t s) {
   using G = Geom<Q>;

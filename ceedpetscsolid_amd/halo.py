@@ -159,10 +159,29 @@ class RcclHalo:
     HaloExchange's neighbour lists; the communicator is bootstrapped like any NCCL communicator (rank 0's unique id,
     distributed here with torch.distributed -- an MPI_Bcast in the reference's world)."""
 
-    def __init__(self, ceed, halo: "HaloExchange", emulate_self: bool = False):
+    @staticmethod
+    def unique_id(ceed, halo: "HaloExchange"):
+        """Rank 0's communicator id on every rank (collective over the torch group; MPI_Bcast in the reference's world).
+        Call it from the thread that owns the process group: the worker thread of checked_rccl_halo must not."""
+        import ctypes as C
+        ident = [None]
+        if halo.rank == 0:
+            try:
+                buf = C.create_string_buffer(128)
+                ceed.L.chk(ceed.L.lib.CeedXCommGetUniqueId(ceed.h, buf))
+                ident = [buf.raw]
+            except Exception as e:   # noqa: BLE001 -- the other ranks are waiting in the broadcast: tell them
+                ident = [RuntimeError(f"CeedXCommGetUniqueId failed on rank 0: {e!r}")]
+        dist.broadcast_object_list(ident, src=0, group=halo.group)
+        if isinstance(ident[0], Exception):
+            raise ident[0]            # on EVERY rank
+        return ident[0]
+
+    def __init__(self, ceed, halo: "HaloExchange", emulate_self: bool = False, ident: Optional[bytes] = None):
         """emulate_self (bench.py --emulate-rank): a ONE-rank communicator; every neighbour list is sent to and received
         from this rank itself -- the launches, buffer sizes and stream hand-overs of the real exchange on a single GPU (the
-        sums it produces are those of a vector folded onto itself, not of the partitioned problem)."""
+        sums it produces are those of a vector folded onto itself, not of the partitioned problem).
+        ident: the communicator id from unique_id() (taken here, collectively, if not given)."""
         import ctypes as C
         self.ceed, self.L = ceed, ceed.L
         self.h = C.c_void_p()
@@ -175,13 +194,9 @@ class RcclHalo:
                 self.L.chk(lib.CeedXCommInit(ceed.h, C.c_int(1), C.c_int(0), C.c_char_p(buf.raw)))
                 ceed._comm_ready = True
         elif halo.world > 1 and not getattr(ceed, "_comm_ready", False):
-            ident = [None]
-            if halo.rank == 0:
-                buf = C.create_string_buffer(128)
-                self.L.chk(lib.CeedXCommGetUniqueId(ceed.h, buf))
-                ident = [buf.raw]
-            dist.broadcast_object_list(ident, src=0, group=halo.group)
-            self.L.chk(lib.CeedXCommInit(ceed.h, C.c_int(halo.world), C.c_int(halo.rank), C.c_char_p(ident[0])))
+            if ident is None:
+                ident = RcclHalo.unique_id(ceed, halo)
+            self.L.chk(lib.CeedXCommInit(ceed.h, C.c_int(halo.world), C.c_int(halo.rank), C.c_char_p(ident)))
             ceed._comm_ready = True
         nn = len(halo.neigh)
         ranks = (C.c_int * max(nn, 1))(*[0 if emulate_self else n.rank for n in halo.neigh])
@@ -205,19 +220,40 @@ class RcclHalo:
             self.h = None
 
 
-def checked_rccl_halo(ceed, halo: "HaloExchange", probe: np.ndarray, device, timeout_s: float = 120.0):
-    """Bring the library's exchange (RcclHalo) up in a worker thread with a time limit and CHECK it against the torch
-    exchange of the same test vector before it is used.  Collective.  Returns (RcclHalo or None, note): on any failure --
-    exception, time-out, wrong sums -- on ANY rank, every rank gets None and uses the torch exchange."""
+class HaloBringUpError(RuntimeError):
+    """The library's exchange could not be brought up on this job (raised on EVERY rank)."""
+
+
+def checked_rccl_halo(ceed, halo: "HaloExchange", probe: np.ndarray, device, timeout_s: float = 120.0, strict: bool = True):
+    """Bring the library's exchange (RcclHalo) up and CHECK it against the torch exchange of the same test vector before
+    it is used.  Collective.  Returns (RcclHalo, note).
+
+    The communicator id is broadcast HERE, on the calling thread (the one that owns the process group); only
+    ncclCommInitRank and the first exchange -- the calls that can hang when a peer is missing -- run in a worker thread
+    under a time limit, with the rank's device made current first (a new thread starts on device 0).
+    * time-out: the worker is stuck inside a collective and nothing sound can be done beside it in this process -- the
+      note is printed and the process EXITS with status 3 (a fresh launch is the retry).
+    * exception or wrong sums on any rank: with strict (the default) HaloBringUpError on every rank; without, every rank
+      gets (None, note) and may use the torch exchange -- the caller must then SAY so (bench.py: "halo_path")."""
+    import sys
     import threading
     from . import ceed as cd
     box = {}
     n = probe.size
+    dev = torch.device(device)
+    try:
+        ident = RcclHalo.unique_id(ceed, halo) if halo.world > 1 and not getattr(ceed, "_comm_ready", False) else None
+    except RuntimeError as e:       # raised on every rank alike
+        if strict:
+            raise HaloBringUpError(str(e))
+        return None, f"{e}; fell back to torch.distributed point-to-point"
 
     def bring_up():
         try:
-            h = RcclHalo(ceed, halo)
-            t = torch.from_numpy(probe).to(device)
+            if dev.type == "cuda":
+                torch.cuda.set_device(dev)
+            h = RcclHalo(ceed, halo, ident=ident)
+            t = torch.from_numpy(probe).to(dev)
             V = ceed.vector(n)
             V.set_device_pointer(t.data_ptr())
             h.add(V)
@@ -231,12 +267,15 @@ def checked_rccl_halo(ceed, halo: "HaloExchange", probe: np.ndarray, device, tim
 
     th = threading.Thread(target=bring_up, daemon=True)
     th.start(); th.join(timeout=timeout_s)
-    ref = torch.from_numpy(probe).to(device)
-    halo.add(ref)                      # the torch exchange of the same vector: EVERY rank, whatever its thread did
-    note, good, h = None, 0.0, None
     if th.is_alive():
-        note = f"CeedXHalo* bring-up timed out after {timeout_s:.0f} s"
-    elif "err" in box:
+        print(f"[halo] CeedXHalo* bring-up timed out after {timeout_s:.0f} s on rank {halo.rank}: exiting (status 3); "
+              f"launch the job again", file=sys.stderr, flush=True)
+        import os
+        os._exit(3)
+    ref = torch.from_numpy(probe).to(dev)
+    halo.add(ref)                      # the torch exchange of the same vector: every rank (no worker is alive beside it)
+    note, good, h = None, 0.0, None
+    if "err" in box:
         note = f"CeedXHalo* failed to initialise ({box['err']})"
     else:
         err = float((box["got"] - ref).abs().max().item()) / max(float(ref.abs().max().item()), 1e-300)
@@ -245,15 +284,16 @@ def checked_rccl_halo(ceed, halo: "HaloExchange", probe: np.ndarray, device, tim
         else:
             note = f"CeedXHalo* sums differ from the torch exchange (rel {err:.2e})"
     if halo.world > 1:
-        flag = torch.tensor([good], device=device)
+        flag = torch.tensor([good], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=halo.group)
         good_all = flag.item() != 0.0
     else:
         good_all = good != 0.0
     if not good_all:
-        if h is not None:
-            note = "CeedXHalo* failed on another rank"
-        return None, (note or "CeedXHalo* unavailable") + "; fell back to torch.distributed point-to-point"
+        note = (note or "CeedXHalo* failed on another rank")
+        if strict:
+            raise HaloBringUpError(note)
+        return None, note + "; fell back to torch.distributed point-to-point"
     return h, "CeedXHalo* checked against the torch exchange on a test vector at start-up"
 
 

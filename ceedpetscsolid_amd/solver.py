@@ -76,7 +76,7 @@ class Vec:
 
 class NewtonPMG:
     def __init__(self, prob: SolidProblem, clamp: Optional[Dict[int, dict]] = None, mms: bool = False, forcing=None,
-                 halo=None, smooth_its: int = 3, coarse_rtol: float = 1e-3, coarse_maxit: int = 200,
+                 halo=None, rccl="auto", lead_elements: int = 0, smooth_its: int = 3, coarse_rtol: float = 1e-3, coarse_maxit: int = 200,
                  coarse: str = "cg", coarse_cheb_its: int = 40, coarse_cheb_ratio: float = 100.0, graph: bool = False,
                  amg_smooth_its: int = 3, amg_smooth_ratio: float = 10.0, amg_max_coarse_dofs: int = 1500, amg_coarse_cycles: int = 1,
                  ksp_rtol: float = 1e-10, snes_rtol: float = 1e-8, snes_maxit: int = 50, verbose: bool = False):
@@ -130,10 +130,26 @@ class NewtonPMG:
         if halo is not None and halo[-1].world > 1:
             if len(halo) != len(prob.levels):
                 raise ValueError("one HaloExchange per multigrid level expected")
-            if self.graph:
-                raise ValueError("graph=True is a single-rank feature (torch.distributed calls cannot be recorded)")
             self.halos = list(halo)
         self.halo = self.halos[-1] if self.halos else None
+        # the library's exchange per level (halo.RcclHalo), or None: torch.distributed point-to-point + index ops
+        self.rhalos = None
+        if self.halos:
+            if isinstance(rccl, (list, tuple)):
+                self.rhalos = list(rccl)
+            elif rccl == "auto":
+                import torch.distributed as dist
+                if dist.is_initialized() and dist.get_backend(self.halos[-1].group) == "nccl" and self.halos[-1].device.type == "cuda":
+                    from .halo import RcclHalo
+                    self.rhalos = [RcclHalo(self.ceed, h) for h in self.halos]
+            if self.rhalos is not None and len(self.rhalos) != len(prob.levels):
+                raise ValueError("one RcclHalo per multigrid level expected")
+            if self.graph and self.rhalos is None:
+                raise ValueError("graph=True on several ranks needs the library's exchange (torch.distributed calls cannot be recorded)")
+            if self.rhalos is not None and lead_elements > 0:      # split-phase Jacobians: exchange under the interior elements
+                for lv, level in enumerate(prob.levels):
+                    level.opJacob.set_overlap_split(int(lead_elements), self.halos[lv].interface_dof_mask())
+        self._split = bool(self.rhalos) and lead_elements > 0
         mk = lambda lv: self._vec(prob.lsize(lv), lv)
         self.w = [{k: mk(lv) for k in ("x", "b", "r", "d", "t", "dinv", "z")} for lv in range(self.nlev)]
         self.emax = [1.0] * self.nlev
@@ -187,6 +203,13 @@ class NewtonPMG:
         r = C.c_double()
         lv = self.nlev - 1 if lv is None else lv
         wv = self.weights[lv].h if self.weights[lv] is not None else None
+        if self.rhalos:      # the sum over the ranks on the device (ncclAllReduce on the Ceed's stream), ONE read at the end
+            if self._scal is None:
+                self._scal = self.ceed.vector(8 + 2 * 16)
+            lib, chk = self.L.lib, self.L.chk
+            chk(lib.CeedXVectorDotTo(x.h, y.h, wv, self._scal.h, 7))
+            chk(lib.CeedXCommAllReduce(self.ceed.h, self._scal.h, 7, 1))
+            return float(self._scal.to_numpy()[7])
         self.L.chk(self.L.lib.CeedXVectorDot(x.h, y.h, wv, C.byref(r)))
         v = r.value
         if self.halos:
@@ -227,7 +250,9 @@ class NewtonPMG:
 
     def _halo_sum(self, lv, vec):
         """Interface sum of an operator output at level lv (the DMLocalToGlobal(ADD_VALUES) of matops.c:57)."""
-        if self.halos:
+        if self.rhalos:               # the library's exchange, on the Ceed's stream: nothing to synchronise, nothing to re-wrap
+            self.rhalos[lv].add(vec)
+        elif self.halos:
             if vec.t.device.type == "cuda":
                 self.ceed.synchronize()
             self.halos[lv].add(vec.t)
@@ -246,6 +271,10 @@ class NewtonPMG:
         if lv == 0 and self.asm is not None:
             self.asm.apply(x, y)
             self.stats.coarse_spmv += 1
+        elif self._split:             # ApplyLocalCeedOp + DMLocalToGlobal(ADD_VALUES) in one library call, exchange overlapped
+            self.p.levels[lv].opJacob.apply_with_halo(x, y, self.rhalos[lv])
+            self.stats.jacobian_applies += 1
+            return
         else:
             self.p.apply_jacobian(lv, x, y)
             self.stats.jacobian_applies += 1
@@ -315,7 +344,7 @@ class NewtonPMG:
             # largest eigenvalue of D^-1 A: 10 steps of Jacobi-preconditioned CG on the noisy right-hand side and
             # the largest eigenvalue of its Lanczos tridiagonal -- what KSPChebyshevEstEig does (elasticity.c:546-549).
             # (A plain power iteration from the same vector was 2x low after 12 steps on the config-3 mesh.)
-            alphas, betas = self._lanczos_host(lv, 10) if self.halos else self._lanczos_device(lv, 10)
+            alphas, betas = self._lanczos_host(lv, 10) if (self.halos and not self.rhalos) else self._lanczos_device(lv, 10)
             k = len(alphas)
             T = np.zeros((max(k, 1), max(k, 1)))
             for j in range(k):
@@ -359,15 +388,22 @@ class NewtonPMG:
         self.copy(r, self._x0[lv])
         self.pmult(z, r, w["dinv"]); self.copy(pv, z)
         one, neg = C.c_double(1.0), C.c_double(-1.0)
-        chk(lib.CeedXVectorDotTo(r.h, z.h, None, sc.h, 0))
+        wv = self.weights[lv].h if self.weights[lv] is not None else None      # several ranks: every dof counts once
+        many = bool(self.rhalos)
+
+        def dot_to(a, b, slot):
+            chk(lib.CeedXVectorDotTo(a.h, b.h, wv, sc.h, slot))
+            if many:                 # summed over the ranks where it lies: the scalar never leaves the device
+                chk(lib.CeedXCommAllReduce(self.ceed.h, sc.h, slot, 1))
+        dot_to(r, z, 0)
         for j in range(steps):
             rz, rz_new, ja, jb = (0, 3, 8 + 2 * j, 9 + 2 * j) if j % 2 == 0 else (3, 0, 8 + 2 * j, 9 + 2 * j)
             self.A(lv, pv, Ap)
-            chk(lib.CeedXVectorDotTo(pv.h, Ap.h, None, sc.h, 1))
+            dot_to(pv, Ap, 1)
             chk(lib.CeedXScalarDivide(sc.h, ja, rz, 1, one))                           # alpha_j = rz / pAp (0 on breakdown)
             chk(lib.CeedXVectorAXPBYScalars(r.h, sc.h, ja, neg, Ap.h, -1, one))         # r -= alpha Ap
             self.pmult(z, r, w["dinv"])
-            chk(lib.CeedXVectorDotTo(r.h, z.h, None, sc.h, rz_new))
+            dot_to(r, z, rz_new)
             chk(lib.CeedXScalarDivide(sc.h, jb, rz_new, rz, one))                       # beta_j = rz_new / rz
             chk(lib.CeedXVectorAXPBYScalars(pv.h, sc.h, -1, one, z.h, jb, one))         # p = z + beta p
         v = sc.to_numpy()

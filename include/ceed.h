@@ -331,12 +331,13 @@ CEED_EXTERN int CeedXCsrDestroy(CeedXCsr *csr);
 /*  - CeedXCsrCreateRect: an nrows x ncols matrix; `vals` fixed (prolongation */
 /*    P, restriction P^T) or NULL for zeros;                                  */
 /*    CeedXCsrApply takes x of ncols, y of nrows.                             */
-/*  - CeedXCsrCreateProduct / CeedXCsrUpdate: C = left * right where one      */
-/*    operand carries FIXED values (from CeedXCsrCreateRect) and the other is */
-/*    `variable` (0: left, 1: right): CeedXCsrUpdate(C) recomputes C from the */
-/*    variable operand's current values.  The pattern of C and the term list  */
-/*    of every entry are worked out once, on the host; the update is one      */
-/*    launch that sums each entry's terms in a fixed order (deterministic).   */
+/*  - CeedXCsrCreateProduct / CeedXCsrUpdate: C = left * right on FIXED       */
+/*    patterns.  The pattern of C is worked out once, on the host; every      */
+/*    update recomputes the values on the device from the operands' current   */
+/*    values -- one launch, a wave per row, each entry summed in the order of */
+/*    the left operand's row (deterministic); no term lists are kept.         */
+/*    `variable` (0 left, 1 right) names the operand that changes between      */
+/*    updates; the right operand's columns must be sorted within a row.       */
 /*    Two of these form the Galerkin product T = A P, A_c = P^T T each Newton */
 /*    step.  dense != 0 gives C the full pattern (for the inverse below).     */
 /*  - CeedXCsrGetPattern: sizes and the host copy of the pattern (borrowed).  */

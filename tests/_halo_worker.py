@@ -69,3 +69,31 @@ def run(rank, world, initfile, outdir, mode):
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), y=y.numpy(), keys=lv.dofmap.node_keys, nglob=nglob, dot=dot,
              nshared=halo.n_shared_dofs, mask=lv.mask, x=x)
     dist.destroy_process_group()
+
+
+def run_bring_up(rank, world, initfile, outdir, strict):
+    """The start-up check of the library's exchange (halo.checked_rccl_halo) where the library HAS no communicator (the
+    oracle): every rank must take the same way out -- HaloBringUpError when strict, the torch exchange otherwise -- and the
+    process group must still work afterwards (no thread left inside a collective)."""
+    from ceedpetscsolid_amd import ceed as cd
+    from ceedpetscsolid_amd.halo import HaloBringUpError, HaloExchange, checked_rccl_halo, part_cylinder
+    from ceedpetscsolid_amd.mesh import build_dofmap
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    ceed = cd.Ceed(cd.CeedLib(os.path.join(ROOT, "oracle", "liboracle_ceed.so")), "/cpu/self/oracle")
+    mesh = part_cylinder(rank, world, 2, 6, 4)
+    dm = build_dofmap(mesh, 2)
+    halo = HaloExchange(mesh, dm, device="cpu")
+    probe = coord_field(dm.node_coords, np.zeros(dm.lsize))
+    outcome = None
+    try:
+        got, note = checked_rccl_halo(ceed, halo, probe, "cpu", timeout_s=30.0, strict=bool(strict))
+        outcome = ("fallback", got is None, note)
+    except HaloBringUpError as e:
+        outcome = ("raised", True, str(e))
+    y = torch.from_numpy(probe.copy())
+    halo.add(y)                                  # the group is still usable
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    np.savez(os.path.join(outdir, f"bring{rank}.npz"), kind=outcome[0], ok=outcome[1], note=outcome[2], total=float(t.item()),
+             changed=float(np.abs(y.numpy() - probe).max()))
+    dist.destroy_process_group()

@@ -235,7 +235,7 @@ def test_full_size_matches_oracle(oracle, oracle_lib, gpu, which):
         x = np.random.default_rng(4).uniform(-1, 1, n)
         xa, xb = vec_pair(pa, pb, n, x)
         pa.apply_jacobian(pa.fine, xa, ya); pb.apply_jacobian(pb.fine, xb, yb)
-        assert pb.levels[pb.fine].opJacob.kernel_name.endswith("/pencil")
+        assert "/pencil" in pb.levels[pb.fine].opJacob.kernel_name
         assert rel_err(yb.to_numpy(), ya.to_numpy()) < TOL
     finally:
         oracle_lib.lib.OracleSetNumThreads(C.c_int(1))
@@ -417,6 +417,15 @@ def test_halo_exchange_through_rccl_on_one_gpu(product_lib):
     counts = (C.c_int * 3)(*[a.size for a in lists])
     ptrs = (C.POINTER(C.c_int) * 3)(*[a.ctypes.data_as(C.POINTER(C.c_int)) for a in lists])
     h = C.c_void_p()
+    # error returns of the constructor free what they had built: a neighbour outside the communicator,
+    # a negative entry in the LAST list (everything before it already allocated) -- and a good call still works afterwards
+    with pytest.raises(cd.CeedError):
+        L.chk(L.lib.CeedXHaloCreate(ceed.h, 3, (C.c_int * 3)(0, 1, 0), counts, ptrs, C.byref(h)))
+    bad = lists[1].copy(); bad[-1] = -5
+    with pytest.raises(cd.CeedError):
+        L.chk(L.lib.CeedXHaloCreate(ceed.h, 2, ranks, (C.c_int * 2)(lists[0].size, bad.size),
+                                    (C.POINTER(C.c_int) * 2)(lists[0].ctypes.data_as(C.POINTER(C.c_int)), bad.ctypes.data_as(C.POINTER(C.c_int))), C.byref(h)))
+    assert not h
     L.chk(L.lib.CeedXHaloCreate(ceed.h, 3, ranks, counts, ptrs, C.byref(h)))
     Y = ceed.vector(n).set_array(y0)
     want = y0.copy()
@@ -685,6 +694,50 @@ def test_recomputed_geometry_equals_stored_qdata(gpu, product_lib, problem):
             outs.append(res)
         for a, b in zip(*outs):
             assert rel_err(a, b) < 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("problem", ["linElas", "hyperSS", "hyperFS"])
+def test_affine_elements_take_the_per_element_factors(gpu, oracle, product_lib, problem):
+    """On a mesh whose elements are ALL affine (parallelepipeds: the cube of config 2, the boxes of configs 1 and 5) dXdx and
+    det J are constants of an element: the SetupGeo operator finds that out (12 vanishing map coefficients per element), and
+    the fused kernels then read ten numbers per element instead of forming J, its adjugate and a reciprocal at every point
+    (qfunctions/common.h:47-101 is the arithmetic either way).  Same results as the general per-point recompute
+    (CEED_MI355X_AFFINE=0) and as the oracle on sheared, stretched boxes, every level; a mesh with ONE non-affine element
+    takes the general path everywhere."""
+    general = _ceed_with_env(product_lib, "CEED_MI355X_AFFINE", "0")
+    shear = np.array([[1.0, 0.3, -0.2], [0.1, 0.7, 0.25], [-0.15, 0.2, 1.4]])
+    def sheared(nx, ny, nz):
+        m = box_mesh(nx, ny, nz)
+        m.coords = m.coords @ shear.T + np.array([0.3, -0.1, 0.2])
+        return m
+    mixed = sheared(3, 3, 2)
+    mixed.coords = mixed.coords.copy()
+    mixed.coords[0] += np.array([0.05, -0.03, 0.02])         # one corner moved: its element is no parallelepiped any more
+    for mesh, degree, want in ((sheared(3, 2, 3), 4, "affine elements"), (sheared(2, 2, 1), 6, "affine elements"),
+                               (sheared(5, 3, 2), 2, "affine elements"), (sheared(4, 3, 3), 1, "affine elements"),
+                               (mixed, 3, "recomputed per point")):
+        outs = []
+        for c in (gpu, general, oracle):
+            p = SolidProblem(c, mesh, degree, problem, nu=0.3, E=2.0, bc_sides=[1])
+            n = p.lsize()
+            X, R = c.vector(n), c.vector(n)
+            X.set_array(p.smooth_state(0.1)); p.form_residual(X, R)
+            res = [R.to_numpy()]
+            for lv in range(len(p.levels)):
+                nl = p.lsize(lv)
+                x = c.vector(nl).set_array(np.random.default_rng(7 + lv).uniform(-1, 1, nl))
+                y = c.vector(nl)
+                p.apply_jacobian(lv, x, y)
+                res.append(y.to_numpy())
+            outs.append(res)
+            if c is gpu:
+                assert want in p.levels[p.fine].opJacob.kernel_name, p.levels[p.fine].opJacob.kernel_name
+            if c is general:
+                assert "recomputed per point" in p.levels[p.fine].opJacob.kernel_name
+        for a, b, o in zip(*outs):
+            assert rel_err(a, b) < 1e-13
+            assert rel_err(a, o) < 1e-10
 
 
 @pytest.mark.gpu

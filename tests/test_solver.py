@@ -271,3 +271,63 @@ def test_eigenvalue_estimate_with_device_scalars_equals_host_path_on_oracle(orac
 @pytest.mark.gpu
 def test_eigenvalue_estimate_with_device_scalars_equals_host_path_on_device(gpu):
     lanczos_paths_agree(gpu, 1e-12)
+
+
+@pytest.mark.gpu
+def test_solver_interface_sums_and_dots_go_through_the_library(product_lib):
+    """ONE halo mechanism for everything.  With the library's exchange (halo.RcclHalo per level) the
+    solver's operator outputs -- Jacobian, residual, transfers, diagonal -- are summed over the interface by CeedXHalo* and its
+    dots by CeedXCommAllReduce, nothing through torch.  On ONE GPU: an emulated rank of a 4-rank cylinder (real sub-mesh
+    and neighbour lists, the exchange sent to the rank itself), so every sum is the vector folded onto itself -- which is
+    exactly predictable: y + sum over the neighbour lists of y[list].  The split-phase Jacobian with the exchange under the
+    interior elements, and the recorded V-cycle (RCCL sends inside a hipGraph), must reproduce the eager, unsplit numbers."""
+    import torch
+    from ceedpetscsolid_amd import ceed as cd
+    from ceedpetscsolid_amd.halo import HaloExchange, RcclHalo, interface_elements, part_cylinder, virtual_world
+    from ceedpetscsolid_amd.mesh import reorder_elements_first
+    K, N = 1, 4
+    part = lambda r: part_cylinder(r, N, 2, 12, 12)
+    mesh = part(K)
+    lead = interface_elements(mesh, virtual=virtual_world(K, N, mesh, part, 1))
+    mesh = reorder_elements_first(mesh, lead)
+    ceed = cd.Ceed(product_lib, "/gpu/hip/mi355x")
+    ceed.set_stream(torch.cuda.current_stream().cuda_stream)
+    p = SolidProblem(ceed, mesh, 2, "hyperSS", nu=0.3, E=10.0, bc_sides=[])
+    halos = [HaloExchange(mesh, lv.dofmap, device="cuda", virtual=virtual_world(K, N, mesh, part, deg)) for lv, deg in zip(p.levels, p.degrees)]
+    rh = [RcclHalo(ceed, h, emulate_self=True) for h in halos]
+    s = NewtonPMG(p, halo=halos, rccl=rh, lead_elements=int(lead.sum()), coarse="chebyshev", coarse_cheb_its=10, graph=True)
+    assert s._split and s.rhalos is rh
+    rng = np.random.default_rng(4)
+    s.U.set_value(0.0); s.residual(s.U, s.R)
+
+    def folded(y, h):
+        out = y.copy()
+        for nb in h.neigh:
+            i = nb.dof_idx.cpu().numpy()
+            out[i] += y[i]
+        return out
+    for lv in range(s.nlev):
+        n = p.lsize(lv)
+        x, y, y0 = s._vec(n, lv), s._vec(n, lv), ceed.vector(n)
+        s._set(x, rng.uniform(-1, 1, n))
+        s.A(lv, x, y)                                   # split-phase + exchange in the library
+        p.apply_jacobian(lv, x, y0)                     # plain apply
+        assert np.array_equal(y.to_numpy(), folded(y0.to_numpy(), halos[lv])), lv
+        # dots: owner-weighted, summed over the (one) rank on the device
+        w = halos[lv].owner_weight * (p.levels[lv].mask == 0)
+        assert abs(s.dot(x, y, lv=lv) - float((x.to_numpy() * y.to_numpy() * w).sum())) < 1e-9 * abs(float((x.to_numpy() * y.to_numpy() * w).sum())) + 1e-300
+    # the V-cycle, eager and recorded (its halo sums are RCCL sends and receives inside the graph)
+    top = s.nlev - 1
+    s.setup_preconditioner()
+    r, z, z2 = s.w[top]["b"], s.kz, s._vec(p.lsize(), top)
+    s._set(r, rng.uniform(-1, 1, p.lsize()) * (p.levels[top].mask == 0))
+    s.vcycle(top, r, z2)
+    want = z2.to_numpy().copy()
+    s.record_preconditioner(r, z)
+    assert s._pc_graph is not None
+    for _ in range(2):
+        z.set_value(3.0)
+        s.precondition(r, z)
+        assert np.array_equal(z.to_numpy(), want)
+    for h in rh:
+        h.destroy()

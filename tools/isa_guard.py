@@ -63,7 +63,7 @@ QF_NAMES = {2: "LinElas", 3: "HyperSSF", 4: "HyperSSdF", 5: "HyperFSF", 6: "Hype
 
 
 def short_name(mangled):
-    m = re.search(r"k_fused_pencilILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E", mangled)
+    m = re.search(r"k_fused_pencilILi(\d+)ELi(\d+)ELi(\d+)ELi(\d)E", mangled)
     if not m:
         return None, 0, 0
     P, Q, qf, geo = (int(x) for x in m.groups())
