@@ -160,10 +160,15 @@ class AggregationAMG:
         G = sp.csr_matrix((np.ones(a_row.size), (node_of[a_row], node_of[A_host.indices])), shape=(nn, nn)).tocsr()
         fn = np.nonzero(free_node)[0]
         Gf = G[fn][:, fn].tocsr()
+        t_ag = time.perf_counter()
         agg_f, na = aggregate_nodes(Gf.indptr, Gf.indices)
+        t_ag = time.perf_counter() - t_ag
         agg = np.full(nn, na, dtype=np.int64)          # left-out nodes: a dummy aggregate without columns
         agg[fn] = agg_f
+        t_p0 = time.perf_counter()
         P0, Bn, col_ptr = tentative_prolongation(agg, na, dof_ptr, B)
+        t_p0 = time.perf_counter() - t_p0
+        t_sm = time.perf_counter()
         # smoothed prolongation from the current (first) Jacobian: P = (I - w D^-1 A) P0, w = damping * 4/3 / lambda_max
         diag = A_host.diagonal()
         dinv = np.where(diag != 0.0, 1.0 / np.where(diag != 0.0, diag, 1.0), 0.0)
@@ -184,12 +189,17 @@ class AggregationAMG:
         lv.P = cd.Csr.rect(c, n, nc, P.indptr, P.indices, P.data)
         lv.Pt = cd.Csr.rect(c, nc, n, Pt.indptr, Pt.indices, Pt.data)
         lv.dense_next = nc <= dense_limit
-        # Galerkin product with fixed patterns: T = A P (A varies), A_next = P^T T (T varies)
+        t_sm = time.perf_counter() - t_sm
+        # Galerkin product on fixed patterns: T = A P (A varies), A_next = P^T T (T varies)
+        t_pr = time.perf_counter()
         lv.T = cd.Csr.product(A_csr, lv.P, variable=0)
         lv.Anext = cd.Csr.product(lv.Pt, lv.T, variable=1, dense=lv.dense_next)
+        t_pr = time.perf_counter() - t_pr
         lv.info = dict(rows=int(n), aggregates=int(na), coarse_dofs=int(nc), nodes_per_aggregate=float(fn.size) / max(na, 1),
                        prolongation_entries_per_row=float(P.nnz) / n, galerkin_entries=int(lv.T.nnz), lambda_max=lam,
-                       next_is_dense=bool(lv.dense_next))
+                       next_is_dense=bool(lv.dense_next),
+                       seconds=dict(aggregate=t_ag, tentative=t_p0, smooth_and_upload=t_sm, product_patterns=t_pr),
+                       device_bytes=int(12 * (P.nnz + Pt.nnz) + 12 * lv.T.nnz + 12 * lv.Anext.nnz))
         return lv, Bn, col_ptr
 
     def build(self):

@@ -240,11 +240,14 @@ class Ceed:
     def capture(self, fn) -> "Graph":
         """Record the device work `fn()` queues on this Ceed into a hipGraph (CeedXGraph*)."""
         self.L.chk(self.L.lib.CeedXGraphBeginCapture(self.h))
+        g, ok = C.c_void_p(), False
         try:
             fn()
+            ok = True
         finally:
-            g = C.c_void_p()
             rc = self.L.lib.CeedXGraphEndCapture(self.h, C.byref(g))
+            if not ok and rc == 0 and g:           # fn() raised: the recording is ended and dropped, the error propagates
+                self.L.lib.CeedXGraphDestroy(C.byref(g))
         self.L.chk(rc)
         return Graph(self.L, g)
 

@@ -204,7 +204,7 @@ extern "C" int CeedXCsrUpdate(CeedXCsr A) {
   if (!A->src || !A->src2) return ceed_error("CeedXCsrUpdate: not a product (CeedXCsrCreateProduct)");
   CeedXCsr Lm = A->src, Rm = A->src2;
   HIPCHK(launch_csr_spgemm(Lm->d_rowptr, Lm->d_cols, Lm->d_vals, Rm->d_rowptr, Rm->d_cols, Rm->d_vals, A->d_rowptr, A->d_cols, A->d_vals,
-                           A->nrows, A->ceed->stream));
+                           A->nrows, A->ceed->stream, A->dense ? A->ncols : 0));
   return 0;
 }
 extern "C" int CeedXCsrGetValues(CeedXCsr A, CeedVector v) {

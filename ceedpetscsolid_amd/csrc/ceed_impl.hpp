@@ -43,9 +43,15 @@ struct CeedOptions {
   bool graph_memset = false;     // CEED_MI355X_GRAPH_MEMSET=1: recorded zero-fills as memset nodes instead of fill kernels
   int pencil_waves = 0;          // CEED_MI355X_PENCIL_WAVES: persistent waves per CU of the fused kernel (tuning hook)
   // split-phase apply with the halo exchange (CeedXOperatorApplyWithHalo)
-  int ovl_concurrent = 1;        // CEED_MI355X_OVL_CONCURRENT=0: phase 1 after phase 0 on one stream (round 2's sequence)
+  int ovl_mode = 0;              // CEED_MI355X_OVL_MODE: 0 (default) the whole apply, then the exchange, in order on one stream;
+                                 // 1 split-phase on one stream (interface elements, exchange started, interior elements: round 2's
+                                 // sequence); 2 split-phase on two streams (both phases' fused kernels side by side)
   int ovl_groups0 = 1, ovl_groups1 = 0;   // CEED_MI355X_OVL_G0 / _G1: groups per wave of the two phases (0: persistent grid)
-  int comm_priority = 1;         // CEED_MI355X_COMM_PRIO=0: the exchange's stream at default priority
+  int reserve_cus = 0, reserve_from = 0;   // EXPERIMENT: CUs the side stream may not use (ceed_need_side_stream)
+  int fold_pack = 1;             // CEED_MI355X_FOLD_PACK=0: the exchange's pack as a launch of its own (A/B)
+  int halo_capture = 0;          // CEED_MI355X_HALO_CAPTURE=1: let the exchange on the communicator's own stream be recorded too (crashes inside RCCL 2.26.6)
+  int comm_inline = 1;           // CEED_MI355X_COMM_INLINE=0: the exchange's sends / receives on a stream of their own (see halo_pack_and_send)
+  int comm_priority = 0;         // CEED_MI355X_COMM_PRIO=1: the exchange on a highest-priority stream -- measured 4x SLOWER (see CeedXCommInit)
 };
 
 // ---------------------------------------------------------------------------
@@ -195,6 +201,9 @@ struct CeedOperator_private {
   unsigned char *d_node_flags_ovl = nullptr;    // per node of the operator's own (priority-first) map
   unsigned char *d_node_flags_shell = nullptr;  // per node of the restriction's shell map (direct-store mode)
   std::vector<std::pair<const PipeMap *, unsigned char *>> pipe_flags;   // per row of a pipelined map of the restriction
+  // pack of a halo exchange folded into the rows' launch: per (transpose map, halo) the rows' send slots (HaloPackFold)
+  struct PackFold { const CsrMap *M; CeedXHalo H; long serial; uint32_t *d_ptr, *d_slot; bool ok; };
+  std::vector<PackFold> pack_folds;
   std::vector<unsigned char> h_mask;      // copy of the output mask (node flags are derived lazily)
   int mask_mode = 0;
   // optional fine-side scale for transfers
@@ -235,18 +244,23 @@ int get_pipe(CeedElemRestriction r, const CsrMap &M, int E, int per_elem, int re
 struct HaloNeighbour { int rank = 0, n = 0, offset = 0; };
 struct CeedXHalo_private {
   Ceed ceed = nullptr;
+  long serial = 0;                   // unique per halo ever created (caches keyed by a halo check it, not just the address)
   std::vector<HaloNeighbour> nb;     // slices [offset, offset + n) of the send / receive buffers
   int total = 0;                     // entries over all neighbours
   uint32_t *d_idx = nullptr;         // [total] L-vector entry of every slot (pack)
+  std::vector<uint32_t> h_idx;       // host copy (the operators fold the pack into their rows' launch from it)
   double *send = nullptr, *recv = nullptr;
   // arrivals by destination: distinct entries, and per entry its slots in neighbour-list order (unpack-add)
   int ndst = 0;
   uint32_t *d_dst = nullptr, *d_uptr = nullptr, *d_uslot = nullptr;
   hipEvent_t packed = nullptr, arrived = nullptr;
+  hipStream_t arrived_on = nullptr;  // the stream the last exchange's receives were issued on (its `arrived` event too)
   bool in_flight = false;
   CeedInt lsize_min = 0;
 };
-int halo_pack_and_send(CeedXHalo H, const double *py, hipStream_t pack_stream);   // pack on pack_stream, RCCL group on the comm stream
+int halo_pack_and_send(CeedXHalo H, const double *py, hipStream_t pack_stream);   // pack, then the RCCL group (same stream, or the comm stream)
+int halo_send(CeedXHalo H, hipStream_t pack_stream);                              // the RCCL group alone (send buffer already filled)
+int halo_wait_arrivals(CeedXHalo H, hipStream_t s);                               // make `s` wait for the last exchange's receives
 cps::HaloUnpackArgs halo_unpack_args(CeedXHalo H);
 
 static inline bool is_offsets(CeedElemRestriction r) { return r && r != CEED_ELEMRESTRICTION_NONE && !r->strided; }

@@ -146,6 +146,7 @@ extern "C" int CeedOperatorDestroy(CeedOperator *op) {
     CeedQFunctionDestroy(&o->qf);
   }
   op_free_flags(o);
+  for (auto &pf : o->pack_folds) { ceed_retire(o->ceed, pf.d_ptr); ceed_retire(o->ceed, pf.d_slot); }
   o->ovl_csr.release();
   CeedVectorDestroy(&o->scale);
   for (auto &ev : o->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -462,10 +463,52 @@ static int fused_launch(CeedOperator op, const FusedApply &F, int e0, int ne, in
   op->geo_mode = F.a.geo_aff && F.a.geo ? 2 : (F.a.geo ? 1 : 0);
   return 0;
 }
-static int assemble_rows(const FusedApply &F, int row0, int nrows, hipStream_t s, int max_blocks = 0, const HaloUnpackArgs *un = nullptr) {
+static int assemble_rows(const FusedApply &F, int row0, int nrows, hipStream_t s, int max_blocks = 0, const HaloUnpackArgs *un = nullptr,
+                         const HaloPackFold *pk = nullptr) {
   const CsrMap *M = F.M;
+  HaloPackFold p0{nullptr, nullptr, nullptr};
+  if (pk) p0 = HaloPackFold{pk->ptr + row0, pk->slot, pk->send};
   HIPCHK(launch_assemble(M->d_rowptr + row0, M->d_cols, M->d_node_off + row0, F.flags ? F.flags + row0 : nullptr, F.a.evec, F.py,
-                         nrows, F.add ? 1 : 0, s, max_blocks, un));
+                         nrows, F.add ? 1 : 0, s, max_blocks, un, pk ? &p0 : nullptr));
+  return 0;
+}
+// The pack of halo H folded into the launch that sums the rows of map M: per row the send slots of its node's entries.
+// Built once per (map, halo); not ok (-> the separate pack kernel) if an entry of the halo is no row of the map.
+static int get_pack_fold(CeedOperator op, CeedElemRestriction r, const CsrMap *M, CeedXHalo H, HaloPackFold *out, bool *ok) {
+  for (auto &pf : op->pack_folds)
+    if (pf.M == M && pf.H == H && pf.serial == H->serial) { *ok = pf.ok; *out = HaloPackFold{pf.d_ptr, pf.d_slot, H->send}; return 0; }
+  CeedOperator_private::PackFold pf{M, H, H->serial, nullptr, nullptr, false};
+  if (op->ceed->capturing) { *ok = false; return 0; }     // cold while recording: the separate pack kernel
+  const int nn = M->nnodes;
+  bool good = r->ncomp == 3 && r->compstride == 1 && (size_t)H->total < (1u << 30);
+  std::vector<uint32_t> ptr((size_t)nn + 1, 0u), slot((size_t)(H->total ? H->total : 1));
+  if (good) {
+    // row of a node offset: the map's rows are distinct node offsets (ascending within each priority class): look up by sort
+    std::vector<std::pair<uint32_t, uint32_t>> rows((size_t)nn);
+    for (int i = 0; i < nn; i++) rows[(size_t)i] = {M->h_node_off[(size_t)i], (uint32_t)i};
+    std::sort(rows.begin(), rows.end());
+    std::vector<uint32_t> row_of((size_t)H->total);
+    for (int k = 0; k < H->total && good; k++) {
+      const uint32_t d = H->h_idx[(size_t)k], node = d - d % 3;
+      auto it = std::lower_bound(rows.begin(), rows.end(), std::make_pair(node, 0u));
+      if (it == rows.end() || it->first != node) good = false;
+      else { row_of[(size_t)k] = it->second; ptr[(size_t)it->second + 1]++; }
+    }
+    if (good) {
+      for (int i = 0; i < nn; i++) ptr[(size_t)i + 1] += ptr[(size_t)i];
+      std::vector<uint32_t> cur(ptr.begin(), ptr.end() - 1);
+      for (int k = 0; k < H->total; k++) slot[cur[row_of[(size_t)k]]++] = (uint32_t)k | ((H->h_idx[(size_t)k] % 3u) << 30);
+    }
+  }
+  if (good) {
+    HIPCHK(hipMalloc((void **)&pf.d_ptr, sizeof(uint32_t) * ptr.size()));
+    HIPCHK(hipMalloc((void **)&pf.d_slot, sizeof(uint32_t) * slot.size()));
+    HIPCHK(hipMemcpy(pf.d_ptr, ptr.data(), sizeof(uint32_t) * ptr.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(pf.d_slot, slot.data(), sizeof(uint32_t) * slot.size(), hipMemcpyHostToDevice));
+    pf.ok = true;
+  }
+  op->pack_folds.push_back(pf);
+  *ok = pf.ok; *out = HaloPackFold{pf.d_ptr, pf.d_slot, H->send};
   return 0;
 }
 
@@ -513,7 +556,9 @@ static int apply_pipelined(CeedOperator op, const FusedApply &F, PipeMap *PM, co
 
 // phase -1: whole apply; phase 0 / 1: the two halves of a split-phase apply (CeedXOperatorApplyPhase), one after the other
 // on the Ceed's stream.
-static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool add, int phase, const char **kname) {
+// `H` (whole applies in overwrite mode only): the interface sum of the output follows IN ORDER on the same stream -- in the
+// serial form the pack is folded into the rows' launch (HaloPackFold), then the RCCL group and the unpack-add launch.
+static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool add, int phase, const char **kname, CeedXHalo H = nullptr) {
   Ceed c = op->ceed;
   hipStream_t s = c->stream;
   FusedApply F;
@@ -545,13 +590,26 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
     CHK(get_pipe(F.r, *M, pencil_group_elems(F.b->Q1d), per_elem, std::max(c->opt.pipe_segments, 0), waves, &PM));
     if (PM && PM->nseg >= 2) {
       CHK(apply_pipelined(op, F, PM, kname));
+      if (H) {
+        CHK(halo_pack_and_send(H, F.py, s));
+        CHK(halo_wait_arrivals(H, s));
+        HIPCHK(launch_halo_unpack_add(halo_unpack_args(H), F.py, s));
+      }
       op->launches++;
       return 0;
     }
   }
   op->launch_info[0] = 1; op->launch_info[1] = 1; op->launch_info[2] = 1; op->launch_info[3] = F.r->nelem;
   CHK(fused_launch(op, F, 0, F.r->nelem, 0, s, kname));
-  CHK(assemble_rows(F, 0, M->nnodes, s));   // timed together with the fused kernel: the launches ARE the operator apply
+  HaloPackFold pk{nullptr, nullptr, nullptr};
+  bool folded = false;
+  if (H && c->opt.fold_pack) CHK(get_pack_fold(op, F.r, M, H, &pk, &folded));
+  CHK(assemble_rows(F, 0, M->nnodes, s, 0, nullptr, folded ? &pk : nullptr));   // timed together with the fused kernel: the launches ARE the operator apply
+  if (H) {
+    if (folded) CHK(halo_send(H, s)); else CHK(halo_pack_and_send(H, F.py, s));
+    CHK(halo_wait_arrivals(H, s));
+    HIPCHK(launch_halo_unpack_add(halo_unpack_args(H), F.py, s));
+  }
   op->launches++;
   return 0;
 }
@@ -575,13 +633,13 @@ static int apply_fused_with_halo(CeedOperator op, CeedVector in, CeedVector out,
   TimerScope ts(op, s);
   const CeedOptions &o = c->opt;
   const HaloUnpackArgs un = halo_unpack_args(H);
-  op->launch_info[0] = 2; op->launch_info[1] = o.ovl_concurrent ? 2 : 1; op->launch_info[2] = 2; op->launch_info[3] = rest;
-  if (!o.ovl_concurrent) {   // round 2's sequence on one stream (A/B)
+  op->launch_info[0] = 2; op->launch_info[1] = o.ovl_mode == 2 ? 2 : 1; op->launch_info[2] = 2; op->launch_info[3] = rest;
+  if (o.ovl_mode != 2) {   // round 2's sequence on one stream
     CHK(fused_launch(op, F, 0, lead, 0, s, kname));
     CHK(assemble_rows(F, 0, M->nprio, s));
     CHK(halo_pack_and_send(H, F.py, s));
     CHK(fused_launch(op, F, lead, rest, 0, s, kname));
-    HIPCHK(hipStreamWaitEvent(s, H->arrived, 0));
+    CHK(halo_wait_arrivals(H, s));
     CHK(assemble_rows(F, M->nprio, M->nnodes - M->nprio, s, 0, &un));
     op->launches++;
     return 0;
@@ -597,7 +655,7 @@ static int apply_fused_with_halo(CeedOperator op, CeedVector in, CeedVector out,
   CHK(assemble_rows(F, 0, M->nprio, s));
   CHK(halo_pack_and_send(H, F.py, s));
   HIPCHK(hipStreamWaitEvent(s1, c->ev_seg[0], 0));
-  HIPCHK(hipStreamWaitEvent(s1, H->arrived, 0));
+  CHK(halo_wait_arrivals(H, s1));
   CHK(assemble_rows(F, M->nprio, M->nnodes - M->nprio, s1, 0, &un));
   HIPCHK(hipEventRecord(c->ev_join, s1));
   HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
@@ -900,7 +958,20 @@ extern "C" int CeedXOperatorApplyWithHalo(CeedOperator op, CeedVector in, CeedVe
   if (op->composite) return ceed_error("split-phase apply of a composite operator is not supported");
   CHK(op_plan(op));
   if (!halo || halo->nb.empty()) return CeedOperatorApply(op, in, out, CEED_REQUEST_IMMEDIATE);
-  if (op->plan != PLAN_FUSED_GRAD || op->ovl_lead <= 0 || !op->ovl_csr.built) {   // no split set: apply, then the exchange
+  // Default (CeedOptions::ovl_mode 0): the whole apply, then pack / RCCL group / unpack-add, IN ORDER on the Ceed's stream.
+  // Measured on the emulated rank 3 of 8: 13 200 hexes at p = 4 -- split-phase on two streams 119 us, split-phase on
+  // one stream 112 us, whole apply + exchange through the communicator's stream 120 us; a hand-over between two streams costs
+  // more than the exchange it would hide.
+  // (while a graph is recorded always this form: RCCL's calls record correctly only in order on the capturing stream)
+  if (op->plan == PLAN_FUSED_GRAD && (op->ceed->opt.ovl_mode == 0 || op->ceed->capturing || op->ovl_lead <= 0 || !op->ovl_csr.built)) {
+    if (halo->in_flight) return ceed_error("CeedXOperatorApplyWithHalo: an exchange is already in flight");
+    if (out->length < halo->lsize_min) return ceed_error("CeedXOperatorApplyWithHalo: vector shorter than the halo's indices");
+    const char *kname = "";
+    CHK(apply_fused_grad(op, in, out, false, -1, &kname, halo));
+    op->kernel_name = kname;
+    return 0;
+  }
+  if (op->plan != PLAN_FUSED_GRAD) {
     CHK(CeedOperatorApply(op, in, out, CEED_REQUEST_IMMEDIATE));
     CHK(CeedXHaloStart(halo, out));
     return CeedXHaloFinish(halo, out);

@@ -189,9 +189,13 @@ constexpr int pencil_group_elems(int Q) { return Q <= 2 ? 8 : (Q <= 4 ? 4 : (Q =
 // `unpack` (may be null): the arrivals of a halo exchange, added to y by extra workgroups of the SAME launch (one launch
 // less on the critical path of a split-phase apply): y[dst[u]] += recv[slot[k]], k in [ptr[u], ptr[u+1]), in list order.
 struct HaloUnpackArgs { const uint32_t *dst, *ptr, *slot; const double *recv; int n; };
+// `pack` (may be null): the pack of a halo exchange folded into the rows' launch -- row r's finished sums also go to
+// send[slot[k] & 0x3FFFFFFF], component slot[k] >> 30, k in [ptr[r], ptr[r+1]) (ptr over the rows of THIS launch).
+struct HaloPackFold { const uint32_t *ptr, *slot; double *send; };
 hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off,
                            const unsigned char *flags, const double *evec, double *y, int nnodes,
-                           int add, hipStream_t s, int max_blocks = 0, const HaloUnpackArgs *unpack = nullptr);   // max_blocks: cap on the grid (pipelined assembly)
+                           int add, hipStream_t s, int max_blocks = 0, const HaloUnpackArgs *unpack = nullptr,
+                           const HaloPackFold *pack = nullptr);   // max_blocks: cap on the grid (pipelined assembly)
 
 // Coordinate-driven set-up operators (kernels_coord.hip): opSetupForce and opTrue of setuplibceed.c:555-623.
 struct CoordOpArgs {
@@ -236,7 +240,8 @@ hipError_t launch_csr_spmv(const uint32_t *rowptr, const uint32_t *cols, const d
 hipError_t launch_csr_diag(const uint32_t *diag_slot_of_row, const double *vals, double *d, int nrows, hipStream_t s);
 hipError_t launch_csr_spgemm(const uint32_t *l_rowptr, const uint32_t *l_cols, const double *l_vals, const uint32_t *r_rowptr,
                              const uint32_t *r_cols, const double *r_vals, const uint32_t *c_rowptr, const uint32_t *c_cols, double *c_vals,
-                             int nrows, hipStream_t s);   // C = L R on fixed patterns (R's columns sorted within each row)
+                             int nrows, hipStream_t s, int dense_ncols = 0);   // C = L R on fixed patterns (R's columns sorted within each row);
+                             // dense_ncols > 0: C is a dense row-major nrows x dense_ncols matrix (LDS row accumulation)
 hipError_t launch_dense_spd_inverse(double *A, int n, double *scratch /* 1024 doubles */, int *info, hipStream_t s);
 
 // Vector / restriction utilities.

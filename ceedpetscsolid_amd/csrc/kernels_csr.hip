@@ -173,10 +173,37 @@ hipError_t launch_csr_diag(const uint32_t *diag_slot_of_row, const double *vals,
   hipLaunchKernelGGL(k_csr_diag, grid_for((size_t)nrows, 256), dim3(256), 0, s, diag_slot_of_row, vals, d, nrows);
   return hipGetLastError();
 }
+// The same product for a DENSE result (row-major nrows x ncols, every entry present: the coarsest Galerkin matrix, up to
+// CSR_DENSE_MAX_COLS columns).  Searching every one of the ncols columns in rows of R that hold ~50 of them wastes ~95 % of
+// the probes; here one wave owns a row of C in LDS and ADDS: for k along L's row (in order), the lanes take the entries of
+// R's row k and add  L[r, k] R[k, c]  to acc[c] -- distinct columns within a row of R, so no two lanes touch one word, and
+// one wave's LDS operations execute in order: every entry is summed in the order of L's row, the same every time.
+constexpr int CSR_DENSE_MAX_COLS = 4096;
+__global__ __launch_bounds__(64) void k_csr_spgemm_dense(const uint32_t *l_rowptr, const uint32_t *l_cols, const double *l_vals,
+                                                        const uint32_t *r_rowptr, const uint32_t *r_cols, const double *r_vals,
+                                                        double *c_vals, int nrows, int ncols) {
+  __shared__ double acc[CSR_DENSE_MAX_COLS];
+  const int lane = threadIdx.x;
+  for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+    for (int c = lane; c < ncols; c += 64) acc[c] = 0.;
+    for (uint32_t k = l_rowptr[r]; k < l_rowptr[r + 1]; k++) {
+      const uint32_t j = l_cols[k];
+      const double a = l_vals[k];
+      for (uint32_t m = r_rowptr[j] + lane; m < r_rowptr[j + 1]; m += 64) acc[r_cols[m]] += a * r_vals[m];
+    }
+    for (int c = lane; c < ncols; c += 64) c_vals[(size_t)r * ncols + c] = acc[c];
+  }
+}
+
 hipError_t launch_csr_spgemm(const uint32_t *l_rowptr, const uint32_t *l_cols, const double *l_vals, const uint32_t *r_rowptr,
                              const uint32_t *r_cols, const double *r_vals, const uint32_t *c_rowptr, const uint32_t *c_cols, double *c_vals,
-                             int nrows, hipStream_t s) {
+                             int nrows, hipStream_t s, int dense_ncols) {
   if (nrows <= 0) return hipSuccess;
+  if (dense_ncols > 0 && dense_ncols <= CSR_DENSE_MAX_COLS) {
+    hipLaunchKernelGGL(k_csr_spgemm_dense, dim3((unsigned)std::min(nrows, 8192)), dim3(64), 0, s, l_rowptr, l_cols, l_vals, r_rowptr, r_cols, r_vals,
+                       c_vals, nrows, dense_ncols);
+    return hipGetLastError();
+  }
   const unsigned blocks = (unsigned)std::min<size_t>(((size_t)nrows + 3) / 4, 16384);     // four rows (waves) per workgroup
   hipLaunchKernelGGL(k_csr_spgemm, dim3(blocks), dim3(256), 0, s, l_rowptr, l_cols, l_vals, r_rowptr, r_cols, r_vals, c_rowptr, c_cols,
                      c_vals, nrows);

@@ -418,7 +418,7 @@ __global__ void k_rstr(const uint32_t *off, size_t total, int elemsize, int ncom
 // (HaloUnpackArgs: different entries of y than any row of this launch).
 __global__ void k_assemble(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off,
                            const unsigned char *flags, const double *evec, double *y, int nnodes, int add, int nb_rows,
-                           const HaloUnpackArgs un) {
+                           const HaloUnpackArgs un, const HaloPackFold pk) {
   if ((int)blockIdx.x >= nb_rows) {
     for (int u = ((int)blockIdx.x - nb_rows) * blockDim.x + threadIdx.x; u < un.n; u += ((int)gridDim.x - nb_rows) * blockDim.x) {
       double v = y[un.dst[u]];
@@ -454,6 +454,11 @@ __global__ void k_assemble(const uint32_t *rowptr, const uint32_t *cols, const u
     if (fl & 4u) a2 = 0.;
     if (add) { a0 += dst[0]; a1 += dst[1]; a2 += dst[2]; }
     dst[0] = a0; dst[1] = a1; dst[2] = a2;
+    if (pk.ptr)   // interface node: its finished sums go straight into the exchange's send buffer (no pack launch)
+      for (uint32_t k = pk.ptr[r]; k < pk.ptr[r + 1]; k++) {
+        const uint32_t e = pk.slot[k], cmp = e >> 30;
+        pk.send[e & 0x3FFFFFFFu] = cmp == 0 ? a0 : (cmp == 1 ? a1 : a2);
+      }
   }
 }
 
@@ -575,14 +580,15 @@ hipError_t launch_multiplicity(const uint32_t *off, int nelem, int elemsize, int
 }
 hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off,
                            const unsigned char *flags, const double *evec, double *y, int nnodes,
-                           int add, hipStream_t s, int max_blocks, const HaloUnpackArgs *unpack) {
+                           int add, hipStream_t s, int max_blocks, const HaloUnpackArgs *unpack, const HaloPackFold *pack) {
   const int nun = unpack ? unpack->n : 0;
   if (nnodes <= 0 && nun <= 0) return hipSuccess;
   unsigned nb_rows = (unsigned)((std::max(nnodes, 0) + 255) / 256);
   if (max_blocks > 0 && nb_rows > (unsigned)max_blocks) nb_rows = (unsigned)max_blocks;     // (grid-stride loop over the rows)
   const unsigned nb_un = (unsigned)std::min((nun + 255) / 256, 1024);
   hipLaunchKernelGGL(k_assemble, dim3(nb_rows + nb_un), dim3(256), 0, s, rowptr, cols, node_off, flags, evec, y, nnodes, add,
-                     (int)nb_rows, unpack ? *unpack : HaloUnpackArgs{nullptr, nullptr, nullptr, nullptr, 0});
+                     (int)nb_rows, unpack ? *unpack : HaloUnpackArgs{nullptr, nullptr, nullptr, nullptr, 0},
+                     pack ? *pack : HaloPackFold{nullptr, nullptr, nullptr});
   return hipGetLastError();
 }
 hipError_t launch_dot(const double *x, const double *y, const double *w, size_t n, double *result_dev, hipStream_t s, double *out) {

@@ -241,6 +241,7 @@ def checked_rccl_halo(ceed, halo: "HaloExchange", probe: np.ndarray, device, tim
     box = {}
     n = probe.size
     dev = torch.device(device)
+    cur_dev = torch.cuda.current_device() if dev.type == "cuda" else None
     try:
         ident = RcclHalo.unique_id(ceed, halo) if halo.world > 1 and not getattr(ceed, "_comm_ready", False) else None
     except RuntimeError as e:       # raised on every rank alike
@@ -250,8 +251,8 @@ def checked_rccl_halo(ceed, halo: "HaloExchange", probe: np.ndarray, device, tim
 
     def bring_up():
         try:
-            if dev.type == "cuda":
-                torch.cuda.set_device(dev)
+            if dev.type == "cuda":       # a new thread starts on device 0: make the rank's device current
+                torch.cuda.set_device(dev if dev.index is not None else cur_dev)
             h = RcclHalo(ceed, halo, ident=ident)
             t = torch.from_numpy(probe).to(dev)
             V = ceed.vector(n)

@@ -21,6 +21,8 @@ ap.add_argument("--problem", default="hyperSS")
 ap.add_argument("--degree", type=int, default=4)
 ap.add_argument("--increments", type=int, default=10)
 ap.add_argument("--mesh", default=os.path.join(ROOT, "tests", "golden", "mesh_cylinder8_5580e_4ss_us.npz"))
+ap.add_argument("--cylinder", default=None, metavar="NR,NTH,NZ",
+                help="instead of --mesh: the structured hollow cylinder of bench.py (10,110,90 = the 99 000-hex stand-in of BASELINE config 4)")
 ap.add_argument("--translate", default="0,-0.05,0.1",
                 help="clamp 998 translation; README.rst:63 uses 0,-0.5,1 (for linElas): with degree-4 elements the jump of a tenth of that per load step already puts the first GLL layer at O(1) strain, outside the small-strain model")
 ap.add_argument("--E", type=float, default=1e3)
@@ -43,7 +45,12 @@ args = ap.parse_args()
 # partition (z-slabs) per rank, halo sums inside the solver (SOLVE_DIST_BACKEND=gloo rehearses it on one GPU)
 world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 halos = None
-mesh = load_mesh_npz(args.mesh)
+if args.cylinder:
+    from ceedpetscsolid_amd.mesh import hollow_cylinder_mesh
+    mesh = hollow_cylinder_mesh(*[int(v) for v in args.cylinder.split(",")])
+    args.mesh = f"hollow_cylinder_{args.cylinder}"
+else:
+    mesh = load_mesh_npz(args.mesh)
 if world > 1:
     import torch, torch.distributed as dist
     from ceedpetscsolid_amd.halo import HaloExchange
@@ -78,6 +85,7 @@ out = {"resource": ceed.resource, "problem": args.problem, "mesh": os.path.basen
        "translate_998": list(tr), "coarse_solver": args.coarse, "vcycle_graph": args.graph, "load_increments": st.increments, "converged": st.converged, "snes_its": st.newton_its, "ksp_its": st.ksp_its,
        "coarse_cg_its": st.coarse_its, "jacobian_applies": st.jacobian_applies, "residual_evals": st.residual_evals, "coarse_spmv": st.coarse_spmv,
        "setup_s": t_setup, "snes_solve_s": st.seconds,
+       "amg": ({k: solver.amg.info.get(k) for k in ("levels", "rows", "build_seconds", "per_level")} if getattr(solver, "amg", None) is not None else None),
        "ranks": world,
        "MDoFs_per_s_in_SNES": 1e-6 * (halos[-1].global_count((prob.levels[prob.fine].mask == 0).astype(np.float64)) if halos else prob.n_free()) * st.ksp_its / st.seconds,   # elasticity.c:755-764
        "max_abs_displacement": np.abs(u).max(axis=0).tolist(), "final_residual_norm": st.history[-1][4] if st.history else None}

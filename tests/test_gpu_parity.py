@@ -340,7 +340,7 @@ def test_one_call_apply_with_halo_equals_its_parts_bitwise(product_lib, workload
     itself through a one-rank RCCL communicator.  Three routes must agree BIT FOR BIT: (a) the one call -- two launches of
     the fused kernel on two streams, the exchange started behind the interface rows, the arrivals added by the launch
     that sums the interior rows; (b) round 2's sequence phase 0 / CeedXHaloStart / phase 1 / CeedXHaloFinish; (c) the whole
-    apply followed by the exchange.  Then (a) recorded into a hipGraph and replayed on new data."""
+    apply followed by the exchange.  Recorded into a hipGraph and replayed on new data where this RCCL allows it."""
     from ceedpetscsolid_amd.halo import HaloExchange, RcclHalo, interface_elements, part_box, part_cylinder, virtual_world
     from ceedpetscsolid_amd.harness import SolidApp
     from ceedpetscsolid_amd.mesh import reorder_elements_first
@@ -355,8 +355,25 @@ def test_one_call_apply_with_halo_equals_its_parts_bitwise(product_lib, workload
     lead = interface_elements(mesh, virtual=vw)
     assert lead.any() and not lead.all()
     mesh = reorder_elements_first(mesh, lead)
-    ceed = cd.Ceed(product_lib, "/gpu/hip/mi355x")
     bc = [s for s in (998, 999, 1, 2) if s in mesh.side_sets]
+    want = None
+    # every form of the one call: whole apply then exchange (0, default), split-phase on one stream (1), on two (2); the
+    # RCCL group in order on the producing stream (default) or on the communicator's own stream
+    for mode, inline in ((0, 1), (2, 1), (1, 1), (2, 0), (1, 0), (0, 0)):
+        os.environ["CEED_MI355X_COMM_INLINE"] = str(inline)
+        try:
+            ceed = _ceed_with_env(product_lib, "CEED_MI355X_OVL_MODE", str(mode))
+        finally:
+            os.environ.pop("CEED_MI355X_COMM_INLINE", None)
+        got = _one_call_routes(ceed, mesh, vw, lead, degree, bc, record=(True if inline else "refused") if mode in (0, 2) else False)
+        if want is None:
+            want = got
+        assert np.array_equal(got, want), (mode, inline)
+
+
+def _one_call_routes(ceed, mesh, vw, lead, degree, bc, record):
+    from ceedpetscsolid_amd.halo import HaloExchange, RcclHalo
+    from ceedpetscsolid_amd.harness import SolidApp
     app = SolidApp(ceed, mesh, degree, "hyperFS", nu=0.3, E=1.0, bc_sides=bc, multigrid="none")
     dm = app.dofmaps[app.fine]
     halo = HaloExchange(mesh, dm, device="cuda", virtual=vw)
@@ -368,6 +385,7 @@ def test_one_call_apply_with_halo_equals_its_parts_bitwise(product_lib, workload
     X.set_array(smooth_displacement(dm.node_coords, 0.05)); app.form_residual(X, Ya)
     op = app.opJacob[app.fine]
     op.set_overlap_split(int(lead.sum()), halo.interface_dof_mask())
+    last = None
     for it in range(4):
         X.set_array(rng.uniform(-1, 1, n) * (app.masks[app.fine] == 0))
         Ya.set_value(7.0); Yb.set_value(-3.0); Yc.set_value(1.0)
@@ -378,23 +396,31 @@ def test_one_call_apply_with_halo_equals_its_parts_bitwise(product_lib, workload
         assert np.isfinite(ya).all() and np.abs(ya).max() > 0
         assert np.array_equal(ya, Yb.to_numpy()), it
         assert np.array_equal(ya, Yc.to_numpy()), it
+        last = ya
     # the C++ harness: ApplyJacobian_Ceed with the level's halo attached takes the one-call route
     app.set_halo(app.fine, ch)
     app.apply_jacobian(app.fine, X, Yb)
     assert np.array_equal(Yb.to_numpy(), Ya.to_numpy())
     app.set_halo(app.fine, None)
-    # recorded: both streams and the communicator's stream join the capture and are joined back
     Yg = ceed.vector(n)
-    op.apply_with_halo(X, Yg, ch)
-    g = ceed.capture(lambda: op.apply_with_halo(X, Yg, ch))
-    for _ in range(3):
-        X.set_array(rng.uniform(-1, 1, n) * (app.masks[app.fine] == 0)); X.device_pointer()
+    if record == "refused":   # RCCL on a stream of its own crashes inside a capture (tools/rccl_capture_probe.py): an error, not a crash
+        with pytest.raises(cd.CeedError):
+            ceed.capture(lambda: op.apply_with_halo(X, Yg, ch))
+        op.apply_with_halo(X, Yg, ch)                     # and the Ceed is usable afterwards
         op.apply_with_halo(X, Ya, ch)
-        Yg.set_value(-7.0)
-        g.launch()
         assert np.array_equal(Yg.to_numpy(), Ya.to_numpy())
-    g.destroy()
+    elif record:              # in order on the capturing stream the exchange records and replays
+        op.apply_with_halo(X, Yg, ch)
+        g = ceed.capture(lambda: op.apply_with_halo(X, Yg, ch))
+        for _ in range(3):
+            X.set_array(rng.uniform(-1, 1, n) * (app.masks[app.fine] == 0)); X.device_pointer()
+            op.apply_with_halo(X, Ya, ch)
+            Yg.set_value(-7.0)
+            g.launch()
+            assert np.array_equal(Yg.to_numpy(), Ya.to_numpy())
+        g.destroy()
     ch.destroy()
+    return last
 
 
 def test_halo_exchange_through_rccl_on_one_gpu(product_lib):
@@ -788,6 +814,37 @@ def test_direct_interior_stores_equal_the_assembled_path(gpu, product_lib):
             outs.append(res)
         for a, b in zip(*outs):
             assert np.array_equal(a, b)
+
+
+def _forcing_and_true(c, p, kind):
+    """opSetupForce / opTrue as the reference wires them (setuplibceed.c:555-583, 608-636)."""
+    lv = p.levels[p.fine]
+    n = p.lsize()
+    if kind == "true":
+        qf = c.qfunction("MMSTrueSoln", source="qfunctions/manufacturedTrue.h:MMSTrueSoln")
+        qf.add_input("x", 3, cd.EVAL_INTERP).add_output("true_soln", 3, cd.EVAL_NONE)
+        bxt = c.basis_lagrange(3, 3, 2, lv.degree + 1, cd.GAUSS_LOBATTO)      # basisxtrue, :600-603
+        op = c.operator(qf)
+        op.set_field("x", p.Erestrictx, bxt, "active")
+        op.set_field("true_soln", lv.Erestrictu, None, "active")
+    else:
+        name = "SetupMMSForce" if kind == "mms" else "SetupConstantForce"
+        src = "manufacturedForce.h" if kind == "mms" else "constantForce.h"
+        qf = c.qfunction(name, source=f"qfunctions/{src}:{name}")
+        qf.add_input("x", 3, cd.EVAL_INTERP).add_input("qdata", 10, cd.EVAL_NONE).add_output("force", 3, cd.EVAL_INTERP)
+        if kind == "mms":
+            qf.set_context(p.phys)
+        else:
+            _forcing_and_true.vec = np.array([0.3, -1.0, 2.0])
+            qf.set_context(_forcing_and_true.vec, reported_size=8)             # sizeof(*forcingVector) quirk, :565-566
+        op = c.operator(qf)
+        op.set_field("x", p.Erestrictx, p.basisx, "active")
+        op.set_field("qdata", p.Erestrictqdi, None, p.qdata)
+        op.set_field("force", lv.Erestrictu, lv.basisu, "active")
+    F = c.vector(n)
+    op.apply(p.xcoord, F)
+    return F.to_numpy()
+
 
 
 @pytest.mark.gpu

@@ -296,7 +296,7 @@ def test_solver_interface_sums_and_dots_go_through_the_library(product_lib):
     halos = [HaloExchange(mesh, lv.dofmap, device="cuda", virtual=virtual_world(K, N, mesh, part, deg)) for lv, deg in zip(p.levels, p.degrees)]
     rh = [RcclHalo(ceed, h, emulate_self=True) for h in halos]
     s = NewtonPMG(p, halo=halos, rccl=rh, lead_elements=int(lead.sum()), coarse="chebyshev", coarse_cheb_its=10, graph=True)
-    assert s._split and s.rhalos is rh
+    assert s._split and s.rhalos == rh
     rng = np.random.default_rng(4)
     s.U.set_value(0.0); s.residual(s.U, s.R)
 
@@ -316,13 +316,15 @@ def test_solver_interface_sums_and_dots_go_through_the_library(product_lib):
         # dots: owner-weighted, summed over the (one) rank on the device
         w = halos[lv].owner_weight * (p.levels[lv].mask == 0)
         assert abs(s.dot(x, y, lv=lv) - float((x.to_numpy() * y.to_numpy() * w).sum())) < 1e-9 * abs(float((x.to_numpy() * y.to_numpy() * w).sum())) + 1e-300
-    # the V-cycle, eager and recorded (its halo sums are RCCL sends and receives inside the graph)
+    # the V-cycle, eager and recorded (its halo sums are RCCL sends and receives inside the graph: in order on the
+    # capturing stream this RCCL records them correctly, tools/rccl_capture_probe.py)
     top = s.nlev - 1
     s.setup_preconditioner()
     r, z, z2 = s.w[top]["b"], s.kz, s._vec(p.lsize(), top)
     s._set(r, rng.uniform(-1, 1, p.lsize()) * (p.levels[top].mask == 0))
     s.vcycle(top, r, z2)
     want = z2.to_numpy().copy()
+    assert np.isfinite(want).all()
     s.record_preconditioner(r, z)
     assert s._pc_graph is not None
     for _ in range(2):
