@@ -70,6 +70,7 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   o.recompute_geo = !env_is("CEED_MI355X_GEO", "0");
   o.direct_interior = !env_is("CEED_MI355X_DIRECT", "0");
   o.affine_geo = !env_is("CEED_MI355X_AFFINE", "0");
+  o.derived_state = !env_is("CEED_MI355X_DERIVED", "0");
   if (env_is("CEED_MI355X_ASSEMBLE", "serial")) o.pipe_segments = 0;
   else { const int ps = env_int("CEED_MI355X_PIPE_SEGMENTS", 0); o.pipe_segments = ps >= 2 ? std::min(ps, 16) : -1; }
   o.pipe_blocks = env_int("CEED_MI355X_PIPE_BLOCKS", 0);
@@ -198,6 +199,7 @@ extern "C" int CeedXGraphDestroy(CeedXGraph *graph) {
 }
 
 void vec_drop_geo(CeedVector v) {
+  v->derived_valid = false;
   if (v->geo) (void)hipFree(v->geo);
   if (v->geo_aff) (void)hipFree(v->geo_aff);
   v->geo = v->geo_aff = nullptr; v->geo_nelem = v->geo_Q = 0;
@@ -353,6 +355,7 @@ extern "C" int CeedVectorDestroy(CeedVector *vec) {
   if (v == CEED_VECTOR_ACTIVE || v == CEED_VECTOR_NONE) return 0;
   if (--v->refcount > 0) return 0;
   vec_drop_host(v); vec_drop_dev(v); vec_drop_geo(v);
+  if (v->derived) (void)hipFree(v->derived);
   ceed_unref(v->ceed);
   delete v;
   return 0;

@@ -32,6 +32,7 @@ int ceed_error(const char *fmt, ...);
 struct CeedOptions {
   bool recompute_geo = true;     // CEED_MI355X_GEO=0: the fused kernels read qdata instead of recomputing it from the element maps
   bool direct_interior = true;   // CEED_MI355X_DIRECT=0: element-interior nodes go through the E-vector like the shared ones
+  bool derived_state = true;     // CEED_MI355X_DERIVED=0: HyperFSdF forms F^-1 and ln J from the stored grad u at every point
   bool affine_geo = true;        // CEED_MI355X_AFFINE=0: all-affine meshes take the general per-point recompute too
   // restriction transpose of large whole applies: pipelined in segments over two streams
   int pipe_segments = -1;        // 0: never (CEED_MI355X_ASSEMBLE=serial); -1: chosen per launch; >= 2: CEED_MI355X_PIPE_SEGMENTS
@@ -107,6 +108,14 @@ struct CeedVector_private {
   double *geo_aff = nullptr;   // set when EVERY element is affine: [nelem][GEO_NAFF] constant factors (FusedGradArgs::geo_aff)
   int geo_nelem = 0, geo_Q = 0;
   double geo_qref[cps::MAXN1D] = {0}, geo_qwt[cps::MAXN1D] = {0};
+  // provenance of a stored-state vector (grad u): written by this backend's HyperFSF kernel, which left the DERIVED state of
+  // the tangent ([nelem][10][Q^3]: F^-1, lambda ln J - mu) beside it; HyperFSdF then reads that instead (QF_HYPERFS_DF_DS).
+  // Any other write to the vector invalidates it (the buffer is kept for the next residual evaluation).
+  double *derived = nullptr;
+  size_t derived_len = 0;
+  bool derived_valid = false;
+  int derived_nelem = 0, derived_Q3 = 0;
+  double derived_nu = 0., derived_E = 0.;   // the material the derived state was formed with
 };
 
 // Transpose map of an offsets restriction: distinct node offsets and, per node, the E-vector

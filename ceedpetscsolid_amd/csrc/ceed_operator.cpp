@@ -370,6 +370,7 @@ struct FusedApply {
   CeedBasis b = nullptr;
   int qfkind = 0;
   bool add = false, direct = false, split = false;
+  CeedVector derived_for = nullptr;        // residual applies: the state vector whose derived state this apply writes
   double *py = nullptr;
   const CsrMap *M = nullptr;               // the transpose map of this apply (restriction's, shell, or the operator's split map)
   const unsigned char *flags = nullptr;    // Dirichlet flags per row of M (null: none)
@@ -401,11 +402,34 @@ static int fused_prepare(CeedOperator op, CeedVector in, CeedVector out, bool ad
   CHK(vec_dev(op->in[op->i_qdata].vec, false, &pq));
   a.offsets = op->d_off_flagged_in ? op->d_off_flagged_in : r->d_offsets;
   a.x = px; a.y = F.py; a.qdata = pq;
-  if (op->i_state >= 0) { CHK(vec_dev(op->in[op->i_state].vec, false, &ps)); a.state_in = ps; }
+  CHK(read_phys(qf, &a.nu, &a.E));
+  const int Q3 = ai.basis->Q1d * ai.basis->Q1d * ai.basis->Q1d;
+  if (op->i_state >= 0) {
+    CeedVector sv = op->in[op->i_state].vec;
+    CHK(vec_dev(sv, false, &ps)); a.state_in = ps;
+    // the derived state the residual kernel left beside grad u, if it still belongs to it (same elements, points, material)
+    if (qf->kind == QF_HYPERFS_DF && c->opt.derived_state && sv->derived_valid && sv->derived_nelem == r->nelem && sv->derived_Q3 == Q3 &&
+        sv->derived_nu == a.nu && sv->derived_E == a.E) {
+      F.qfkind = QF_HYPERFS_DF_DS;
+      a.state_in = sv->derived;
+    }
+  }
   if (op->o_state >= 0) {
     CeedVector sv = op->out[op->o_state].vec;
     if (!sv || sv == CEED_VECTOR_NONE || sv == CEED_VECTOR_ACTIVE) return ceed_error("state output needs a passive vector");
-    CHK(vec_dev(sv, true, &ps)); a.state_out = ps;  // every point is overwritten
+    CHK(vec_dev(sv, true, &ps)); a.state_out = ps;  // every point is overwritten (and the derived state invalidated)
+    if (qf->kind == QF_HYPERFS_F && c->opt.derived_state && !split) {
+      const size_t need = (size_t)r->nelem * 10 * Q3;
+      if (sv->derived_len < need) {
+        if (c->capturing) return ceed_error("evaluate the residual once before recording (derived-state buffer)");
+        ceed_retire(c, sv->derived);
+        sv->derived = nullptr; sv->derived_len = 0;
+        HIPCHK(hipMalloc((void **)&sv->derived, sizeof(double) * need));
+        sv->derived_len = need;
+      }
+      a.state_out2 = sv->derived;
+      F.derived_for = sv;
+    }
   }
   a.mask_in = (op->mask_mode & 1) ? 1 : 0; a.mask_out = (op->mask_mode & 2) ? 1 : 0;
   if (pencil_even_odd(ai.basis->Q1d)) memcpy(a.eo, op->eo, sizeof a.eo);
@@ -420,7 +444,6 @@ static int fused_prepare(CeedOperator op, CeedVector in, CeedVector out, bool ad
       for (int i = 0; i < ai.basis->Q1d; i++) { a.qref[i] = qv->geo_qref[i]; a.qwt[i] = qv->geo_qwt[i]; }
     }
   }
-  CHK(read_phys(qf, &a.nu, &a.E));
   lame_constants(a.nu, a.E, &a.lambda, &a.TwoMu);
   a.waves_per_cu = c->opt.pencil_waves;
   if (split && (add || op->ovl_lead <= 0 || !op->ovl_csr.built))
@@ -566,6 +589,11 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
   CHK(fused_prepare(op, in, out, add, split, F));
   const CsrMap *M = F.M;
   if (!add && !M->full_cover && phase <= 0) CHK(dev_zero(c, F.py, (size_t)out->length));
+  if (F.derived_for) {   // this (whole) residual apply also writes the tangent's derived state beside grad u: valid from here on in stream order
+    CeedVector sv = F.derived_for;
+    sv->derived_valid = true; sv->derived_nelem = F.r->nelem; sv->derived_Q3 = F.b->Q1d * F.b->Q1d * F.b->Q1d;
+    sv->derived_nu = F.a.nu; sv->derived_E = F.a.E;
+  }
   TimerScope ts(op, s);
   if (split) {
     const int lead = op->ovl_lead;

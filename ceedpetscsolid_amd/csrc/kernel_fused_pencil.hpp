@@ -246,6 +246,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
   constexpr int BI = 8, BJ = 8 * SJ, BK = 8 * SK, BC = 8 * SC;        // byte strides
   constexpr int oA = 0, oBX = 8 * G::ARR, oBZ = 16 * G::ARR;         // byte offsets of the arrays
   constexpr bool ST_IN = QFTraits<QF>::state_in, ST_OUT = QFTraits<QF>::state_out;
+  constexpr int NST = QFTraits<QF>::nstate;
   constexpr int QS = Q3;
   static_assert(P <= Q, "interpolation to at least as many points as nodes");
   // re-read the launch arguments at every use (kargs_fresh) where that frees the SGPR file of spills: Q <= 5.  At
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
   // live element instead.
   auto nlive_of = [&](int nelem, int g) { const int n = nelem - g * E; return n < E ? n : E; };  // uniform, >= 1
   constexpr int NSET = RQ >= 2 ? (Q >= 6 ? CPS_PENCIL_NSET_BIGQ : CPS_PENCIL_NSET) : 1;
-  double qd[NSET][10], st[NSET][9];
+  double qd[NSET][10], st[NSET][NST];
   auto load_point = [&](double *qdv, double *stv, int g, int r) {
     const kargs_t ka = kargs_fresh<KA>();  // one scalar load for the fields used here
     const int t = lane + 64 * r, el0 = el_of(t, Q3);
@@ -362,10 +363,10 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       for (int c = 0; c < 10; c++) qdv[c] = (qb + c * Q3)[vo];
     }
     if constexpr (ST_IN) {
-      const double *sb = ka->state_in + e0 * (9 * QS);
-      const uint32_t vs = (uint32_t)(el * (9 * QS) + q);
+      const double *sb = ka->state_in + e0 * (NST * QS);
+      const uint32_t vs = (uint32_t)(el * (NST * QS) + q);
 #pragma unroll
-      for (int c = 0; c < 9; c++) stv[c] = (sb + c * QS)[vs];
+      for (int c = 0; c < NST; c++) stv[c] = (sb + c * QS)[vs];
     }
   };
   auto load_offsets = [&](int g, uint32_t *o) {
@@ -527,7 +528,19 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
         for (int c = 0; c < 10; c++) qdl[c] = qd[r % NSET][c];
       }
       if (live) {
-        qf_point<QF>(Phys{ka->nu, ka->E, ka->lambda, ka->TwoMu}, ug, qdl, st[r % NSET], dv, sto);
+        if constexpr (QF == QF_HYPERFS_F) {
+          double dso[10];
+          double *db = ka->state_out2;      // wave-uniform: also write the derived state of the tangent?
+          qf_point<QF>(Phys{ka->nu, ka->E, ka->lambda, ka->TwoMu}, ug, qdl, st[r % NSET], dv, sto, db ? dso : nullptr);
+          if (db) {
+            db += (size_t)(ka->elem_begin + grp * E) * (10 * QS);
+            const uint32_t vd = (uint32_t)(pel * (10 * QS) + pq);
+#pragma unroll
+            for (int c = 0; c < 10; c++) (db + c * QS)[vd] = dso[c];
+          }
+        } else {
+          qf_point<QF>(Phys{ka->nu, ka->E, ka->lambda, ka->TwoMu}, ug, qdl, st[r % NSET], dv, sto);
+        }
         if constexpr (ST_OUT) {
           double *sb = ka->state_out + (size_t)(ka->elem_begin + grp * E) * (9 * QS);
           const uint32_t vs = (uint32_t)(pel * (9 * QS) + pq);

@@ -23,6 +23,7 @@ enum QFKind : int {
   QF_DIAG_LINELAS,
   QF_DIAG_HYPERSS,
   QF_DIAG_HYPERFS,
+  QF_HYPERFS_DF_DS,   // HyperFSdF reading the DERIVED state (F^-1, lambda ln J - mu) the residual kernel wrote beside grad u
 };
 
 constexpr int MAXN1D = 8;  // largest P or Q supported by the kernel tables
@@ -54,8 +55,9 @@ struct FusedGradArgs {
   const double *x;          // active input L-vector, interlaced [node][3]
   double *y;                // active output L-vector: element-interior nodes are stored here directly (direct)
   const double *qdata;      // [nelem][10][Q^3]
-  const double *state_in;   // [nelem][9][Q^3] or null
+  const double *state_in;   // [nelem][9][Q^3] (QF_HYPERFS_DF_DS: [nelem][10][Q^3], the derived state) or null
   double *state_out;        // [nelem][9][Q^3] or null
+  double *state_out2;       // HyperFSF only, may be null: [nelem][10][Q^3] derived state of the tangent (qf_hyperfs_df_ds), written too
   int nelem;                // elements processed by this launch ...
   int elem_begin;           // ... starting at this element (segments of a pipelined apply, split-phase apply)
   int mask_in, mask_out;    // honour the Dirichlet flags on gather / scatter

@@ -27,7 +27,8 @@ namespace cps {
 #define CPS_JACOBIANS(Pv)              \
   CPS_CASE(Pv, QF_LINELAS, "LinElas")  \
   CPS_CASE(Pv, QF_HYPERSS_DF, "HyperSSdF") \
-  CPS_CASE(Pv, QF_HYPERFS_DF, "HyperFSdF")
+  CPS_CASE(Pv, QF_HYPERFS_DF, "HyperFSdF") \
+  CPS_CASE(Pv, QF_HYPERFS_DF_DS, "HyperFSdF+derived")
 
 hipError_t CPS_CAT(launch_fused_grad_q, CPS_Q)(int P, int qf, const BasisTables &t,
                                                const FusedGradArgs &a, hipStream_t s,

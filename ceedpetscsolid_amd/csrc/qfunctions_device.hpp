@@ -180,7 +180,9 @@ CPS_DEV void fs_lame(const Phys ph, double &lambda, double &mu) {  // hyperFS.h:
   lame(ph, lambda, TwoMu);
   mu = TwoMu / 2;
 }
-CPS_DEV void qf_hyperfs_f(const Phys ph, const double *ug, const double *qd, double *dv, double *st) {
+CPS_DEV void fs_derived_state(double lambda, double mu, const double g[3][3], double *ds);
+// ds (may be null, wave-uniform): the derived state of the tangent, written beside grad u (fs_derived_state)
+CPS_DEV void qf_hyperfs_f(const Phys ph, const double *ug, const double *qd, double *dv, double *st, double *ds = nullptr) {
   double lambda, mu, g[3][3], P[3][3];
   fs_lame(ph, lambda, mu);
   physical_grad(ug, qd, g);
@@ -188,6 +190,7 @@ CPS_DEV void qf_hyperfs_f(const Phys ph, const double *ug, const double *qd, dou
   for (int c = 0; c < 3; c++)
 #pragma unroll
     for (int k = 0; k < 3; k++) st[3 * c + k] = g[c][k];
+  if (ds) fs_derived_state(lambda, mu, g, ds);
   FSState s;
   fs_state<false>(lambda, mu, g, s);
 #pragma unroll
@@ -271,6 +274,58 @@ CPS_DEV void qf_hyperfs_df(const Phys ph, const double *dug, const double *qd, c
       double t = mu * dg[a][b];
 #pragma unroll
       for (int m = 0; m < 3; m++) t += M[a][m] * A[b][m];
+      dP[a][b] = t;
+    }
+  pull_back(dP, qd, dv);
+}
+// DERIVED STATE (index.rst:458-464 discusses the same storage / recompute trade): what the tangent
+// above needs of the state is F^-1 (nine numbers) and f = lambda ln J - mu (one); forming them from the stored grad u costs
+// an adjugate, a determinant, a reciprocal and the log series at every point of every Jacobian apply.  The residual kernel
+// can write them once per Newton step beside grad u (ten doubles per point instead of nine to read afterwards):
+//   ds[3 r + s] = F^-1[r][s],  ds[9] = lambda ln J - mu.
+CPS_DEV void fs_derived_state(double lambda, double mu, const double g[3][3], double *ds) {
+  double F[3][3], A[3][3];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) F[c][k] = g[c][k] + (c == k ? 1. : 0.);
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      const int s1 = (s + 1) % 3, s2 = (s + 2) % 3, r1 = (r + 1) % 3, r2 = (r + 2) % 3;
+      A[r][s] = F[s1][r1] * F[s2][r2] - F[s1][r2] * F[s2][r1];
+    }
+  const double Jdet = F[0][0] * A[0][0] + F[0][1] * A[1][0] + F[0][2] * A[2][0];
+  const double rJ = rcp_nr(Jdet);
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int s = 0; s < 3; s++) ds[3 * r + s] = A[r][s] * rJ;
+  ds[9] = lambda * log1p_series4_shifted_fast(__builtin_fma(Jdet, Jdet, -1.)) * 0.5 - mu;
+}
+// dP = mu grad(du) + (lambda tr(h) I - f h^T) F^-T,  h = grad(du) F^-1, from the derived state
+CPS_DEV void qf_hyperfs_df_ds(const Phys ph, const double *dug, const double *qd, const double *ds, double *dv) {
+  double lambda, mu, dg[3][3], h[3][3], dP[3][3];
+  fs_lame(ph, lambda, mu);
+  physical_grad(dug, qd, dg);
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int n = 0; n < 3; n++) {
+      double t = 0.;
+#pragma unroll
+      for (int m = 0; m < 3; m++) t += dg[a][m] * ds[3 * m + n];
+      h[a][n] = t;
+    }
+  const double ltrh = lambda * (h[0][0] + h[1][1] + h[2][2]), f = ds[9];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      double t = mu * dg[a][b] + ltrh * ds[3 * b + a];       // (lambda tr h I) F^-T
+#pragma unroll
+      for (int m = 0; m < 3; m++) t -= f * h[m][a] * ds[3 * b + m];
       dP[a][b] = t;
     }
   pull_back(dP, qd, dv);
@@ -379,20 +434,23 @@ CPS_DEV void qf_setup_geo_rcp(const double *Jg, double w, double *qd) {
 // ---- uniform dispatch used by the fused kernels ----------------------------
 // HAS_STATE_IN : Jacobians of the non-linear models read the stored gradu
 // HAS_STATE_OUT: their residuals write it
+// nstate: components of the state read per point (9: grad u; 10: the derived state of the finite-strain tangent)
 template <int QF> struct QFTraits;
-template <> struct QFTraits<QF_LINELAS>    { static constexpr bool state_in = false, state_out = false; };
-template <> struct QFTraits<QF_HYPERSS_F>  { static constexpr bool state_in = false, state_out = true;  };
-template <> struct QFTraits<QF_HYPERSS_DF> { static constexpr bool state_in = true,  state_out = false; };
-template <> struct QFTraits<QF_HYPERFS_F>  { static constexpr bool state_in = false, state_out = true;  };
-template <> struct QFTraits<QF_HYPERFS_DF> { static constexpr bool state_in = true,  state_out = false; };
+template <> struct QFTraits<QF_LINELAS>    { static constexpr bool state_in = false, state_out = false; static constexpr int nstate = 9; };
+template <> struct QFTraits<QF_HYPERSS_F>  { static constexpr bool state_in = false, state_out = true;  static constexpr int nstate = 9; };
+template <> struct QFTraits<QF_HYPERSS_DF> { static constexpr bool state_in = true,  state_out = false; static constexpr int nstate = 9; };
+template <> struct QFTraits<QF_HYPERFS_F>  { static constexpr bool state_in = false, state_out = true;  static constexpr int nstate = 9; };
+template <> struct QFTraits<QF_HYPERFS_DF> { static constexpr bool state_in = true,  state_out = false; static constexpr int nstate = 9; };
+template <> struct QFTraits<QF_HYPERFS_DF_DS> { static constexpr bool state_in = true, state_out = false; static constexpr int nstate = 10; };
 
 template <int QF>
 CPS_DEV void qf_point(const Phys ph, const double *ug, const double *qd, const double *st_in,
-                      double *dv, double *st_out) {
+                      double *dv, double *st_out, double *derived_out = nullptr) {
   if constexpr (QF == QF_LINELAS) qf_linelas(ph, ug, qd, dv);
   else if constexpr (QF == QF_HYPERSS_F) qf_hyperss_f(ph, ug, qd, dv, st_out);
   else if constexpr (QF == QF_HYPERSS_DF) qf_hyperss_df(ph, ug, qd, st_in, dv);
-  else if constexpr (QF == QF_HYPERFS_F) qf_hyperfs_f(ph, ug, qd, dv, st_out);
+  else if constexpr (QF == QF_HYPERFS_F) qf_hyperfs_f(ph, ug, qd, dv, st_out, derived_out);
+  else if constexpr (QF == QF_HYPERFS_DF_DS) qf_hyperfs_df_ds(ph, ug, qd, st_in, dv);
 #ifdef CPS_FS_REFERENCE_FORM  // A/B builds only
   else if constexpr (QF == QF_HYPERFS_DF) qf_hyperfs_df_reference_form(ph, ug, qd, st_in, dv);
 #else

@@ -767,6 +767,48 @@ def test_affine_elements_take_the_per_element_factors(gpu, oracle, product_lib, 
 
 
 @pytest.mark.gpu
+def test_derived_state_of_the_finite_strain_tangent(gpu, oracle, product_lib):
+    """HyperFSF leaves, beside the stored grad u, the DERIVED state HyperFSdF needs -- F^-1 and lambda ln J - mu, ten doubles
+    per point -- and the Jacobian kernels read that instead of forming an adjugate, a determinant, a reciprocal and the log
+    series at every point of every apply (qfunctions_device.hpp; hyperFS.h:286-464 is the map).  Same numbers as the plain
+    form (CEED_MI355X_DERIVED=0) and as the oracle, every level, nu up to 0.49; and the derived state is DROPPED when the
+    application writes grad u itself: the Jacobian must then follow the new values."""
+    plain = _ceed_with_env(product_lib, "CEED_MI355X_DERIVED", "0")
+    for mesh, degree, nu, amp in ((distorted_box(3, 2, 3, seed=2, amp=0.2), 4, 0.3, 0.1), (distorted_box(2, 2, 1, seed=3, amp=0.2), 6, 0.49, 0.05),
+                                  (hollow_cylinder_mesh(2, 8, 3), 2, 0.3, 0.3)):
+        outs, probs = [], []
+        for c in (gpu, plain, oracle):
+            p = SolidProblem(c, mesh, degree, "hyperFS", nu=nu, E=2.0, bc_sides=[1] if 1 in mesh.side_sets else [998])
+            n = p.lsize()
+            X, R = c.vector(n), c.vector(n)
+            X.set_array(p.smooth_state(amp)); p.form_residual(X, R)
+            res = [R.to_numpy()]
+            for lv in range(len(p.levels)):
+                nl = p.lsize(lv)
+                x = c.vector(nl).set_array(np.random.default_rng(7 + lv).uniform(-1, 1, nl))
+                y = c.vector(nl)
+                p.apply_jacobian(lv, x, y)
+                res.append(y.to_numpy())
+            outs.append(res); probs.append(p)
+        assert "HyperFSdF+derived" in probs[0].levels[probs[0].fine].opJacob.kernel_name
+        assert "derived" not in probs[1].levels[probs[1].fine].opJacob.kernel_name
+        for a, b, o in zip(*outs):
+            assert rel_err(a, b) < 1e-13
+            assert rel_err(a, o) < 1e-10
+        # the application overwrites grad u (half of it): both libraries must now linearise about THAT state
+        ys = []
+        for c, p in ((gpu, probs[0]), (plain, probs[1])):
+            p.gradu.set_array(0.5 * p.gradu.to_numpy())
+            nl = p.lsize()
+            x = c.vector(nl).set_array(np.random.default_rng(99).uniform(-1, 1, nl))
+            y = c.vector(nl)
+            p.apply_jacobian(p.fine, x, y)
+            ys.append(y.to_numpy())
+        assert "derived" not in probs[0].levels[probs[0].fine].opJacob.kernel_name
+        assert rel_err(ys[0], ys[1]) < 1e-13 and rel_err(ys[0], outs[0][-1]) > 1e-3
+
+
+@pytest.mark.gpu
 def test_overwritten_qdata_is_read_not_recomputed(gpu):
     """The recompute is only valid while qdata is SetupGeo's output: any other write to the vector must switch the
     operators back to reading it.  Doubling all ten entries multiplies the linear-elastic action by 2 (w detJ) x 2 x 2

@@ -41,7 +41,7 @@ out = {"kernel": bench["config"]["kernel"], "elements_per_gpu": bench["config"][
        "note": "rocprofv3 serialises the kernels while it collects counters: the bytes are those of the launches run one after the other",
        "fetch_calibration_factor": f_cal, "write_calibration_factor": w_cal, "per_kernel": {}}
 tot = 0.0
-for name in ("k_fused_pencil<5, 5, 6", "k_fused_grad<5, 5, 6>", "k_assemble(", "k_assemble_gated", "k_assemble_tail"):
+for name in (os.environ.get("KPAT", "k_fused_pencil<5, 5, 6"), "k_assemble("):
     kf, kw = find(fetch, name), find(write, name)
     if not kf: continue
     fb = per_apply(fetch[kf[0]]["FETCH_SIZE"]) * 1024.0 * (f_cal or 2.0)

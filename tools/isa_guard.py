@@ -59,7 +59,7 @@ def kernel_meta(co):
     return out
 
 
-QF_NAMES = {2: "LinElas", 3: "HyperSSF", 4: "HyperSSdF", 5: "HyperFSF", 6: "HyperFSdF"}
+QF_NAMES = {2: "LinElas", 3: "HyperSSF", 4: "HyperSSdF", 5: "HyperFSF", 6: "HyperFSdF", 17: "HyperFSdF+derived"}
 
 
 def short_name(mangled):
