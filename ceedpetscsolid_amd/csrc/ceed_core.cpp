@@ -87,8 +87,6 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   o.comm_inline = env_int("CEED_MI355X_COMM_INLINE", o.comm_inline);
   o.halo_capture = env_int("CEED_MI355X_HALO_CAPTURE", o.halo_capture);
   o.fold_pack = env_int("CEED_MI355X_FOLD_PACK", o.fold_pack);
-  o.reserve_cus = std::max(0, env_int("CEED_MI355X_RESERVE_CUS", 0));
-  o.reserve_from = std::max(0, env_int("CEED_MI355X_RESERVE_FROM", 0));
   *ceed = c;
   return 0;
 }
@@ -124,16 +122,8 @@ void ceed_unref(Ceed c) {
 }
 int ceed_need_side_stream(Ceed c) {
   if (c->side_stream) return 0;
-  if (c->opt.reserve_cus > 0) {
-    // EXPERIMENT (CEED_MI355X_RESERVE_CUS=n [CEED_MI355X_RESERVE_FROM=b]): the side stream -- phase 1 of a two-stream split-phase
-    // apply -- may not use n compute units (mask bits b .. b + n - 1), so that RCCL's 256-thread, 132-register, 20 KB
-    // workgroups find a place while the fused kernel's resident waves hold every other CU (tools/microbench/cu_mask.hip)
-    const int ncu = device_cu_count(), nw = (ncu + 31) / 32;
-    std::vector<uint32_t> mask((size_t)nw, 0xFFFFFFFFu);
-    if (ncu % 32) mask[(size_t)nw - 1] = (1u << (ncu % 32)) - 1u;
-    for (int b = c->opt.reserve_from; b < c->opt.reserve_from + c->opt.reserve_cus && b < ncu; b++) mask[(size_t)b / 32] &= ~(1u << (b % 32));
-    HIPCHK(hipExtStreamCreateWithCUMask(&c->side_stream, (uint32_t)nw, mask.data()));
-  } else
+  // (A side stream created with hipExtStreamCreateWithCUMask, leaving one or two CUs per XCD to RCCL's kernel, was measured in round 3:
+  // every kernel on the masked queue ran 2-3x longer with 100-us gaps, 650-800 us per apply instead of 108: profiles/r03_ab_experiments.txt.)
   HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));

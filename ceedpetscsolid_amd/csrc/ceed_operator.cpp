@@ -408,7 +408,7 @@ static int fused_prepare(CeedOperator op, CeedVector in, CeedVector out, bool ad
     CeedVector sv = op->in[op->i_state].vec;
     CHK(vec_dev(sv, false, &ps)); a.state_in = ps;
     // the derived state the residual kernel left beside grad u, if it still belongs to it (same elements, points, material)
-    if (qf->kind == QF_HYPERFS_DF && c->opt.derived_state && sv->derived_valid && sv->derived_nelem == r->nelem && sv->derived_Q3 == Q3 &&
+    if (qf->kind == QF_HYPERFS_DF && c->opt.derived_state && pencil_derived_state(ai.basis->Q1d) && sv->derived_valid && sv->derived_nelem == r->nelem && sv->derived_Q3 == Q3 &&
         sv->derived_nu == a.nu && sv->derived_E == a.E) {
       F.qfkind = QF_HYPERFS_DF_DS;
       a.state_in = sv->derived;
@@ -418,7 +418,7 @@ static int fused_prepare(CeedOperator op, CeedVector in, CeedVector out, bool ad
     CeedVector sv = op->out[op->o_state].vec;
     if (!sv || sv == CEED_VECTOR_NONE || sv == CEED_VECTOR_ACTIVE) return ceed_error("state output needs a passive vector");
     CHK(vec_dev(sv, true, &ps)); a.state_out = ps;  // every point is overwritten (and the derived state invalidated)
-    if (qf->kind == QF_HYPERFS_F && c->opt.derived_state && !split) {
+    if (qf->kind == QF_HYPERFS_F && c->opt.derived_state && pencil_derived_state(ai.basis->Q1d) && !split) {
       const size_t need = (size_t)r->nelem * 10 * Q3;
       if (sv->derived_len < need) {
         if (c->capturing) return ceed_error("evaluate the residual once before recording (derived-state buffer)");

@@ -49,6 +49,9 @@ constexpr int OFF_FLAG_SHIFT = 29;
 // the additions cost what the halved products save (measured -1.6 % at Q = 3); at Q = 8 an even-odd table (36
 // coefficients) no longer fits the 60 SGPRs a pass has for its table.
 constexpr bool pencil_even_odd(int Q) { return Q >= 4 && Q <= 7; }
+// The derived state of the finite-strain tangent (QF_HYPERFS_DF_DS) is used -- and written by the residual kernel -- from Q = 6 on:
+// measured -2.6 ... -3.1 % there, +-0 % at Q = 5 (profiles/r03_ab_experiments.txt item 3), for ten more doubles per point stored.
+constexpr bool pencil_derived_state(int Q) { return Q >= 6; }
 
 struct FusedGradArgs {
   const uint32_t *offsets;  // [nelem][P^3] (flagged)

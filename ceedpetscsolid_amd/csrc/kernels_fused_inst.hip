@@ -24,11 +24,18 @@ namespace cps {
     *name = "fused_grad<P=" #Pv ",Q=" CPS_STR(CPS_Q) "," QFname ">/pencil";         \
     return launch_fused_pencil_t<Pv, CPS_Q, QFv>(t, a, s);                          \
   }
+// The derived-state tangent is instantiated where it measured a gain: Q >= 6 (one element per wave; -2.6 ... -3.1 % on config 5's
+// block, same box); at Q = 5 it removes 9 % of the VALU instructions and 0 % of the time (pencil_derived_state, kernels.hpp).
+#if CPS_Q >= 6
+#define CPS_DERIVED(Pv) CPS_CASE(Pv, QF_HYPERFS_DF_DS, "HyperFSdF+derived")
+#else
+#define CPS_DERIVED(Pv)
+#endif
 #define CPS_JACOBIANS(Pv)              \
   CPS_CASE(Pv, QF_LINELAS, "LinElas")  \
   CPS_CASE(Pv, QF_HYPERSS_DF, "HyperSSdF") \
   CPS_CASE(Pv, QF_HYPERFS_DF, "HyperFSdF") \
-  CPS_CASE(Pv, QF_HYPERFS_DF_DS, "HyperFSdF+derived")
+  CPS_DERIVED(Pv)
 
 hipError_t CPS_CAT(launch_fused_grad_q, CPS_Q)(int P, int qf, const BasisTables &t,
                                                const FusedGradArgs &a, hipStream_t s,

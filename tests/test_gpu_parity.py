@@ -774,8 +774,8 @@ def test_derived_state_of_the_finite_strain_tangent(gpu, oracle, product_lib):
     form (CEED_MI355X_DERIVED=0) and as the oracle, every level, nu up to 0.49; and the derived state is DROPPED when the
     application writes grad u itself: the Jacobian must then follow the new values."""
     plain = _ceed_with_env(product_lib, "CEED_MI355X_DERIVED", "0")
-    for mesh, degree, nu, amp in ((distorted_box(3, 2, 3, seed=2, amp=0.2), 4, 0.3, 0.1), (distorted_box(2, 2, 1, seed=3, amp=0.2), 6, 0.49, 0.05),
-                                  (hollow_cylinder_mesh(2, 8, 3), 2, 0.3, 0.3)):
+    for mesh, degree, nu, amp in ((distorted_box(3, 2, 3, seed=2, amp=0.2), 5, 0.3, 0.1), (distorted_box(2, 2, 1, seed=3, amp=0.2), 6, 0.49, 0.05),
+                                  (hollow_cylinder_mesh(2, 6, 2), 7, 0.3, 0.2), (hollow_cylinder_mesh(2, 8, 3), 4, 0.3, 0.3)):
         outs, probs = [], []
         for c in (gpu, plain, oracle):
             p = SolidProblem(c, mesh, degree, "hyperFS", nu=nu, E=2.0, bc_sides=[1] if 1 in mesh.side_sets else [998])
@@ -790,7 +790,8 @@ def test_derived_state_of_the_finite_strain_tangent(gpu, oracle, product_lib):
                 p.apply_jacobian(lv, x, y)
                 res.append(y.to_numpy())
             outs.append(res); probs.append(p)
-        assert "HyperFSdF+derived" in probs[0].levels[probs[0].fine].opJacob.kernel_name
+        # used from Q = 6 on (where it measured a gain: kernels.hpp, pencil_derived_state); below, the plain tangent
+        assert ("HyperFSdF+derived" in probs[0].levels[probs[0].fine].opJacob.kernel_name) == (degree + 1 >= 6)
         assert "derived" not in probs[1].levels[probs[1].fine].opJacob.kernel_name
         for a, b, o in zip(*outs):
             assert rel_err(a, b) < 1e-13

@@ -77,7 +77,10 @@ def test_config3_full_solve_on_the_device(gpu):
     """BASELINE config 3 as stated: hyperSS, cylinder8_5580e_4ss_us (the reference's own mesh), degree 4, the FULL
     Newton-CG-pMG solve (10 load increments, levels p = 1, 2, 4, assembled coarse level) on one MI355X.  Pinned: convergence
     of every increment, the Newton count (3 per increment), a Krylov count in the band the matrix-free and the assembled
-    coarse solve both give, the clamp displacement reached, and a final residual at the solver's tolerance."""
+    coarse solve both give, the clamp displacement reached, and a final residual at the solver's tolerance.
+    THE LOAD the pinned counts belong to: -bc_clamp_998_translate 0,-0.05,0.1 -- a TENTH of the README's 0,-0.5,1
+    (README.rst:63, whose minimal command runs linElas).  At the README's load linElas converges (10 / 210 iterations) and
+    neither hyperelastic model gets through the first of 10 or 40 increments (profiles/r03_config3_readme_load.txt)."""
     mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_5580e_4ss_us.npz"))
     p = SolidProblem(gpu, mesh, 4, "hyperSS", nu=0.3, E=1e3, bc_sides=[998, 999])
     assert p.degrees == [1, 2, 4] and p.n_free() == 1150068
