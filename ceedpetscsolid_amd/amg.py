@@ -207,12 +207,11 @@ class AggregationAMG:
         t0 = time.perf_counter()
         asm, c = self.asm, self.ceed
         n = asm.nrows
-        lvl = asm.p.levels[asm.level]
-        constrained = lvl.mask != 0
+        constrained = np.asarray(asm.mask) != 0          # (of the matrix's rows: the global ones when the level is replicated)
         A_host = sp.csr_matrix((asm.csr.values(c), asm.cols, asm.rowptr), shape=(n, n))
         nn = n // 3
         dof_ptr = 3 * np.arange(nn + 1, dtype=np.int64)
-        B = rigid_body_modes(lvl.dofmap.node_coords, constrained)
+        B = rigid_body_modes(np.asarray(asm.node_coords), constrained)
         free_node = ~constrained.reshape(nn, 3).all(axis=1)       # fully constrained nodes have identity rows
         A_csr = asm.csr
         self.levels = []

@@ -96,8 +96,9 @@ def read_exodus(path: str) -> HexMesh:
     """Exodus II (NetCDF classic CDF-2) reader for the reference's ``meshes/*.exo``: HEX8 blocks, and HEX27 blocks through
     their eight corner nodes (the first eight of an Exodus HEX27; the mid-edge / mid-face / centre nodes carry no
     information for an isoparametric trilinear geometry and are dropped).  Boundaries: side sets (``*_ss_*``), or -- the
-    ``*_ns_*`` files, SURVEY App. D -- node sets, turned into side sets: an element face belongs to set ``id`` when
-    all four of its corner nodes do."""
+    ``*_ns_*`` files, SURVEY App. D -- node sets, turned into side sets: a BOUNDARY face (one owned by exactly one element)
+    belongs to set ``id`` when all four of its corner nodes do (interior faces never: a mesh one element thick between two
+    surfaces of a set would otherwise turn them into boundary faces -- ADVICE r2)."""
     from scipy.io import netcdf_file
     f = netcdf_file(path, "r", mmap=False)
     v = f.variables
@@ -132,6 +133,11 @@ def read_exodus(path: str) -> HexMesh:
         renum[used] = np.arange(used.size)
         cells, coords = renum[cells], coords[used]
         node_sets = {sid: renum[ns][renum[ns] >= 0] for sid, ns in node_sets.items()}
+    boundary = None
+    if node_sets:                                   # faces owned by exactly one element, per local face
+        allf = np.concatenate([np.sort(cells[:, [c for c in range(8) if ((c >> (f // 2)) & 1) == f % 2]], axis=1) for f in range(6)], axis=0)
+        _, inv, cnt = np.unique(allf, axis=0, return_inverse=True, return_counts=True)
+        boundary = (cnt[inv] == 1).reshape(6, cells.shape[0])
     for sid, ns in node_sets.items():
         inset = np.zeros(coords.shape[0], dtype=bool)
         inset[ns] = True
@@ -139,7 +145,7 @@ def read_exodus(path: str) -> HexMesh:
         for face in range(6):                       # local faces as in box_mesh: 0 x-, 1 x+, 2 y-, 3 y+, 4 z-, 5 z+
             axis, side = face // 2, face % 2
             corners = [c for c in range(8) if ((c >> axis) & 1) == side]
-            el = np.nonzero(inset[cells[:, corners]].all(axis=1))[0]
+            el = np.nonzero(inset[cells[:, corners]].all(axis=1) & boundary[face])[0]
             faces.append(np.stack([el, np.full(el.size, face)], axis=1))
         ss.setdefault(sid, np.concatenate(faces, axis=0))
     mesh = HexMesh(coords, cells, ss, name=path.split("/")[-1])
