@@ -206,6 +206,11 @@ def main():
                     help="also launch k_axpby over a 1 GiB vector (known byte count) for PMC calibration")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout: libraries that print there on their own (RCCL's version banner at communicator start-up) go to
+    # stderr until the line is printed
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -437,7 +442,9 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, args.nr, args.nth)
             except Exception as e:  # the baseline is informational; never hide the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
