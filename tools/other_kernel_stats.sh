@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel time of the fused + assemble kernels for the other models / shapes (GPU box)
-cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-/root/repo}
 run() {
   tag=$1; shift; rm -rf /tmp/os_$tag
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/os_$tag -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline "$@" > /tmp/os_$tag.log 2>&1
