@@ -67,7 +67,9 @@ def run(rank, world, initfile, outdir, mode):
     w = torch.from_numpy(halo.owner_weight.copy())
     dot = halo.dot(torch.from_numpy(x), y, w)
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), y=y.numpy(), keys=lv.dofmap.node_keys, nglob=nglob, dot=dot,
-             nshared=halo.n_shared_dofs, mask=lv.mask, x=x)
+             nshared=halo.n_shared_dofs, mask=lv.mask, x=x, nlead=int(lead.sum()),
+             neigh_rank=np.array([nb.rank for nb in halo.neigh]), neigh_n=np.array([nb.dof_idx.numel() for nb in halo.neigh]),
+             neigh_keys=np.concatenate([lv.dofmap.node_keys[(nb.dof_idx.numpy()[::3] // 3)] for nb in halo.neigh]) if halo.neigh else np.zeros((0, 7), dtype=np.int64))
     dist.destroy_process_group()
 
 

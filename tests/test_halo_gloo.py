@@ -92,6 +92,32 @@ def test_strong_scaling_partitions_match_single_rank(oracle, mode, world):
         assert rel_err(part["y"].reshape(-1, 3)[shared_kind], yref[idx]) < 1e-11
 
 
+@pytest.mark.parametrize("mode,world", [("strong-cyl", 3), ("blocks", 4)])
+def test_emulated_rank_has_the_neighbour_lists_of_the_real_job(mode, world):
+    """bench.py --emulate-rank runs ONE rank of a partitioned job on a single GPU; its neighbour lists come from
+    halo.virtual_world (the other ranks' boundary elements numbered locally) instead of the collectives.  They must be the
+    lists the real job has: same neighbour ranks, same entries in the same order (compared through the partition-independent
+    node keys), same interface-touching elements -- against an actual gloo run of every rank."""
+    from ceedpetscsolid_amd.halo import HaloExchange, interface_elements, part_box, part_cylinder, virtual_world
+    from ceedpetscsolid_amd.mesh import build_dofmap, reorder_elements_first
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_halo_worker.run, args=(world, os.path.join(d, "init"), d, mode), nprocs=world, join=True)
+        parts = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(world)]
+    part = (lambda r: part_cylinder(r, world, 2, 6, 5)) if mode == "strong-cyl" else (lambda r: part_box(r, world, 4, 4, 2))
+    for K in range(world):
+        mesh = part(K)
+        vw = virtual_world(K, world, mesh, part, 3)
+        lead = interface_elements(mesh, virtual=vw)
+        assert int(lead.sum()) == int(parts[K]["nlead"])
+        mesh = reorder_elements_first(mesh, lead)
+        dm = build_dofmap(mesh, 3)
+        h = HaloExchange(mesh, dm, device="cpu", virtual=vw)
+        assert [nb.rank for nb in h.neigh] == list(parts[K]["neigh_rank"])
+        assert [nb.dof_idx.numel() for nb in h.neigh] == list(parts[K]["neigh_n"])
+        keys = np.concatenate([dm.node_keys[nb.dof_idx.numpy()[::3] // 3] for nb in h.neigh])
+        assert np.array_equal(keys, parts[K]["neigh_keys"])
+
+
 @pytest.mark.parametrize("coarse", ["chebyshev", "assembled", "amg"])
 def test_two_rank_solve_matches_single_rank(oracle, coarse):
     """The whole Newton - PCG - pMG solve on two element partitions (halo sums after every operator, ownership-
