@@ -701,6 +701,9 @@ hipError_t launch_fused_pencil_t(const BasisTables &t, const FusedGradArgs &a, h
   if (a.query_waves) { *a.query_waves = resident; return hipSuccess; }
   int grid = resident;
   if (a.wave_groups > 0) grid = ((ngroups + a.wave_groups - 1) / a.wave_groups + 7) / 8 * 8;
+  // (A persistent grid SHRUNK so that every wave gets the same number of groups -- 1 650 waves x 4 groups instead of 2 048 x 3.2 at
+  // 13 200 hexes -- was measured in round 3: 3 ... 14 % slower at every size from 5 500 to 99 000 hexes.  More waves in flight beat an
+  // even finish: profiles/r03_ab_experiments.txt item 11.)
   if (grid > ngroups) grid = ngroups;
   if (a.geo && a.geo_aff) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, 2>), dim3(grid), dim3(64), 0, s, t, a);
   else if (a.geo) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, 1>), dim3(grid), dim3(64), 0, s, t, a);
