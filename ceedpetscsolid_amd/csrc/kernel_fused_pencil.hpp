@@ -220,7 +220,10 @@ CPS_DEV void pencil_pass(ktab_t table, const ldsp_t (&addr)[R], int lane, int nt
 #ifndef CPS_PENCIL_NSET
 #define CPS_PENCIL_NSET 2   // q-point register sets: 2 = every round's data is requested two rounds ahead
 #endif                      // (198 VGPRs with the hyperFS tangent; 1 set: 4-6 % slower; 3 sets: no gain)
-constexpr int pencil_minw(int) { return CPS_PENCIL_MINW; }
+#ifndef CPS_PENCIL_MINW5
+#define CPS_PENCIL_MINW5 CPS_PENCIL_MINW   // (tuning hook for variant builds: Q = 5 only)
+#endif
+constexpr int pencil_minw(int Q) { return Q == 5 ? CPS_PENCIL_MINW5 : CPS_PENCIL_MINW; }
 #ifndef CPS_PENCIL_NSET_BIGQ
 #define CPS_PENCIL_NSET_BIGQ 1   // Q >= 6: the split-table passes keep all rounds' pencils in VGPRs; a second q-point set
 #endif                           // would push the hyperFS tangent past 256 VGPRs (26 spilled to scratch)

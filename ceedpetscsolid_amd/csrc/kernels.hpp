@@ -187,7 +187,10 @@ hipError_t launch_diag(int P, int Q, int qf, const BasisTables &t, const DiagArg
 
 // elements per wave (= per group) of the pencil kernel, PencilGeom<P, Q>::E: 3 Q^2 pencils per element and pass against 64
 // lanes and the 9 Q^3-double LDS slab per element
-constexpr int pencil_group_elems(int Q) { return Q <= 2 ? 8 : (Q <= 4 ? 4 : (Q == 5 ? 2 : 1)); }
+#ifndef CPS_PENCIL_E5
+#define CPS_PENCIL_E5 2      // (tuning hook for variant builds: elements per wave at Q = 5)
+#endif
+constexpr int pencil_group_elems(int Q) { return Q <= 2 ? 8 : (Q <= 4 ? 4 : (Q == 5 ? CPS_PENCIL_E5 : 1)); }
 
 // Deterministic, atomic-free E^T: y[node_off[r] + c] (+)= sum over the node's contributors, in element
 // order, of E[3 * cols[k] + c] (cols[k] = e * P3 + n).  `flags` (one byte per node, bit c = component c constrained) may be null.
