@@ -202,6 +202,9 @@ def main():
     ap.add_argument("--of", type=int, default=8, metavar="N")
     ap.add_argument("--cold-idle-s", type=float, default=1.0,
                     help="idle time before the COLD timing of --steps applies (reported as ms_per_step_cold; 0: skipped)")
+    ap.add_argument("--phase-timing", default=None, metavar="FILE",
+                    help="diagnostic, needs a library built with -DCPS_PHASE_TIMING=<k> (tools/mkvariant.sh): after the timed loop one more "
+                         "apply with the waves' phase time stamps collected; mean shader cycles per phase of the fused kernel -> FILE")
     ap.add_argument("--calibrate-traffic", action="store_true",
                     help="also launch k_axpby over a 1 GiB vector (known byte count) for PMC calibration")
     args = ap.parse_args()
@@ -359,6 +362,25 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = op.get_timing()
     op.set_timing(False)
+    if args.phase_timing:
+        pbuf = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
+        os.environ["CEED_MI355X_PHASE_BUF"] = hex(pbuf.data_ptr())
+        step(); torch.cuda.synchronize()
+        del os.environ["CEED_MI355X_PHASE_BUF"]
+        tb = pbuf.cpu().numpy().reshape(-1, 32)
+        tb = tb[tb[:, 0] > 0]
+        names = ["requests+gather", "F1", "F2", "F3", "F4", "F5", "geo->LDS"] + [f"physics {r}" for r in range(9)] + ["B1", "B2", "B3", "x+B4", "B5", "final"]
+        with open(args.phase_timing, "w") as f:
+            f.write(f"# {len(tb)} waves, shader-clock cycles per phase of one group (mean, median, p90)\n")
+            prev = 0
+            for i in range(1, 23):
+                if not (tb[:, i] > 0).all():
+                    continue
+                d = tb[:, i] - tb[:, prev]
+                f.write("%-16s %8.0f %8.0f %8.0f\n" % (names[prev], d.mean(), np.median(d), np.percentile(d, 90)))
+                prev = i
+            d = tb[:, prev] - tb[:, 0]
+            f.write("%-16s %8.0f %8.0f %8.0f\n" % ("whole group", d.mean(), np.median(d), np.percentile(d, 90)))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

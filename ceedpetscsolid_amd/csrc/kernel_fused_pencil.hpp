@@ -56,6 +56,34 @@ template <int P, int Q> struct PencilGeom {
 // output is still in flight, so it may copy or spill the register before the wait -- it did.)
 typedef __attribute__((address_space(3))) double lds_double;
 typedef volatile lds_double *ldsp_t;
+typedef volatile __attribute__((address_space(3))) char *ldsb_t;
+// Wave priority by phase (s_setprio, 0 ... 3).  The two waves of a SIMD share its vector pipe; the arbiter prefers the higher
+// priority.  A wave in its pencil passes issues short bursts of FMAs between LDS round trips, a wave in its q-point rounds a long
+// run of them: with the passes at 3 and the q-point rounds at 0 a pass never waits behind the other wave's physics, its LDS
+// latency is hidden by that physics, and two waves that started together drift half a group apart by themselves.  Same-box A/B
+// (profiles/r03_ab_experiments.txt item 13): config 4 -2.6 %, 13 200 hexes -8 %, config 5's block -3.6 %, p = 2 -6.5 %; a
+// level for the requests / gather / final stores of their own, and for the loads and stores inside a q-point round: no
+// further gain; the staggered start of round 2 (-1.9 % then) adds nothing beside it and left the kernel.
+// (the levels are tuning hooks for variant builds, tools/mkvariant.sh; -1: never set)
+#ifndef CPS_PRIO_TOP
+#define CPS_PRIO_TOP -1    // requests for the next group, gather, final stores: stay at the passes' level
+#endif
+#ifndef CPS_PRIO_PASS
+#define CPS_PRIO_PASS 3    // the twelve pencil passes
+#endif
+#ifndef CPS_PRIO_PHYS
+#define CPS_PRIO_PHYS 0    // the q-point rounds
+#endif
+template <int LEVEL> CPS_DEV void set_prio() {
+  if constexpr (LEVEL >= 0) __builtin_amdgcn_s_setprio(LEVEL);
+}
+// (diagnostic build only, tools/phase_timing.py) -DCPS_PHASE_TIMING=<k>: every wave writes the shader-clock time stamps of the
+// phase boundaries of its k-th group to the buffer whose address the environment gives (CEED_MI355X_PHASE_BUF), 32 per wave.
+#ifdef CPS_PHASE_TIMING
+#define CPS_PH(i) do { if (ph_iter == CPS_PHASE_TIMING && lane == 0 && ph_buf) ph_buf[(size_t)blockIdx.x * 32 + (i)] = clock64(); } while (0)
+#else
+#define CPS_PH(i) do { } while (0)
+#endif
 template <int OFF>
 CPS_DEV double lds_rd(ldsp_t a) {
   static_assert(OFF >= 0 && OFF < 65536 && OFF % 8 == 0, "ds offset field is 16 bits");
@@ -261,17 +289,6 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
   constexpr bool geo = GEO != 0;   // the geometric factors are not read from qdata
   constexpr int NCO = GEO == 2 ? GEO_NAFF : GEO_NCOEF;   // doubles per element kept in LDS for them
   const int lane = threadIdx.x & 63;
-#ifndef CPS_NO_STAGGER
-  // Staggered start (large launches only: every wave has at least four groups): the persistent waves of a launch begin
-  // within a microsecond of each other and would walk through their phases -- gather, passes, q-point loads, physics,
-  // stores -- in step, all of the chip bursting on memory together.  A pseudo-random delay of 0 ... 6.5 us per workgroup
-  // (15 x s_sleep 16) spreads them over about half a group period.  Same-box A/B (profiles/r02_ab_experiments.txt): fused
-  // kernel 374.2 -> 367.1 us (-1.9 %); a fixed half-period delay of every second wave of a SIMD: -0.1 ... -1.2 %; per-CU
-  // slot-wise delays up to 12 us: -1.8 %; random up to 13 us: -1.2 %.
-  if ((a.nelem + E - 1) / E >= 4 * (int)gridDim.x)
-    for (int i = 0; i < (int)((blockIdx.x * 2654435761u) >> 28) * 2; i++) __builtin_amdgcn_s_sleep(8);
-#endif
-
   // ---- work list of this wave -----------------------------------------------------------------------
   // The groups are cut into 8 contiguous chunks, one per XCD (neighbouring elements share their nodes through one L2):
   // block b serves chunk b % 8 (blocks b and b + 8 share an XCD under the round-robin placement), group = chunk begin +
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
   if (geo && lane < 2 * Q) {   // 1-D points then weights (written once; the LDS queue orders it before any read)
     const auto kp = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(BasisTables);
     const double v = lane < Q ? ((kargs_t)kp)->qref[lane] : ((kargs_t)kp)->qwt[lane - Q];
-    *(ldsp_t)((volatile __attribute__((address_space(3))) char *)lds0 + oGT + lane * 8) = v;
+    *(ldsp_t)((ldsb_t)lds0 + oGT + lane * 8) = v;
   }
   uint32_t nd_interior = 0;  // bit r: this lane's node of round r is interior to its element (direct store to y)
   uint32_t ev_idx[(RN + 1) / 2] = {};  // E-vector entry (in doubles) of this lane's node within the group's block, 16 bits each
@@ -401,7 +418,12 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
 #pragma unroll
   for (int t = 0; t < NSET; t++) load_point(qd[t], st[t], grp, t);
 
+#ifdef CPS_PHASE_TIMING
+  int ph_iter = 0;
+  long long *const ph_buf = (long long *)a.query_waves;
+#endif
   for (;;) {
+    CPS_PH(0);
     const int grp_nx = grp + wper;
     const bool more = grp_nx < gend;  // wave-uniform
     const int g_nx = more ? grp_nx : grp;
@@ -434,8 +456,12 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     }
 
     // ---- B: nodes -> points, in place -----------------------------------------------------------------
+    set_prio<CPS_PRIO_PASS>();
+    CPS_PH(1);
     pencil_pass<P, Q, P, false, BI, oA, oA, +1, EO>(tBf, aIP, lane, E * T_IP);   // F1: along i at nodal (j, k)
+    CPS_PH(2);
     pencil_pass<P, Q, P, false, BJ, oA, oA, +1, EO>(tBf, aJP, lane, E * T_JP);   // F2: along j at (i', nodal k)
+    CPS_PH(3);
     {  // F3: along k at (i', j'): U -> A in place and dU/dz -> BZ (grad1d on the nodal values), one
        // table at a time (both = 100 SGPRs = SGPR spills)
       double in[R_K][P];
@@ -478,18 +504,23 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       }
     }
     // ---- collocated gradient on the quadrature points -----------------------------------------------------
+    CPS_PH(4);
     pencil_pass<Q, Q, Q, false, BI, oA, oBX, -1, EO>(tDf, aIQ, lane, E * T_IQ);  // F4: d/dx: A -> BX
+    CPS_PH(5);
     pencil_pass<Q, Q, Q, false, BJ, oA, oA, -1, EO>(tDf, aJQ, lane, E * T_JQ);   // F5: d/dy: A -> A in place
+    CPS_PH(6);
 
+    set_prio<CPS_PRIO_PHYS>();
     if (geo) {
 #pragma unroll
       for (int i = 0; i < RG; i++)
         if (lane + 64 * i < E * NCO)
-          *(ldsp_t)((volatile __attribute__((address_space(3))) char *)lds0 + oGC + (lane + 64 * i) * 8) = gcoef[i];
+          *(ldsp_t)((ldsb_t)lds0 + oGC + (lane + 64 * i) * 8) = gcoef[i];
     }
     // ---- physics: point owners, one round at a time; ug[d*3+c] from (BX, A, BZ), dv back in place ----
 #pragma unroll
     for (int r = 0; r < RQ; r++) {
+      CPS_PH(7 + (r < 8 ? r : 8));
       const kargs_t ka = kargs_fresh<KA>();
       const bool okp = pencil_ok(lane, r, E * Q3);
       const int pel = el_of(lane + 64 * r, Q3), pq = lane + 64 * r - pel * Q3;
@@ -503,7 +534,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       double qdl[10];
       if constexpr (GEO == 2) {  // affine element: dXdx and det J are the element's, the weight the point's (common.h:47-101)
         const uint32_t pk = pqi[r];
-        const auto lb = (volatile __attribute__((address_space(3))) char *)lds0;
+        const auto lb = (ldsb_t)lds0;
         const ldsp_t ti = (ldsp_t)(lb + oGT + (pk & 0xFFu)), tj = (ldsp_t)(lb + oGT + ((pk >> 8) & 0xFFu)),
                      tk = (ldsp_t)(lb + oGT + ((pk >> 16) & 0xFFu)), cf = (ldsp_t)(lb + oGC + (pk >> 24) * (GEO_NAFF * 8));
         qdl[0] = ti[Q] * tj[Q] * tk[Q] * cf[0];
@@ -511,7 +542,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
         for (int c = 1; c < 10; c++) qdl[c] = cf[c];
       } else if (geo) {  // SetupGeo (common.h:47-101) recomputed at this point from the element's trilinear map
         const uint32_t pk = pqi[r];
-        const auto lb = (volatile __attribute__((address_space(3))) char *)lds0;
+        const auto lb = (ldsb_t)lds0;
         const ldsp_t ti = (ldsp_t)(lb + oGT + (pk & 0xFFu)), tj = (ldsp_t)(lb + oGT + ((pk >> 8) & 0xFFu)),
                      tk = (ldsp_t)(lb + oGT + ((pk >> 16) & 0xFFu)), cf = (ldsp_t)(lb + oGC + (pk >> 24) * (GEO_NCOEF * 8));
         const double xi = ti[0], eta = tj[0], zeta = tk[0], w = ti[Q] * tj[Q] * tk[Q];
@@ -565,7 +596,10 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     }
 
     // ---- gradient^T --------------------------------------------------------------------------------------
+    set_prio<CPS_PRIO_PASS>();
+    CPS_PH(16);
     pencil_pass<Q, Q, Q, true, BI, oBX, oBX, -1, EO>(tDt, aIQ, lane, E * T_IQ);  // B1: W1 = Dx^T g0, BX in place
+    CPS_PH(17);
     {  // B2: W2 = W1 + Dy^T g1, A in place.  Two inputs per task: software-pipelined over the rounds
        // (two rounds of inputs live instead of all)
       if constexpr (table_splits<Q, Q, EO>() == 1) {
@@ -597,6 +631,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
           if (pencil_ok(lane, r, E * T_JQ)) pencil_st<Q, BJ, oA>(aJQ[r], acc[r]);
       }
     }
+    CPS_PH(18);
     {  // B3: along k: A[k<P] = B^T W2 + G^T g2, in two sweeps so that one coefficient table is live at a time
       double out[R_K][P];
       if constexpr (table_splits<P, Q, EO>() > 1) {  // large tables: all rounds live, the tables in row blocks
@@ -644,13 +679,17 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       }
       }
     }
+    CPS_PH(19);
     load_x(off_nx, xin);  // next group's x (its offsets landed long ago): issued this late so its 6 RN registers
                           // are not live across the physics and the register-hungry passes; B4, B5, the
                           // final store and the next gather's address work hide most of its latency
     // ---- B^T: points -> nodes ---------------------------------------------------------------------------
     pencil_pass<Q, P, P, true, BJ, oA, oA, +1, EO>(tBt, aJP, lane, E * T_JP);    // B4: along j
+    CPS_PH(20);
     pencil_pass<Q, P, P, true, BI, oA, oA, +1, EO>(tBt, aIP, lane, E * T_IP);    // B5: along i
+    CPS_PH(21);
     // ---- final: node owners -> y (element-interior nodes) / shell E-vector (plain coalesced stores) ------------------
+    set_prio<CPS_PRIO_TOP>();
     {
       double v[RN][3];
 #pragma unroll
@@ -676,6 +715,10 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
         }
       }
     }
+    CPS_PH(22);
+#ifdef CPS_PHASE_TIMING
+    ph_iter++;
+#endif
     if (!more) break;
     grp = grp_nx;
 #pragma unroll
@@ -694,8 +737,18 @@ template <int P, int Q> constexpr int pencil_waves_per_cu() {
 // (rounded to whole XCD sets) -- workgroups beyond the resident set are dispatched as earlier ones retire, which balances
 // a launch of a few rounds and gives co-scheduled kernels (the halo exchange's) a slot at every retirement.
 template <int P, int Q, int QF>
-hipError_t launch_fused_pencil_t(const BasisTables &t, const FusedGradArgs &a, hipStream_t s) {
+hipError_t launch_fused_pencil_t(const BasisTables &t, const FusedGradArgs &a_in, hipStream_t s) {
   using G = PencilGeom<P, Q>;
+#ifdef CPS_PHASE_TIMING
+  FusedGradArgs a = a_in;
+  if (const char *e = a.query_waves ? nullptr : getenv("CEED_MI355X_PHASE_BUF")) {
+    a.query_waves = (int *)strtoull(e, nullptr, 0);
+    hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, 1>), dim3(min(device_cu_count() * pencil_waves_per_cu<P, Q>(), (a.nelem + G::E - 1) / G::E)), dim3(64), 0, s, t, a);
+    return hipGetLastError();
+  }
+#else
+  const FusedGradArgs &a = a_in;
+#endif
   if (a.nelem <= 0 && !a.query_waves) return hipSuccess;
   const int ngroups = (a.nelem + G::E - 1) / G::E;
   const int ncu = device_cu_count();
