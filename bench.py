@@ -381,6 +381,9 @@ def main():
                 prev = i
             d = tb[:, prev] - tb[:, 0]
             f.write("%-16s %8.0f %8.0f %8.0f\n" % ("whole group", d.mean(), np.median(d), np.percentile(d, 90)))
+            if (tb[:, 25] > tb[:, 24]).all():   # the same interval on the constant 100 MHz counter: the shader clock during it
+                f.write("shader clock     %8.3f GHz (cycles of the group / its time on the 100 MHz wall clock, mean over the waves)\n"
+                        % float((d / ((tb[:, 25] - tb[:, 24]) * 10.0)).mean()))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

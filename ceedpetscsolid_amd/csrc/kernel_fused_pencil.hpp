@@ -71,6 +71,9 @@ typedef volatile __attribute__((address_space(3))) char *ldsb_t;
 #ifndef CPS_PRIO_PASS
 #define CPS_PRIO_PASS 3    // the twelve pencil passes
 #endif
+#ifndef CPS_PRIO_PASS_B
+#define CPS_PRIO_PASS_B CPS_PRIO_PASS   // the transposed passes after the q-point rounds
+#endif
 #ifndef CPS_PRIO_PHYS
 #define CPS_PRIO_PHYS 0    // the q-point rounds
 #endif
@@ -424,6 +427,9 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
 #endif
   for (;;) {
     CPS_PH(0);
+#ifdef CPS_PHASE_TIMING
+    if (ph_iter == CPS_PHASE_TIMING && lane == 0 && ph_buf) ph_buf[(size_t)blockIdx.x * 32 + 24] = wall_clock64();   // 100 MHz
+#endif
     const int grp_nx = grp + wper;
     const bool more = grp_nx < gend;  // wave-uniform
     const int g_nx = more ? grp_nx : grp;
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     }
 
     // ---- gradient^T --------------------------------------------------------------------------------------
-    set_prio<CPS_PRIO_PASS>();
+    set_prio<CPS_PRIO_PASS_B>();
     CPS_PH(16);
     pencil_pass<Q, Q, Q, true, BI, oBX, oBX, -1, EO>(tDt, aIQ, lane, E * T_IQ);  // B1: W1 = Dx^T g0, BX in place
     CPS_PH(17);
@@ -717,6 +723,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     }
     CPS_PH(22);
 #ifdef CPS_PHASE_TIMING
+    if (ph_iter == CPS_PHASE_TIMING && lane == 0 && ph_buf) ph_buf[(size_t)blockIdx.x * 32 + 25] = wall_clock64();
     ph_iter++;
 #endif
     if (!more) break;

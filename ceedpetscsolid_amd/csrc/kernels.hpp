@@ -51,7 +51,10 @@ constexpr int OFF_FLAG_SHIFT = 29;
 constexpr bool pencil_even_odd(int Q) { return Q >= 4 && Q <= 7; }
 // The derived state of the finite-strain tangent (QF_HYPERFS_DF_DS) is used -- and written by the residual kernel -- from Q = 6 on:
 // measured -2.6 ... -3.1 % there, +-0 % at Q = 5 (profiles/r03_ab_experiments.txt item 3), for ten more doubles per point stored.
-constexpr bool pencil_derived_state(int Q) { return Q >= 6; }
+#ifndef CPS_DERIVED_MIN_Q
+#define CPS_DERIVED_MIN_Q 6   // (tuning hook; the whole library must be built with the same value)
+#endif
+constexpr bool pencil_derived_state(int Q) { return Q >= CPS_DERIVED_MIN_Q; }
 
 struct FusedGradArgs {
   const uint32_t *offsets;  // [nelem][P^3] (flagged)

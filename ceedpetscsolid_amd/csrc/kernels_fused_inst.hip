@@ -26,7 +26,7 @@ namespace cps {
   }
 // The derived-state tangent is instantiated where it measured a gain: Q >= 6 (one element per wave; -2.6 ... -3.1 % on config 5's
 // block, same box); at Q = 5 it removes 9 % of the VALU instructions and 0 % of the time (pencil_derived_state, kernels.hpp).
-#if CPS_Q >= 6
+#if CPS_Q >= CPS_DERIVED_MIN_Q
 #define CPS_DERIVED(Pv) CPS_CASE(Pv, QF_HYPERFS_DF_DS, "HyperFSdF+derived")
 #else
 #define CPS_DERIVED(Pv)

@@ -422,6 +422,9 @@ __global__ void k_rstr(const uint32_t *off, size_t total, int elemsize, int ncom
 __global__ void k_assemble(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off,
                            const unsigned char *flags, const double *evec, double *y, int nnodes, int add, int nb_rows,
                            const HaloUnpackArgs un, const HaloPackFold pk) {
+#ifdef CPS_ASM_PRIO   // (tuning hook) wave priority of the row sums beside a fused kernel
+  __builtin_amdgcn_s_setprio(CPS_ASM_PRIO);
+#endif
   if ((int)blockIdx.x >= nb_rows) {
     for (int u = ((int)blockIdx.x - nb_rows) * blockDim.x + threadIdx.x; u < un.n; u += ((int)gridDim.x - nb_rows) * blockDim.x) {
       double v = y[un.dst[u]];

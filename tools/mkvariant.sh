@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/mkvariant.sh <name> "<extra hipcc flags>" [Q ...]   (CPU; default Q list: 5)
+# usage: tools/mkvariant.sh <name> "<extra hipcc flags>" [Q ... | all]   (CPU; default Q list: 5; all: every object, host side included)
 # Builds a variant of the product library out of tree (tools/variants/<name>/*.so, git-ignored): the in-tree objects are
 # reused, only the fused kernels of the listed quadrature sizes are recompiled with the extra flags (-D tuning hooks of
 # kernel_fused_pencil.hpp, -mllvm options).  tools/r3_variants.sh runs variants against the default on one box.
@@ -7,6 +7,8 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd); name=$1; flags=$2; shift 2; qs=${@:-5}
 T=/tmp/variants/$name; W=$T/pkg/csrc; rm -rf $T; mkdir -p $W $T/include; cp -r $R/ceedpetscsolid_amd/csrc/. $W/; cp $R/include/*.h $T/include/
 cd $W; touch build/*.o build/isa_summary.txt
+if [ "$qs" = all ]; then rm -f build/*.o; qs="2 3 4 5 6 7 8"; fi
+if [ "$qs" = misc ]; then rm -f build/misc.o; qs=""; fi
 for q in $qs; do rm -f build/fused_q$q.o; done
 make -s -j8 EXTRA_HIPFLAGS="$flags" libceed_mi355x.so libsolid_harness_mi355x.so
 mkdir -p $R/tools/variants/$name; cp $W/*.so $R/tools/variants/$name/
