@@ -50,6 +50,9 @@ CASES = [  # (mesh factory, degree, problem, bc)
     ("ragged p1", lambda: distorted_box(3, 1, 1), 1, "hyperFS", dict(bc_sides=[6])),   # Q=2: eight elements per wave, 3 elements
     ("single element", lambda: distorted_box(1, 1, 1), 3, "hyperFS", dict()),
     ("uniform ladder", lambda: distorted_box(2, 2, 2), 4, "linElas", dict(bc_sides=[1], multigrid="uniform")),  # P = 2,3,4,5 at Q = 5
+    ("p5 ladder", lambda: distorted_box(2, 2, 1), 5, "hyperFS", dict(bc_sides=[1])),             # degrees 1,2,4,5: P = 2,3,5,6 at Q = 6
+    ("p7 ladder", lambda: distorted_box(1, 2, 1), 7, "hyperSS", dict(bc_sides=[1])),             # degrees 1,2,4,7: P = 2,3,5,8 at Q = 8
+    ("p5 uniform", lambda: distorted_box(2, 1, 1), 5, "linElas", dict(bc_sides=[1], multigrid="uniform")),  # P = 2..6 at Q = 6
 ]
 
 
