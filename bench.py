@@ -202,6 +202,11 @@ def main():
     ap.add_argument("--of", type=int, default=8, metavar="N")
     ap.add_argument("--cold-idle-s", type=float, default=1.0,
                     help="idle time before the COLD timing of --steps applies (reported as ms_per_step_cold; 0: skipped)")
+    ap.add_argument("--per-apply-events", action="store_true",
+                    help="kernel_avg_us from a pair of hipEvents around EVERY apply (round 1-3's form) instead of one pair around the timed steps")
+    ap.add_argument("--graph", action="store_true",
+                    help="record one step (apply + exchange) into a hipGraph after the first applies and time its replays "
+                         "(CeedXGraph*; the exchange is recorded in its in-order form)")
     ap.add_argument("--phase-timing", default=None, metavar="FILE",
                     help="diagnostic, needs a library built with -DCPS_PHASE_TIMING=<k> (tools/mkvariant.sh): after the timed loop one more "
                          "apply with the waves' phase time stamps collected; mean shader cycles per phase of the fused kernel -> FILE")
@@ -337,6 +342,10 @@ def main():
         for _ in range(3):
             lib.chk(lib.lib.CeedXVectorAXPBY(va.h, C.c_double(0.5), vb.h, C.c_double(0.25)))
         torch.cuda.synchronize()
+    if args.graph:   # one step recorded; every later step() is a replay
+        step(); torch.cuda.synchronize()
+        recorded = ceed.capture(step)
+        step = recorded.launch
     # pre-warm (untimed, reported): back-to-back applies until the clock / power state has settled
     prewarm_steps = 0
     if args.prewarm_ms > 0:
@@ -349,19 +358,30 @@ def main():
             prewarm_steps += 10
     for _ in range(args.warmup):
         step()
-    op.set_timing(True)
+    # Device time of the timed region: ONE pair of hipEvents on the operator's stream (= torch's current stream, ceed.set_stream
+    # above; the side stream of a pipelined apply forks from it and joins it) around the K steps.  --per-apply-events brackets
+    # every apply instead (CeedXOperatorSetTiming: two event records per apply, which cost the small launches of the N-GPU
+    # regime ~10 % -- profiles/r03_ab_experiments.txt item 16).
+    if args.per_apply_events:
+        op.set_timing(True)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         step()
+    ev1.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = op.get_timing()
-    op.set_timing(False)
+    if args.per_apply_events:
+        kernel_ms, launches = op.get_timing()
+        op.set_timing(False)
+    else:
+        kernel_ms, launches = ev0.elapsed_time(ev1), args.steps
     if args.phase_timing:
         pbuf = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
         os.environ["CEED_MI355X_PHASE_BUF"] = hex(pbuf.data_ptr())
@@ -410,6 +430,8 @@ def main():
         P, Q = args.degree + 1, args.degree + 1
         abytes = algorithmic_bytes(mesh.nelem, P, Q, n, args.problem != "linElas")
         avg_s = kernel_ms * 1e-3 / max(args.steps, 1)   # per APPLY (a split-phase apply is two timed launch pairs)
+        if avg_s <= 0.0:   # --graph with --per-apply-events: the replays carry no hipEvents; the step time stands in
+            avg_s = elapsed / args.steps
         li = op.launch_info()
         assembly_form = ("pipelined: %d segments on %d streams, last segment %d elements" % (li["segments"], li["streams"], li["last_segment_elements"])
                          if li["segments"] > 1 else os.environ.get("CEED_MI355X_ASSEMBLE", "serial (launch too small to pipeline, split-phase apply, or switched off)"))
@@ -422,6 +444,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "halo_path": halo_path,   # N > 1: "rccl" = the library's CeedXHalo* (pack kernel, RCCL group, unpack-add); "torch" on request / on gloo; "torch-fallback" only with --no-strict-halo
             "prewarm_ms": args.prewarm_ms, "prewarm_steps": prewarm_steps,
+            "launch": "hipGraph replay of one recorded step" if args.graph else "direct",
             "ms_per_step": 1e3 * elapsed / args.steps,
             "ms_per_step_cold": ms_cold,   # the same loop right after a 1 s idle, before the pre-warm (rank 0's clock; not max-reduced)
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
@@ -450,6 +473,8 @@ def main():
                          "measured_traffic_GBs": (traffic / avg_s / 1e9) if traffic else None,
                          "algorithmic_bytes_per_launch": abytes, "kernel_avg_us": avg_s * 1e6,
                          "kernel_launches_timed": launches,
+                         "kernel_avg_us_from": "a pair of hipEvents around every apply" if args.per_apply_events else "one pair of hipEvents on the operator's stream around the timed steps / steps",
+
                          "launches_per_apply": li["segments"] + li["assemble_launches"],
                          "kernels": ("k_fused_pencil (gather..physics..shell E-vector, interior nodes straight to y) + k_assemble (deterministic per-node sum of the shared nodes): "
                                      + ("the two launches of one CeedOperatorApply, timed together with hipEvents on their stream" if li["segments"] <= 1 else
