@@ -6,12 +6,36 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstring>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 __global__ void k(long long *stamp, int idx, int spin) {
   if (threadIdx.x == 0 && blockIdx.x == 0) stamp[2 * idx] = wall_clock64();
   for (int i = 0; i < spin; i++) __builtin_amdgcn_s_sleep(64);
   __syncthreads();
   if (threadIdx.x == 0 && blockIdx.x == 0) stamp[2 * idx + 1] = wall_clock64();
+}
+// the same chain on ONE stream with a kernel whose argument block is NB bytes (the fused kernel's is ~5 KB)
+template <int NB> struct Blob { char b[NB]; };
+template <int NB> __global__ void kbig(long long *stamp, int idx, int spin, Blob<NB> blob) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) stamp[2 * idx] = wall_clock64() + (blob.b[idx % NB] & 0);
+  for (int i = 0; i < spin; i++) __builtin_amdgcn_s_sleep(64);
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x == 0) stamp[2 * idx + 1] = wall_clock64();
+}
+template <int NB> int run_big(int grid, int lds) {
+  const int N = 200, spin = 100;
+  hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  long long *stamp; CK(hipMalloc(&stamp, sizeof(long long) * 4 * N)); CK(hipMemset(stamp, 0, sizeof(long long) * 4 * N));
+  Blob<NB> blob; memset(&blob, 0, sizeof blob);
+  CK(hipDeviceSynchronize());
+  for (int i = 0; i < 2 * N; i++) hipLaunchKernelGGL(kbig<NB>, dim3(grid), dim3(64), lds, s, stamp, i, spin, blob);
+  CK(hipDeviceSynchronize());
+  std::vector<long long> h(4 * N);
+  CK(hipMemcpy(h.data(), stamp, sizeof(long long) * 4 * N, hipMemcpyDeviceToHost));
+  double gap = 0; int n = 0;
+  for (int i = 2 * N / 4; i < 2 * N - 1; i++) { gap += (h[2 * (i + 1)] - h[2 * i + 1]) * 0.01; n++; }
+  printf("grid %5d  one stream, %4d-byte argument block, %5d B of LDS per workgroup: gap to the next kernel %.2f us\n", grid, NB, lds, gap / n);
+  return 0;
 }
 int run(int mode, int grid) {
   const int N = 200, spin = 100;
@@ -69,6 +93,7 @@ int main() {
   if (visibility()) printf("visibility test failed to run\n");
   int can = 0; (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0);
   printf("hipDeviceAttributeCanUseStreamWaitValue = %d\n", can);
+  for (int grid : {1, 2048}) { run_big<64>(grid, 0); run_big<2048>(grid, 0); run_big<3900>(grid, 0); run_big<64>(grid, 18496); run_big<3900>(grid, 18496); }
   for (int grid : {1, 2048}) for (int m = 0; m < 4; m++) if (run(m, grid)) printf("mode %d failed\n", m);
   return 0;
 }
