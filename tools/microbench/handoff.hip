@@ -4,6 +4,7 @@
 // Hand-over: (0) none: one stream (baseline); (1) hipEventRecord + hipStreamWaitEvent (events without timing);
 // (2) hipStreamWriteValue64 + hipStreamWaitValue64 on device memory; (3) the same on hipMallocSignalMemory.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <vector>
 #include <cstring>
@@ -89,7 +90,24 @@ int visibility() {
   printf("visibility across a write/wait-value hand-over: %llu mismatches in %d x %zu checked entries\n", h, N, n);
   return 0;
 }
+// does hipExtAnyOrderLaunch let a kernel start beside its predecessor in the SAME stream?  (hip_ext.h: "not supported on AMD GFX9xx boards")
+int any_order() {
+  const int N = 50, spin = 100;
+  hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  long long *stamp; CK(hipMalloc(&stamp, sizeof(long long) * 4 * N)); CK(hipMemset(stamp, 0, sizeof(long long) * 4 * N));
+  CK(hipDeviceSynchronize());
+  for (int i = 0; i < 2 * N; i++)
+    hipExtLaunchKernelGGL(k, dim3(64), dim3(64), 0, s, nullptr, nullptr, (i & 1) ? hipExtAnyOrderLaunch : 0, stamp, i, spin);
+  CK(hipDeviceSynchronize());
+  std::vector<long long> h(4 * N);
+  CK(hipMemcpy(h.data(), stamp, sizeof(long long) * 4 * N, hipMemcpyDeviceToHost));
+  double ov = 0; int n = 0;
+  for (int i = 10; i < 2 * N - 1; i += 2) { ov += (h[2 * (i + 1)] - h[2 * i + 1]) * 0.01; n++; }   // start of the any-order kernel minus end of its predecessor
+  printf("any-order launch on one stream: the second kernel starts %.2f us after the first one ENDS (negative = beside it)\n", ov / n);
+  return 0;
+}
 int main() {
+  if (any_order()) printf("any-order test failed to run\n");
   if (visibility()) printf("visibility test failed to run\n");
   int can = 0; (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0);
   printf("hipDeviceAttributeCanUseStreamWaitValue = %d\n", can);
