@@ -4,7 +4,7 @@
 //
 // Node counts P per Q follow the level-degree rules of the reference
 // (cloptions.c:195-225): the fine level has P = Q (qextra = 0), coarse levels
-// use degrees 1, 2, 4 (logarithmic) with the FINE quadrature (setuplibceed.c:757).
+// use degrees 1, 2, 4 (logarithmic) or every degree below the fine one (uniform) with the FINE quadrature (setuplibceed.c:757).
 // Residual kernels (which write the stored state) only exist on the fine level.
 #include "kernel_fused_pencil.hpp"
 
@@ -54,6 +54,12 @@ hipError_t CPS_CAT(launch_fused_grad_q, CPS_Q)(int P, int qf, const BasisTables 
 #endif
 #if CPS_Q > 5
   CPS_JACOBIANS(5)
+#endif
+#if CPS_Q > 6      // (uniform ladders of degrees 6 and 7, cloptions.c:195-225: every degree below the fine one is a level)
+  CPS_JACOBIANS(6)
+#endif
+#if CPS_Q > 7
+  CPS_JACOBIANS(7)
 #endif
   return hipErrorInvalidValue;
 }

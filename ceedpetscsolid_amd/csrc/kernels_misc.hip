@@ -333,7 +333,7 @@ hipError_t launch_diag(int P, int Q, int qf, const BasisTables &t, const DiagArg
   CPS_DG3(2, 5) CPS_DG3(3, 5) CPS_DG3(4, 5) CPS_DG3(5, 5) CPS_DG3(2, 7) CPS_DG3(3, 7) CPS_DG3(5, 7) CPS_DG3(7, 7)
   // degrees 5 and 7 (logarithmic ladders 1, 2, 4, p) and the uniform ladders of degrees 5 and 6
   CPS_DG3(2, 6) CPS_DG3(3, 6) CPS_DG3(4, 6) CPS_DG3(5, 6) CPS_DG3(6, 6) CPS_DG3(4, 7) CPS_DG3(6, 7)
-  CPS_DG3(2, 8) CPS_DG3(3, 8) CPS_DG3(5, 8) CPS_DG3(8, 8)
+  CPS_DG3(2, 8) CPS_DG3(3, 8) CPS_DG3(4, 8) CPS_DG3(5, 8) CPS_DG3(6, 8) CPS_DG3(7, 8) CPS_DG3(8, 8)
   return hipErrorInvalidValue;
 }
 

@@ -53,6 +53,8 @@ CASES = [  # (mesh factory, degree, problem, bc)
     ("p5 ladder", lambda: distorted_box(2, 2, 1), 5, "hyperFS", dict(bc_sides=[1])),             # degrees 1,2,4,5: P = 2,3,5,6 at Q = 6
     ("p7 ladder", lambda: distorted_box(1, 2, 1), 7, "hyperSS", dict(bc_sides=[1])),             # degrees 1,2,4,7: P = 2,3,5,8 at Q = 8
     ("p5 uniform", lambda: distorted_box(2, 1, 1), 5, "linElas", dict(bc_sides=[1], multigrid="uniform")),  # P = 2..6 at Q = 6
+    ("p6 uniform", lambda: distorted_box(1, 1, 2), 6, "hyperFS", dict(bc_sides=[1], multigrid="uniform")),  # P = 2..7 at Q = 7
+    ("p7 uniform", lambda: distorted_box(1, 1, 1), 7, "hyperSS", dict(bc_sides=[1], multigrid="uniform")),  # P = 2..8 at Q = 8
 ]
 
 
