@@ -389,6 +389,9 @@ def main():
         del os.environ["CEED_MI355X_PHASE_BUF"]
         tb = pbuf.cpu().numpy().reshape(-1, 32)
         tb = tb[tb[:, 0] > 0]
+        if len(tb) == 0:
+            sys.exit("--phase-timing: no time stamps came back -- the library in ceedpetscsolid_amd/csrc was not built with -DCPS_PHASE_TIMING=<k> "
+                     "(tools/mkvariant.sh ph1 \"-DCPS_PHASE_TIMING=1\", then copy tools/variants/ph1/*.so over it as tools/r3_phase_timing.sh does)")
         names = ["requests+gather", "F1", "F2", "F3", "F4", "F5", "geo->LDS"] + [f"physics {r}" for r in range(9)] + ["B1", "B2", "B3", "x+B4", "B5", "final"]
         with open(args.phase_timing, "w") as f:
             f.write(f"# {len(tb)} waves, shader-clock cycles per phase of one group (mean, median, p90)\n")
