@@ -70,6 +70,7 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   o.recompute_geo = !env_is("CEED_MI355X_GEO", "0");
   o.direct_interior = !env_is("CEED_MI355X_DIRECT", "0");
   o.affine_geo = !env_is("CEED_MI355X_AFFINE", "0");
+  o.swept_geo = !env_is("CEED_MI355X_SWEPT", "0");
   o.derived_state = !env_is("CEED_MI355X_DERIVED", "0");
   if (env_is("CEED_MI355X_ASSEMBLE", "serial")) o.pipe_segments = 0;
   else { const int ps = env_int("CEED_MI355X_PIPE_SEGMENTS", 0); o.pipe_segments = ps >= 2 ? std::min(ps, 16) : -1; }
@@ -192,7 +193,8 @@ void vec_drop_geo(CeedVector v) {
   v->derived_valid = false;
   if (v->geo) (void)hipFree(v->geo);
   if (v->geo_aff) (void)hipFree(v->geo_aff);
-  v->geo = v->geo_aff = nullptr; v->geo_nelem = v->geo_Q = 0;
+  if (v->geo_swept) (void)hipFree(v->geo_swept);
+  v->geo = v->geo_aff = v->geo_swept = nullptr; v->geo_nelem = v->geo_Q = 0;
 }
 
 int ceed_need_evec(Ceed c, size_t len) {

@@ -34,6 +34,7 @@ struct CeedOptions {
   bool direct_interior = true;   // CEED_MI355X_DIRECT=0: element-interior nodes go through the E-vector like the shared ones
   bool derived_state = true;     // CEED_MI355X_DERIVED=0: HyperFSdF forms F^-1 and ln J from the stored grad u at every point
   bool affine_geo = true;        // CEED_MI355X_AFFINE=0: all-affine meshes take the general per-point recompute too
+  bool swept_geo = true;         // CEED_MI355X_SWEPT=0: meshes of swept (extruded) elements take the general per-point recompute too
   // restriction transpose of large whole applies: pipelined in segments over two streams
   int pipe_segments = -1;        // 0: never (CEED_MI355X_ASSEMBLE=serial); -1: chosen per launch; >= 2: CEED_MI355X_PIPE_SEGMENTS
   int pipe_blocks = 0;           // CEED_MI355X_PIPE_BLOCKS: cap on the workgroups of a k_assemble that runs beside a fused kernel
@@ -105,6 +106,8 @@ struct CeedVector_private {
   // reading them (FusedGradArgs::geo).  Dropped by any other write to the vector.
   double *geo = nullptr;
   double *geo_aff = nullptr;   // set when EVERY element is affine: [nelem][GEO_NAFF] constant factors (FusedGradArgs::geo_aff)
+  double *geo_swept = nullptr; // set when every element is swept along the reference direction geo_axis (FusedGradArgs::geo_swept)
+  int geo_axis = 0;
   int geo_nelem = 0, geo_Q = 0;
   double geo_qref[cps::MAXN1D] = {0}, geo_qwt[cps::MAXN1D] = {0};
   // provenance of a stored-state vector (grad u): written by this backend's HyperFSF kernel, which left the DERIVED state of

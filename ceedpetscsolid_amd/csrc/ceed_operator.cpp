@@ -441,6 +441,7 @@ static int fused_prepare(CeedOperator op, CeedVector in, CeedVector out, bool ad
     if (same_rule && c->opt.recompute_geo) {
       a.geo = qv->geo;
       a.geo_aff = qv->geo_aff;
+      a.geo_swept = qv->geo_swept; a.geo_axis = qv->geo_axis;
       for (int i = 0; i < ai.basis->Q1d; i++) { a.qref[i] = qv->geo_qref[i]; a.qwt[i] = qv->geo_qwt[i]; }
     }
   }
@@ -483,7 +484,7 @@ static int fused_launch(CeedOperator op, const FusedApply &F, int e0, int ne, in
   if (e == hipErrorInvalidValue && !**kname)
     return ceed_error("no fused kernel instantiated for P=%d Q=%d QFunction %s", F.b->P1d, F.b->Q1d, op->qf->name.c_str());
   HIPCHK(e);
-  op->geo_mode = F.a.geo_aff && F.a.geo ? 2 : (F.a.geo ? 1 : 0);
+  op->geo_mode = F.a.geo_aff && F.a.geo ? 2 : (F.a.geo_swept && F.a.geo ? 3 : (F.a.geo ? 1 : 0));
   return 0;
 }
 static int assemble_rows(const FusedApply &F, int row0, int nrows, hipStream_t s, int max_blocks = 0, const HaloUnpackArgs *un = nullptr,
@@ -731,6 +732,20 @@ static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool 
         (void)hipFree(d_cnt);
         if (cnt != 0) { (void)hipFree(out->geo_aff); out->geo_aff = nullptr; }   // a mixed mesh takes the general recompute everywhere
       }
+      if (!out->geo_aff && op->ceed->opt.swept_geo) {   // every element swept along ONE reference direction (extruded meshes)?
+        int *d_cnt = nullptr, cnt[4] = {0, 0, 0, 1};
+        HIPCHK(hipMalloc((void **)&out->geo_swept, sizeof(double) * GEO_NSWEPT * (size_t)a.nelem));
+        HIPCHK(hipMalloc((void **)&d_cnt, 4 * sizeof(int)));
+        HIPCHK(hipMemsetAsync(d_cnt, 0, 4 * sizeof(int), s));
+        HIPCHK(launch_geo_swept(out->geo, out->geo_swept, a.nelem, d_cnt, s));
+        HIPCHK(hipMemcpyAsync(cnt, d_cnt, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));      // set-up time only
+        (void)hipFree(d_cnt);
+        int axis = -1;
+        for (int d = 0; d < 3; d++) if (cnt[d] == a.nelem) axis = d;
+        if (axis < 0) { (void)hipFree(out->geo_swept); out->geo_swept = nullptr; }   // mixed directions or general hexes: the general recompute
+        else out->geo_axis = axis;
+      }
       for (int i = 0; i < x.basis->Q1d && i < MAXN1D; i++) { out->geo_qref[i] = x.basis->qref1d[i]; out->geo_qwt[i] = x.basis->qweight1d[i]; }
     }
     break;
@@ -876,7 +891,7 @@ extern "C" int CeedOperatorLinearAssembleDiagonal(CeedOperator op, CeedVector as
 // the instantiation of the last apply; for the fused operators also how the geometric factors were obtained
 extern "C" int CeedXOperatorGetKernelName(CeedOperator op, const char **name) {
   if (op->plan == PLAN_FUSED_GRAD && !op->kernel_name.empty() && op->kernel_name.find(" [") == std::string::npos)
-    op->kernel_name += op->geo_mode == 2 ? " [affine elements: dXdx per element]" : (op->geo_mode == 1 ? " [dXdx recomputed per point]" : " [qdata read]");
+    op->kernel_name += op->geo_mode == 2 ? " [affine elements: dXdx per element]" : (op->geo_mode == 3 ? " [swept elements: 2 x 2 dXdx recomputed per point]" : (op->geo_mode == 1 ? " [dXdx recomputed per point]" : " [qdata read]"));
   *name = op->kernel_name.c_str();
   return 0;
 }

@@ -261,6 +261,12 @@ constexpr int pencil_minw(int Q) { return Q == 5 ? CPS_PENCIL_MINW5 : CPS_PENCIL
 // GEO = 1: the geometric factors are recomputed per point from the element's trilinear map (FusedGradArgs::geo) instead of
 // read; GEO = 2: every element of the mesh is AFFINE (a parallelepiped: the box meshes of configs 1, 2 and 5), dXdx and
 // det J are constants of the element (FusedGradArgs::geo_aff, ten doubles) and only the weight varies from point to point;
+// GEO = 3: every element is SWEPT along the same reference direction (FusedGradArgs::geo_swept, geo_axis): x and y bilinear in the other two
+// directions, z linear in that one -- the prisms of an extruded mesh, which the reference's cylinders are.  J is a 2 x 2 block and a
+// constant: four FMAs, a 2 x 2 determinant and one reciprocal per point instead of 27 FMAs, an adjugate and a 3 x 3 determinant, and the
+// physics multiplies with the five entries of dXdx that are left (qf_point<QF, true>): 15 multiply-adds for each of its two products
+// instead of 27.  The q-point round hands the reference directions to the physics in the order (in-plane, in-plane, sweep) by choosing
+// which of the three arrays it reads first -- a relabelling of a sum's terms, no arithmetic;
 // GEO = 0: qdata is read.  The 1-D tables are applied in even-odd form wherever that form exists (pencil_even_odd(Q)).
 template <int P, int Q, int QF, int GEO>
 __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const BasisTables tab_, const FusedGradArgs a) {
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
   __shared__ __attribute__((aligned(16))) double slab[E * SE + G::GEO];
   const ldsp_t lds0 = (lds_double *)slab;
   constexpr bool geo = GEO != 0;   // the geometric factors are not read from qdata
-  constexpr int NCO = GEO == 2 ? GEO_NAFF : GEO_NCOEF;   // doubles per element kept in LDS for them
+  constexpr int NCO = GEO == 2 ? GEO_NAFF : (GEO == 3 ? GEO_NSWEPT : GEO_NCOEF);   // doubles per element kept in LDS for them
   const int lane = threadIdx.x & 63;
   // ---- work list of this wave -----------------------------------------------------------------------
   // The groups are cut into 8 contiguous chunks, one per XCD (neighbouring elements share their nodes through one L2):
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     if (geo) {
       const kargs_t ka = kargs_fresh<KA>();
       const int nlive = nlive_of(ka->nelem, grp);
-      const double *gb = (GEO == 2 ? ka->geo_aff : ka->geo) + (size_t)(ka->elem_begin + grp * E) * NCO;
+      const double *gb = (GEO == 2 ? ka->geo_aff : (GEO == 3 ? ka->geo_swept : ka->geo)) + (size_t)(ka->elem_begin + grp * E) * NCO;
 #pragma unroll
       for (int i = 0; i < RG; i++) {
         const int t = min(lane + 64 * i, E * NCO - 1), el = min(t / NCO, nlive - 1);
@@ -532,10 +538,25 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       const int pel = el_of(lane + 64 * r, Q3), pq = lane + 64 * r - pel * Q3;
       const bool live = okp && (grp * E + pel < ka->nelem);
       double ug[9], dv[9], sto[9];
+      // swept elements: the arrays of the two in-plane reference directions first, the sweep direction's last (wave-uniform byte offsets)
+      ldsp_t pd0 = aPt[r], pd1 = aPt[r], pd2 = aPt[r];
+      int sw_a = 0, sw_b = 1;
+      if constexpr (GEO == 3) {
+        const int ax = ka->geo_axis;
+        sw_a = ax == 0 ? 1 : 0; sw_b = ax == 2 ? 1 : 2;
+        auto arr = [](int d) { return d == 0 ? oBX : (d == 1 ? oA : oBZ); };
+        pd0 = (ldsp_t)((ldsb_t)aPt[r] + arr(sw_a)); pd1 = (ldsp_t)((ldsb_t)aPt[r] + arr(sw_b)); pd2 = (ldsp_t)((ldsb_t)aPt[r] + arr(ax));
+      }
       if (okp) {
-        ug[0] = lds_rd<oBX + 0 * BC>(aPt[r]); ug[1] = lds_rd<oBX + 1 * BC>(aPt[r]); ug[2] = lds_rd<oBX + 2 * BC>(aPt[r]);
-        ug[3] = lds_rd<oA + 0 * BC>(aPt[r]);  ug[4] = lds_rd<oA + 1 * BC>(aPt[r]);  ug[5] = lds_rd<oA + 2 * BC>(aPt[r]);
-        ug[6] = lds_rd<oBZ + 0 * BC>(aPt[r]); ug[7] = lds_rd<oBZ + 1 * BC>(aPt[r]); ug[8] = lds_rd<oBZ + 2 * BC>(aPt[r]);
+        if constexpr (GEO == 3) {
+          ug[0] = lds_rd<0 * BC>(pd0); ug[1] = lds_rd<1 * BC>(pd0); ug[2] = lds_rd<2 * BC>(pd0);
+          ug[3] = lds_rd<0 * BC>(pd1); ug[4] = lds_rd<1 * BC>(pd1); ug[5] = lds_rd<2 * BC>(pd1);
+          ug[6] = lds_rd<0 * BC>(pd2); ug[7] = lds_rd<1 * BC>(pd2); ug[8] = lds_rd<2 * BC>(pd2);
+        } else {
+          ug[0] = lds_rd<oBX + 0 * BC>(aPt[r]); ug[1] = lds_rd<oBX + 1 * BC>(aPt[r]); ug[2] = lds_rd<oBX + 2 * BC>(aPt[r]);
+          ug[3] = lds_rd<oA + 0 * BC>(aPt[r]);  ug[4] = lds_rd<oA + 1 * BC>(aPt[r]);  ug[5] = lds_rd<oA + 2 * BC>(aPt[r]);
+          ug[6] = lds_rd<oBZ + 0 * BC>(aPt[r]); ug[7] = lds_rd<oBZ + 1 * BC>(aPt[r]); ug[8] = lds_rd<oBZ + 2 * BC>(aPt[r]);
+        }
       }
       double qdl[10];
       if constexpr (GEO == 2) {  // affine element: dXdx and det J are the element's, the weight the point's (common.h:47-101)
@@ -546,6 +567,22 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
         qdl[0] = ti[Q] * tj[Q] * tk[Q] * cf[0];
 #pragma unroll
         for (int c = 1; c < 10; c++) qdl[c] = cf[c];
+      } else if constexpr (GEO == 3) {  // swept element: J = {2 x 2 block in the plane, zs along the sweep} (common.h:47-101 on that J)
+        const uint32_t pk = pqi[r];
+        const auto lb = (ldsb_t)lds0;
+        const ldsp_t ti = (ldsp_t)(lb + oGT + (pk & 0xFFu)), tj = (ldsp_t)(lb + oGT + ((pk >> 8) & 0xFFu)),
+                     tk = (ldsp_t)(lb + oGT + ((pk >> 16) & 0xFFu)), cf = (ldsp_t)(lb + oGC + (pk >> 24) * (GEO_NSWEPT * 8));
+        const ldsp_t ta = (ldsp_t)(lb + oGT + ((pk >> (8 * sw_a)) & 0xFFu)), tb = (ldsp_t)(lb + oGT + ((pk >> (8 * sw_b)) & 0xFFu));
+        const double xa = ta[0], xb = tb[0], w = ti[Q] * tj[Q] * tk[Q];
+        const double xab = cf[2], yab = cf[5];
+        const double J00 = __builtin_fma(xab, xb, cf[0]), J10 = __builtin_fma(xab, xa, cf[1]);   // d x / d xi_a, d x / d xi_b
+        const double J01 = __builtin_fma(yab, xb, cf[3]), J11 = __builtin_fma(yab, xa, cf[4]);   // d y / d xi_a, d y / d xi_b
+        const double d2 = __builtin_fma(J00, J11, -(J01 * J10));
+        const double r2 = rcp_nr(d2), nr2 = -r2;
+        qdl[0] = w * cf[6] * d2;                       // w det J (cf[6] = sgn zs: the sign of the permutation (a, b, sweep))
+        qdl[1] = J11 * r2; qdl[2] = J10 * nr2; qdl[3] = 0.;
+        qdl[4] = J01 * nr2; qdl[5] = J00 * r2; qdl[6] = 0.;
+        qdl[7] = 0.; qdl[8] = 0.; qdl[9] = cf[7];      // 1 / zs
       } else if (geo) {  // SetupGeo (common.h:47-101) recomputed at this point from the element's trilinear map
         const uint32_t pk = pqi[r];
         const auto lb = (ldsb_t)lds0;
@@ -571,7 +608,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
         if constexpr (QF == QF_HYPERFS_F) {
           double dso[10];
           double *db = ka->state_out2;      // wave-uniform: also write the derived state of the tangent?
-          qf_point<QF>(Phys{ka->nu, ka->E, ka->lambda, ka->TwoMu}, ug, qdl, st[r % NSET], dv, sto, db ? dso : nullptr);
+          qf_point<QF, GEO == 3>(Phys{ka->nu, ka->E, ka->lambda, ka->TwoMu}, ug, qdl, st[r % NSET], dv, sto, db ? dso : nullptr);
           if (db) {
             db += (size_t)(ka->elem_begin + grp * E) * (10 * QS);
             const uint32_t vd = (uint32_t)(pel * (10 * QS) + pq);
@@ -579,7 +616,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
             for (int c = 0; c < 10; c++) (db + c * QS)[vd] = dso[c];
           }
         } else {
-          qf_point<QF>(Phys{ka->nu, ka->E, ka->lambda, ka->TwoMu}, ug, qdl, st[r % NSET], dv, sto);
+          qf_point<QF, GEO == 3>(Phys{ka->nu, ka->E, ka->lambda, ka->TwoMu}, ug, qdl, st[r % NSET], dv, sto);
         }
         if constexpr (ST_OUT) {
           double *sb = ka->state_out + (size_t)(ka->elem_begin + grp * E) * (9 * QS);
@@ -595,9 +632,15 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       if (r + NSET < RQ) load_point(qd[r % NSET], st[r % NSET], grp, r + NSET);
       else load_point(qd[r % NSET], st[r % NSET], g_nx, r + NSET - RQ);
       if (okp) {
-        lds_wr<oBX + 0 * BC>(aPt[r], dv[0]); lds_wr<oBX + 1 * BC>(aPt[r], dv[1]); lds_wr<oBX + 2 * BC>(aPt[r], dv[2]);
-        lds_wr<oA + 0 * BC>(aPt[r], dv[3]);  lds_wr<oA + 1 * BC>(aPt[r], dv[4]);  lds_wr<oA + 2 * BC>(aPt[r], dv[5]);
-        lds_wr<oBZ + 0 * BC>(aPt[r], dv[6]); lds_wr<oBZ + 1 * BC>(aPt[r], dv[7]); lds_wr<oBZ + 2 * BC>(aPt[r], dv[8]);
+        if constexpr (GEO == 3) {
+          lds_wr<0 * BC>(pd0, dv[0]); lds_wr<1 * BC>(pd0, dv[1]); lds_wr<2 * BC>(pd0, dv[2]);
+          lds_wr<0 * BC>(pd1, dv[3]); lds_wr<1 * BC>(pd1, dv[4]); lds_wr<2 * BC>(pd1, dv[5]);
+          lds_wr<0 * BC>(pd2, dv[6]); lds_wr<1 * BC>(pd2, dv[7]); lds_wr<2 * BC>(pd2, dv[8]);
+        } else {
+          lds_wr<oBX + 0 * BC>(aPt[r], dv[0]); lds_wr<oBX + 1 * BC>(aPt[r], dv[1]); lds_wr<oBX + 2 * BC>(aPt[r], dv[2]);
+          lds_wr<oA + 0 * BC>(aPt[r], dv[3]);  lds_wr<oA + 1 * BC>(aPt[r], dv[4]);  lds_wr<oA + 2 * BC>(aPt[r], dv[5]);
+          lds_wr<oBZ + 0 * BC>(aPt[r], dv[6]); lds_wr<oBZ + 1 * BC>(aPt[r], dv[7]); lds_wr<oBZ + 2 * BC>(aPt[r], dv[8]);
+        }
       }
     }
 
@@ -769,6 +812,7 @@ hipError_t launch_fused_pencil_t(const BasisTables &t, const FusedGradArgs &a_in
   // even finish: profiles/r03_ab_experiments.txt item 11.)
   if (grid > ngroups) grid = ngroups;
   if (a.geo && a.geo_aff) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, 2>), dim3(grid), dim3(64), 0, s, t, a);
+  else if (a.geo && a.geo_swept) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, 3>), dim3(grid), dim3(64), 0, s, t, a);
   else if (a.geo) hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, 1>), dim3(grid), dim3(64), 0, s, t, a);
   else hipLaunchKernelGGL((k_fused_pencil<P, Q, QF, 0>), dim3(grid), dim3(64), 0, s, t, a);
   return hipGetLastError();

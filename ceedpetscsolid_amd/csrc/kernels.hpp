@@ -77,6 +77,11 @@ struct FusedGradArgs {
   const double *geo_aff;      // set (with geo) only when EVERY element is affine: [nelem][GEO_NAFF] = {det J, dXdx[9]} of the
                                // element (launch_geo_affine) -- the kernel then multiplies det J by the point's weight and
                                // reads the nine factors instead of forming J, its adjugate and a reciprocal at every point
+  const double *geo_swept;    // set (with geo, without geo_aff) when EVERY element is SWEPT along the same reference direction geo_axis:
+                               // x and y bilinear in the other two directions, z linear in that one (the prisms of an extruded mesh: the
+                               // reference's cylinders).  [nelem][GEO_NSWEPT] (launch_geo_swept); J is then a 2 x 2 block and a constant,
+                               // dXdx has five entries and the two products of the physics with it take 15 multiply-adds instead of 27
+  int geo_axis;               // the sweep's reference direction (0, 1, 2), one for the whole mesh
   double qref[MAXN1D], qwt[MAXN1D];  // 1-D quadrature points / weights of the geometry (used with geo)
   // Even-odd form of the 1-D tables (pencil_even_odd(Q)).  The tables of symmetric point sets are
   // centro-symmetric (interp: M[N-1-i][K-1-j] = M[i][j]) or centro-antisymmetric (derivatives), so with
@@ -159,6 +164,12 @@ hipError_t launch_geo_coeffs(const uint32_t *off_x, const double *xcoord, double
 // aff[e][GEO_NAFF]; *n_not_affine (device, zeroed by the caller) counts the elements that are NOT affine.
 constexpr int GEO_NAFF = 10;
 hipError_t launch_geo_affine(const double *geo, double *aff, int nelem, int *n_not_affine, hipStream_t s);
+// Swept elements: z = z0 + zs xi_s for one reference direction s, x and y bilinear in the other two (a < b) and free of xi_s, all to
+// 1e-13 of the largest linear coefficient.  sw[e][GEO_NSWEPT] = {x_a, x_b, x_ab, y_a, y_b, y_ab, sgn zs, 1 / zs} for the element's OWN
+// sweep direction (sgn = -1 for s = 1: (a, b, s) is then an odd permutation of the reference directions); count[s] (device, zeroed
+// by the caller) counts the elements swept along s, count[3] the ones that are not swept at all (or along x or y in space).
+constexpr int GEO_NSWEPT = 8;
+hipError_t launch_geo_swept(const double *geo, double *sw, int nelem, int *count, hipStream_t s);
 
 struct SetupGeoArgs {
   const uint32_t *off_x;  // [nelem][8]

@@ -108,6 +108,46 @@ hipError_t launch_geo_affine(const double *geo, double *aff, int nelem, int *n_n
   return hipGetLastError();
 }
 
+__global__ void k_geo_swept(const double *geo, double *sw, int nelem, int *count) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nelem) return;
+  const double *g = geo + (size_t)e * GEO_NCOEF;   // [c][m], m: 0 xi, 1 eta, 2 zeta, 3 xi eta, 4 xi zeta, 5 eta zeta, 6 xi eta zeta
+  double lin = 0.;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int m = 0; m < 3; m++) lin = fmax(lin, fabs(g[c * 7 + m]));
+  const double tol = 1e-13 * lin;
+  int found = 3;
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    // monomials that contain direction s: the linear one, the two pairs with it, the triple
+    const int p0 = s == 0 ? 3 : (s == 1 ? 3 : 4), p1 = s == 0 ? 4 : (s == 1 ? 5 : 5);
+    bool ok = fabs(g[2 * 7 + s]) > tol;
+#pragma unroll
+    for (int m = 0; m < 7; m++)
+      if (m != s) ok = ok && fabs(g[2 * 7 + m]) <= tol;                 // z depends on xi_s alone
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+      ok = ok && fabs(g[c * 7 + s]) <= tol && fabs(g[c * 7 + p0]) <= tol && fabs(g[c * 7 + p1]) <= tol && fabs(g[c * 7 + 6]) <= tol;
+    if (ok && found == 3) found = s;
+  }
+  atomicAdd(count + found, 1);
+  if (found == 3) return;
+  const int a = found == 0 ? 1 : 0, b = found == 2 ? 1 : 2, ab = (a == 0 && b == 1) ? 3 : ((a == 0 && b == 2) ? 4 : 5);
+  double *o = sw + (size_t)e * GEO_NSWEPT;
+  o[0] = g[a]; o[1] = g[b]; o[2] = g[ab];
+  o[3] = g[7 + a]; o[4] = g[7 + b]; o[5] = g[7 + ab];
+  const double zs = g[14 + found];
+  o[6] = found == 1 ? -zs : zs;
+  o[7] = 1. / zs;
+}
+hipError_t launch_geo_swept(const double *geo, double *sw, int nelem, int *count, hipStream_t s) {
+  if (nelem <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_geo_swept, dim3((unsigned)((nelem + 255) / 256)), dim3(256), 0, s, geo, sw, nelem, count);
+  return hipGetLastError();
+}
+
 template <int Q>
 static hipError_t setup_geo_t(const BasisTables &t, const SetupGeoArgs &a, hipStream_t s) {
   using G = Geom<Q>;

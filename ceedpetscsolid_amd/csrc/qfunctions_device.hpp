@@ -26,7 +26,13 @@ struct Phys { double nu, E, lambda, TwoMu; };
 
 #define CPS_DEV static __device__ __forceinline__
 
+// SW ("swept" elements, FusedGradArgs::geo_swept): the element is a prism -- x and y are bilinear in two reference directions, z is
+// linear in the third -- and the fused kernel hands the reference directions over in the order (in-plane, in-plane, sweep), so that
+// dXdx[m][k] vanishes wherever exactly one of m, k is 2: five of its nine entries are left and the two products below take 15
+// multiply-adds instead of 27 (the sums run over the same terms in the same order; the dropped ones are exact zeros).
+constexpr bool swept_zero(int m, int k) { return (m < 2) != (k < 2); }
 // g[c][k] = sum_m dXdx[m][k] du[c][m], du[c][m] = ug[m*3+c]   (linElas.h:90-95)
+template <bool SW = false>
 CPS_DEV void physical_grad(const double *ug, const double *qd, double g[3][3]) {
 #pragma unroll
   for (int c = 0; c < 3; c++)
@@ -34,11 +40,13 @@ CPS_DEV void physical_grad(const double *ug, const double *qd, double g[3][3]) {
     for (int k = 0; k < 3; k++) {
       double s = 0.;
 #pragma unroll
-      for (int m = 0; m < 3; m++) s += qd[1 + 3 * m + k] * ug[m * 3 + c];
+      for (int m = 0; m < 3; m++)
+        if (!(SW && swept_zero(m, k))) s += qd[1 + 3 * m + k] * ug[m * 3 + c];
       g[c][k] = s;
     }
 }
 // dv[k*3+c] = sum_m dXdx[k][m] T[c][m] wdetJ                  (linElas.h:148-153)
+template <bool SW = false>
 CPS_DEV void pull_back(const double T[3][3], const double *qd, double *dv) {
   // the reference scales every product by wdetJ; scaling the sum once differs by <= 2 ulp
   const double wdetJ = qd[0];
@@ -48,16 +56,18 @@ CPS_DEV void pull_back(const double T[3][3], const double *qd, double *dv) {
     for (int k = 0; k < 3; k++) {
       double s = 0.;
 #pragma unroll
-      for (int m = 0; m < 3; m++) s += qd[1 + 3 * k + m] * T[c][m];
+      for (int m = 0; m < 3; m++)
+        if (!(SW && swept_zero(k, m))) s += qd[1 + 3 * k + m] * T[c][m];
       dv[k * 3 + c] = s * wdetJ;
     }
 }
 
 // ---- linear elasticity (linElas.h:97-145; note the reference's shear terms
 // are ss*(1-2nu)*e_ij/2 with the TENSOR strain e_ij) -------------------------
+template <bool SW = false>
 CPS_DEV void qf_linelas(const Phys ph, const double *ug, const double *qd, double *dv) {
   double g[3][3], sig[3][3];
-  physical_grad(ug, qd, g);
+  physical_grad<SW>(ug, qd, g);
   const double nu = ph.nu;
   const double ss = ph.E / ((1 + nu) * (1 - 2 * nu));
   const double e00 = g[0][0], e11 = g[1][1], e22 = g[2][2];
@@ -68,7 +78,7 @@ CPS_DEV void qf_linelas(const Phys ph, const double *ug, const double *qd, doubl
   sig[1][2] = sig[2][1] = ss * (1 - 2 * nu) * e12 * 0.5;
   sig[0][2] = sig[2][0] = ss * (1 - 2 * nu) * e02 * 0.5;
   sig[0][1] = sig[1][0] = ss * (1 - 2 * nu) * e01 * 0.5;
-  pull_back(sig, qd, dv);
+  pull_back<SW>(sig, qd, dv);
 }
 
 // ---- Neo-Hookean small strain (hyperSS.h) ---------------------------------
@@ -85,10 +95,11 @@ CPS_DEV void lame(const Phys ph, double &lambda, double &TwoMu) {  // hyperSS.h:
   TwoMu = ph.TwoMu;
   lambda = ph.lambda;
 }
+template <bool SW = false>
 CPS_DEV void qf_hyperss_f(const Phys ph, const double *ug, const double *qd, double *dv, double *st) {
   double lambda, TwoMu, g[3][3], sig[3][3];
   lame(ph, lambda, TwoMu);
-  physical_grad(ug, qd, g);
+  physical_grad<SW>(ug, qd, g);
 #pragma unroll
   for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -99,12 +110,13 @@ CPS_DEV void qf_hyperss_f(const Phys ph, const double *ug, const double *qd, dou
 #pragma unroll
     for (int b = 0; b < 3; b++)
       sig[a][b] = TwoMu * ((g[a][b] + g[b][a]) / 2.) + (a == b ? lambda * llv : 0.);
-  pull_back(sig, qd, dv);
+  pull_back<SW>(sig, qd, dv);
 }
+template <bool SW = false>
 CPS_DEV void qf_hyperss_df(const Phys ph, const double *dug, const double *qd, const double *st, double *dv) {
   double lambda, TwoMu, dg[3][3], ds[3][3];
   lame(ph, lambda, TwoMu);
-  physical_grad(dug, qd, dg);
+  physical_grad<SW>(dug, qd, dg);
   const double lambda_bar = lambda / (1 + (st[0] + st[4] + st[8]));  // hyperSS.h:294-295
   const double ltr = lambda_bar * (dg[0][0] + dg[1][1] + dg[2][2]);
 #pragma unroll
@@ -112,7 +124,7 @@ CPS_DEV void qf_hyperss_df(const Phys ph, const double *dug, const double *qd, c
 #pragma unroll
     for (int b = 0; b < 3; b++)
       ds[a][b] = TwoMu * ((dg[a][b] + dg[b][a]) / 2.) + (a == b ? ltr : 0.);
-  pull_back(ds, qd, dv);
+  pull_back<SW>(ds, qd, dv);
 }
 
 // ---- Neo-Hookean finite strain (hyperFS.h) --------------------------------
@@ -182,10 +194,11 @@ CPS_DEV void fs_lame(const Phys ph, double &lambda, double &mu) {  // hyperFS.h:
 }
 CPS_DEV void fs_derived_state(double lambda, double mu, const double g[3][3], double *ds);
 // ds (may be null, wave-uniform): the derived state of the tangent, written beside grad u (fs_derived_state)
+template <bool SW = false>
 CPS_DEV void qf_hyperfs_f(const Phys ph, const double *ug, const double *qd, double *dv, double *st, double *ds = nullptr) {
   double lambda, mu, g[3][3], P[3][3];
   fs_lame(ph, lambda, mu);
-  physical_grad(ug, qd, g);
+  physical_grad<SW>(ug, qd, g);
 #pragma unroll
   for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -202,7 +215,7 @@ CPS_DEV void qf_hyperfs_f(const Phys ph, const double *ug, const double *qd, dou
       for (int m = 0; m < 3; m++) t += (g[a][m] + (a == m ? 1. : 0.)) * CPS_SYM(s.S, m, b);
       P[a][b] = t;
     }
-  pull_back(P, qd, dv);
+  pull_back<SW>(P, qd, dv);
 }
 // 1/x by v_rcp_f64 + two Newton steps (<= 1 ulp for the normal, well-scaled arguments met here).
 CPS_DEV double rcp_nr(double x) {
@@ -234,10 +247,11 @@ CPS_DEV double log1p_series4_shifted_fast(double x) {
 // evaluation to rounding: ~1e-15 relative for the conditioning of F met in elasticity; the 1e-10 parity tests
 // cover it).  ln J uses the reference's own series on det C - 1 = J^2 - 1.  F^-1 = A / J is never formed: A enters
 // unscaled and 1/J^2 is folded into the two scalars.
+template <bool SW = false>
 CPS_DEV void qf_hyperfs_df(const Phys ph, const double *dug, const double *qd, const double *st, double *dv) {
   double lambda, mu, dg[3][3], F[3][3], A[3][3], h[3][3], M[3][3], dP[3][3];
   fs_lame(ph, lambda, mu);
-  physical_grad(dug, qd, dg);
+  physical_grad<SW>(dug, qd, dg);
 #pragma unroll
   for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -276,7 +290,7 @@ CPS_DEV void qf_hyperfs_df(const Phys ph, const double *dug, const double *qd, c
       for (int m = 0; m < 3; m++) t += M[a][m] * A[b][m];
       dP[a][b] = t;
     }
-  pull_back(dP, qd, dv);
+  pull_back<SW>(dP, qd, dv);
 }
 // DERIVED STATE (index.rst:458-464 discusses the same storage / recompute trade): what the tangent
 // above needs of the state is F^-1 (nine numbers) and f = lambda ln J - mu (one); forming them from the stored grad u costs
@@ -305,10 +319,11 @@ CPS_DEV void fs_derived_state(double lambda, double mu, const double g[3][3], do
   ds[9] = lambda * log1p_series4_shifted_fast(__builtin_fma(Jdet, Jdet, -1.)) * 0.5 - mu;
 }
 // dP = mu grad(du) + (lambda tr(h) I - f h^T) F^-T,  h = grad(du) F^-1, from the derived state
+template <bool SW = false>
 CPS_DEV void qf_hyperfs_df_ds(const Phys ph, const double *dug, const double *qd, const double *ds, double *dv) {
   double lambda, mu, dg[3][3], h[3][3], dP[3][3];
   fs_lame(ph, lambda, mu);
-  physical_grad(dug, qd, dg);
+  physical_grad<SW>(dug, qd, dg);
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -328,14 +343,15 @@ CPS_DEV void qf_hyperfs_df_ds(const Phys ph, const double *dug, const double *qd
       for (int m = 0; m < 3; m++) t -= f * h[m][a] * ds[3 * b + m];
       dP[a][b] = t;
     }
-  pull_back(dP, qd, dv);
+  pull_back<SW>(dP, qd, dv);
 }
 // The reference's own evaluation order (kept for A/B and as documentation of the map above).
+template <bool SW = false>
 CPS_DEV void qf_hyperfs_df_reference_form(const Phys ph, const double *dug, const double *qd, const double *st, double *dv) {
   constexpr int J[6] = {0, 1, 2, 1, 0, 0}, K[6] = {0, 1, 2, 2, 2, 1};
   double lambda, mu, dg[3][3], g[3][3], F[3][3];
   fs_lame(ph, lambda, mu);
-  physical_grad(dug, qd, dg);
+  physical_grad<SW>(dug, qd, dg);
 #pragma unroll
   for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -389,7 +405,7 @@ CPS_DEV void qf_hyperfs_df_reference_form(const Phys ph, const double *dug, cons
       for (int m = 0; m < 3; m++) t += dg[a][m] * CPS_SYM(s.S, m, b) + F[a][m] * CPS_SYM(dS, m, b);
       dP[a][b] = t;
     }
-  pull_back(dP, qd, dv);
+  pull_back<SW>(dP, qd, dv);
 }
 
 // ---- geometry (common.h:47-101).  Jg[d*3+c] = d x_c / d xi_d ---------------
@@ -443,18 +459,18 @@ template <> struct QFTraits<QF_HYPERFS_F>  { static constexpr bool state_in = fa
 template <> struct QFTraits<QF_HYPERFS_DF> { static constexpr bool state_in = true,  state_out = false; static constexpr int nstate = 9; };
 template <> struct QFTraits<QF_HYPERFS_DF_DS> { static constexpr bool state_in = true, state_out = false; static constexpr int nstate = 10; };
 
-template <int QF>
+template <int QF, bool SW = false>
 CPS_DEV void qf_point(const Phys ph, const double *ug, const double *qd, const double *st_in,
                       double *dv, double *st_out, double *derived_out = nullptr) {
-  if constexpr (QF == QF_LINELAS) qf_linelas(ph, ug, qd, dv);
-  else if constexpr (QF == QF_HYPERSS_F) qf_hyperss_f(ph, ug, qd, dv, st_out);
-  else if constexpr (QF == QF_HYPERSS_DF) qf_hyperss_df(ph, ug, qd, st_in, dv);
-  else if constexpr (QF == QF_HYPERFS_F) qf_hyperfs_f(ph, ug, qd, dv, st_out, derived_out);
-  else if constexpr (QF == QF_HYPERFS_DF_DS) qf_hyperfs_df_ds(ph, ug, qd, st_in, dv);
+  if constexpr (QF == QF_LINELAS) qf_linelas<SW>(ph, ug, qd, dv);
+  else if constexpr (QF == QF_HYPERSS_F) qf_hyperss_f<SW>(ph, ug, qd, dv, st_out);
+  else if constexpr (QF == QF_HYPERSS_DF) qf_hyperss_df<SW>(ph, ug, qd, st_in, dv);
+  else if constexpr (QF == QF_HYPERFS_F) qf_hyperfs_f<SW>(ph, ug, qd, dv, st_out, derived_out);
+  else if constexpr (QF == QF_HYPERFS_DF_DS) qf_hyperfs_df_ds<SW>(ph, ug, qd, st_in, dv);
 #ifdef CPS_FS_REFERENCE_FORM  // A/B builds only
-  else if constexpr (QF == QF_HYPERFS_DF) qf_hyperfs_df_reference_form(ph, ug, qd, st_in, dv);
+  else if constexpr (QF == QF_HYPERFS_DF) qf_hyperfs_df_reference_form<SW>(ph, ug, qd, st_in, dv);
 #else
-  else if constexpr (QF == QF_HYPERFS_DF) qf_hyperfs_df(ph, ug, qd, st_in, dv);
+  else if constexpr (QF == QF_HYPERFS_DF) qf_hyperfs_df<SW>(ph, ug, qd, st_in, dv);
 #endif
 }
 

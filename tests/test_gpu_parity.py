@@ -771,6 +771,61 @@ def test_affine_elements_take_the_per_element_factors(gpu, oracle, product_lib, 
             assert rel_err(a, o) < 1e-10
 
 
+def _relabel_axes(mesh, perm):
+    """The same mesh with every element's local (reference) directions relabelled: new direction d is old direction perm[d]
+    (a cyclic perm keeps the Jacobians positive); vertex order and local face numbers of the side sets follow."""
+    import copy
+    m = copy.copy(mesh)
+    old_of_new = [sum(((c >> d) & 1) << perm[d] for d in range(3)) for c in range(8)]
+    m.cells = mesh.cells[:, old_of_new].copy()
+    new_dir = {perm[d]: d for d in range(3)}
+    m.side_sets = {k: np.stack([v[:, 0], 2 * np.array([new_dir[f // 2] for f in v[:, 1]]) + v[:, 1] % 2], axis=1) for k, v in mesh.side_sets.items()}
+    return m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("problem", ["linElas", "hyperSS", "hyperFS"])
+def test_swept_elements_take_the_two_by_two_jacobian(gpu, oracle, product_lib, problem):
+    """The reference's cylinders are EXTRUDED meshes: in every element x and y are bilinear in two reference directions and z is
+    linear in the third (tests/golden/mesh_cylinder8_*: the sweep runs along the element's zeta in two of them, along eta in
+    cylinder8_44928e).  The SetupGeo operator finds that out (one sweep direction for the whole mesh), and the fused kernels then
+    form a 2 x 2 Jacobian per point and multiply with the five entries of dXdx that are left (qfunctions/common.h:47-101 is the
+    arithmetic either way).  Same results as the general per-point recompute (CEED_MI355X_SWEPT=0) and as the oracle for the
+    sweep along each of the three reference directions, every level; a mesh with ONE element that is no prism takes the general
+    path everywhere; the reference's own unstructured cylinder is recognised."""
+    general = _ceed_with_env(product_lib, "CEED_MI355X_SWEPT", "0")
+    base = hollow_cylinder_mesh(2, 8, 3)
+    mixed = hollow_cylinder_mesh(2, 6, 2)
+    mixed.coords = mixed.coords.copy()
+    mixed.coords[0] += np.array([0.0, 0.0, 0.07])              # one vertex lifted: its elements are no prisms any more
+    real = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_672e_4ss_us.npz"))
+    cases = [(base, 4, "swept elements"), (_relabel_axes(base, [1, 2, 0]), 4, "swept elements"), (_relabel_axes(base, [2, 0, 1]), 3, "swept elements"),
+             (_relabel_axes(hollow_cylinder_mesh(2, 6, 2), [1, 2, 0]), 6, "swept elements"), (real, 2, "swept elements"), (mixed, 3, "dXdx recomputed per point")]
+    for mesh, degree, want in cases:
+        outs = []
+        for c in (gpu, general, oracle):
+            p = SolidProblem(c, mesh, degree, problem, nu=0.3, E=2.0, bc_sides=[998])
+            n = p.lsize()
+            X, R = c.vector(n), c.vector(n)
+            X.set_array(p.smooth_state(0.1)); p.form_residual(X, R)
+            res = [R.to_numpy()]
+            for lv in range(len(p.levels)):
+                nl = p.lsize(lv)
+                x = c.vector(nl).set_array(np.random.default_rng(7 + lv).uniform(-1, 1, nl))
+                y = c.vector(nl)
+                p.apply_jacobian(lv, x, y)
+                res.append(y.to_numpy())
+            outs.append(res)
+            name = p.levels[p.fine].opJacob.kernel_name if c is not oracle else ""
+            if c is gpu:
+                assert want in name and ("swept" in name) == (want == "swept elements"), name
+            if c is general:
+                assert "recomputed per point" in name and "swept" not in name, name
+        for a, b, o in zip(*outs):
+            assert rel_err(a, b) < 1e-13
+            assert rel_err(a, o) < 1e-10
+
+
 @pytest.mark.gpu
 def test_derived_state_of_the_finite_strain_tangent(gpu, oracle, product_lib):
     """HyperFSF leaves, beside the stored grad u, the DERIVED state HyperFSdF needs -- F^-1 and lambda ln J - mu, ten doubles
