@@ -50,6 +50,24 @@ template <bool SW = false>
 CPS_DEV void pull_back(const double T[3][3], const double *qd, double *dv) {
   // the reference scales every product by wdetJ; scaling the sum once differs by <= 2 ulp
   const double wdetJ = qd[0];
+  if constexpr (SW) {   // five entries: scale THEM once instead of the nine sums
+    double K[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int m = 0; m < 3; m++) K[k][m] = swept_zero(k, m) ? 0. : qd[1 + 3 * k + m] * wdetJ;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        double s = 0.;
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+          if (!swept_zero(k, m)) s += K[k][m] * T[c][m];
+        dv[k * 3 + c] = s;
+      }
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < 3; c++)
 #pragma unroll
