@@ -146,7 +146,7 @@ def valu_issue(kernel_name: str, ngroups: int, seconds: float):
     if not m:
         return None
     P, Q, qf = int(m.group(1)), int(m.group(2)), m.group(3)
-    geo = 2 if "affine elements" in kernel_name else (1 if "recomputed" in kernel_name else 0)
+    geo = 2 if "affine elements" in kernel_name else (3 if "swept elements" in kernel_name else (1 if "recomputed" in kernel_name else 0))
     want = f"k_fused_pencil<P={P},Q={Q},{qf},geo={geo},eo={1 if 4 <= Q <= 7 else 0}>"
     for path in (os.path.join(ROOT, "ceedpetscsolid_amd", "csrc", "build", "isa_summary.txt"), os.path.join(ROOT, "profiles", "r03_isa_summary.txt")):
         if not os.path.exists(path):
@@ -158,7 +158,7 @@ def valu_issue(kernel_name: str, ngroups: int, seconds: float):
                 t_valu = valu * ngroups * 4 / (1024 * 2.4e9)
                 return {"valu_instructions_per_group": valu, "groups": ngroups, "valu_issue_us": 1e6 * t_valu,
                         "valu_issue_frac": t_valu / seconds, "of": "the whole apply's device time (kernel_avg_us), k_assemble included", "source": os.path.relpath(path, ROOT),
-                        "assumes": "4 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz (spec clock)"}
+                        "assumes": "4 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz (spec clock; the clock measured inside the kernel under this load is 2.0 GHz and two waves per SIMD issue one instruction per 4.5 cycles: profiles/r03_phase_timing.txt, DESIGN.md 7c); the count is the kernel's static one, prologue included"}
     return None
 
 
