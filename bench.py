@@ -162,6 +162,111 @@ def valu_issue(kernel_name: str, ngroups: int, seconds: float):
     return None
 
 
+def self_launch(n: int) -> None:
+    """`python bench.py --gpus N` run directly (no launcher in the environment): start the N ranks as a CHILD process --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same
+    arguments>` -- BEFORE anything in this process touches the GPU (a process that has initialised the GPU must not be
+    replaced, and the parent needs none), relay rank 0's single JSON line and exit with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without a launcher: starting {' '.join(cmd[1:8])} ... as a child process", file=sys.stderr, flush=True)
+    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in child.stdout.decode(errors="replace").splitlines() if ln.startswith("{") and ln.rstrip().endswith("}")]
+    for ln in child.stdout.decode(errors="replace").splitlines():
+        if ln not in lines[-1:]:
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    elif child.returncode == 0:
+        sys.exit("the ranks exited with status 0 but printed no JSON line")
+    sys.exit(child.returncode)
+
+
+def partition_text(args, world: int, overlap: bool, use_rccl: bool, emu: bool) -> str:
+    if not (world > 1 or emu):
+        return "single GPU"
+    strong = args.scaling == "strong"
+    if strong and args.workload == "box":
+        from ceedpetscsolid_amd.halo import block_grid
+        what = "blocks %dx%dx%d of ONE box" % block_grid(args.of if emu else world)
+    else:
+        what = "z-layers of ONE mesh" if strong else "one such mesh per GPU (z-slabs)"
+    return (what + "; halo sum " + ("overlapped with interior elements" if overlap else "after the apply")
+            + (" through CeedXHalo* (RCCL group of ncclSend/ncclRecv, pack / unpack-add kernels)" if use_rccl else " through torch.distributed P2P"))
+
+
+def dry_run(args, world: int, rank: int) -> None:
+    """--dry-run: the launch path of the N-rank job WITHOUT a device and without the operator -- the ranks rendezvous on
+    gloo, partition the ONE mesh exactly as the real run does, find their neighbour lists, and time --steps interface sums
+    of a test vector over torch.distributed (halo.HaloExchange on CPU tensors).  Rank 0 prints the line with "value": null
+    and "dry_run": true: what a CPU test (tests/test_bench_launch.py) and a rehearsal before an 8-GPU run can check --
+    that `bench.py --gpus N` starts, that every rank gets its share, and what the line says about itself."""
+    from ceedpetscsolid_amd.mesh import build_dofmap, dirichlet_mask, side_set_nodes
+    if world > 1:
+        dist.init_process_group("gloo")
+    strong = args.scaling == "strong"
+    if args.workload == "cylinder":
+        mesh = part_cylinder(rank, world, args.nr, args.nth, args.nz) if strong else slab_cylinder(rank, world, args.nr, args.nth, args.nz)
+        bc = [s for s in (998, 999) if s in mesh.side_sets]
+    elif args.workload == "box":
+        mesh = part_box(rank, world, args.nr, args.nth, args.nz) if strong else slab_box(rank, world, args.nr, args.nth, args.nz)
+        bc = [s for s in (1, 2) if s in mesh.side_sets]
+    else:
+        sys.exit("--dry-run: cylinder or box workload")
+    lead = interface_elements(mesh)
+    overlap = world > 1 and not args.no_overlap and lead.any() and not lead.all()
+    if overlap:
+        mesh = reorder_elements_first(mesh, lead)
+    dofmap = build_dofmap(mesh, args.degree)
+    mask = np.ascontiguousarray(dirichlet_mask(dofmap, side_set_nodes(mesh, dofmap, bc) if bc else np.zeros(0, dtype=np.int64)), dtype=np.uint8)
+    n = dofmap.lsize
+    halo = HaloExchange(mesh, dofmap, device=torch.device("cpu"))
+    n_global = halo.global_count((mask == 0).astype(np.float64))
+    yt = torch.from_numpy(coord_hash_vector(dofmap.node_coords, np.zeros(n, dtype=np.uint8)))
+    y0 = yt.clone()
+    for _ in range(args.warmup):
+        yt.copy_(y0); halo.add(yt)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        halo.add(yt)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    # every interface entry of the once-summed test vector = multiplicity over the ranks x the entry (the vector is rank-independent)
+    yt.copy_(y0); halo.add(yt)
+    ok = bool(torch.isfinite(yt).all())
+    if world > 1:
+        t = torch.tensor([elapsed, float(mesh.nelem)], dtype=torch.float64)
+        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+        ne = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(ne, t[1:])
+        elapsed, elems = float(t[0]), [int(v.item()) for v in ne]
+    else:
+        elems = [mesh.nelem]
+    if rank == 0:
+        Q = args.degree + 1
+        print(json.dumps({
+            "metric": "MDoF/s for matrix-free Jacobian apply, p=4 hyperFS hex, 1/2/4/8 GPU", "value": None, "unit": "MDoF/s",
+            "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "halo_path": None if world == 1 else "torch",
+            "rccl_ranks": None, "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"DRY RUN (no device, no operator: partition + gloo interface sums only) of {args.workload} "
+                                   f"{args.nr}x{args.nth}x{args.nz}, degree {args.degree}, Q={Q}",
+                       "global_dofs": n_global, "elements_per_rank": elems, "ldofs_rank0": n, "halo_dofs_rank0": halo.n_shared_dofs,
+                       "partition": partition_text(args, world, overlap, False, False), "finite": ok}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,7 +317,17 @@ def main():
                          "apply with the waves' phase time stamps collected; mean shader cycles per phase of the fused kernel -> FILE")
     ap.add_argument("--calibrate-traffic", action="store_true",
                     help="also launch k_axpby over a 1 GiB vector (known byte count) for PMC calibration")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no device, no operator: the N ranks rendezvous on gloo, partition the mesh as the real run does and time the "
+                         "interface sums of a test vector over torch.distributed; the line says \"dry_run\": true and \"value\": null")
     args = ap.parse_args()
+    # `python bench.py --gpus N` without a launcher: start the ranks ourselves, as a child, before any GPU call here
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but the launcher started {os.environ.get('WORLD_SIZE', '1')} ranks")
+    if args.dry_run:
+        return dry_run(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")))
 
     # ONE JSON line on stdout: libraries that print there on their own (RCCL's version banner at communicator start-up) go to
     # stderr until the line is printed
@@ -222,9 +337,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     ngpu_visible = torch.cuda.device_count()
     local_rank = local_rank % max(1, ngpu_visible)   # rehearsal: several ranks may share the one visible GPU
     torch.cuda.set_device(local_rank)
@@ -445,6 +557,7 @@ def main():
             "value": 1e-6 * n_global * args.steps / elapsed,
             "unit": "MDoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "rccl_ranks": (ceed.comm_size()[0] or None),   # ranks of the library's communicator READ BACK from RCCL (ncclCommCount); null: none was created
             "halo_path": halo_path,   # N > 1: "rccl" = the library's CeedXHalo* (pack kernel, RCCL group, unpack-add); "torch" on request / on gloo; "torch-fallback" only with --no-strict-halo
             "prewarm_ms": args.prewarm_ms, "prewarm_steps": prewarm_steps,
             "launch": "hipGraph replay of one recorded step" if args.graph else "direct",
@@ -462,10 +575,7 @@ def main():
                        "global_dofs": n_global, "elements_per_gpu": mesh.nelem, "ldofs_per_gpu": n,
                        "halo_dofs_rank0": halo.n_shared_dofs, "kernel": op.kernel_name,
                        "assembly": assembly_form, "schedule": os.environ.get("CEED_MI355X_SCHED", "static"),
-                       "partition": ((("z-layers of ONE mesh" if args.workload != "box" else "blocks %dx%dx%d of ONE box" % __import__("ceedpetscsolid_amd.halo", fromlist=["block_grid"]).block_grid(world)) if strong else "one such mesh per GPU (z-slabs)")
-                                     + "; halo sum " + ("overlapped with interior elements" if overlap else "after the apply")
-                                     + (" through CeedXHalo* (RCCL group of ncclSend/ncclRecv, pack / unpack-add kernels)" if use_rccl else " through torch.distributed P2P"))
-                                    if (world > 1 or emu) else "single GPU",
+                       "partition": partition_text(args, world, overlap, use_rccl, emu),
                        "halo_exchange_us_alone": halo_us, "halo_note": halo_note, "multi_gpu_measured": (None if world == 1 else "this run")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

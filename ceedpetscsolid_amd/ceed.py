@@ -64,7 +64,7 @@ class CeedLib:
         "CeedXSetErrorReturn", "CeedXLastError", "CeedXSetStream", "CeedXSynchronize",
         "CeedXOperatorGetKernelName", "CeedXOperatorSetDirichletMask",
         "CeedXOperatorSetTiming", "CeedXOperatorGetTiming", "CeedXOperatorSetDirichletMaskMode", "CeedXOperatorGetLaunchInfo", "CeedXOperatorApplyWithHalo", "CeedXCommAllReduce",
-        "CeedXCommGetUniqueId", "CeedXCommInit", "CeedXCommDestroy", "CeedXHaloCreate", "CeedXHaloStart", "CeedXHaloFinish", "CeedXHaloDestroy",
+        "CeedXCommGetUniqueId", "CeedXCommInit", "CeedXCommDestroy", "CeedXCommGetSize", "CeedXHaloCreate", "CeedXHaloStart", "CeedXHaloFinish", "CeedXHaloDestroy",
         "CeedXOperatorSetFineScale", "CeedXOperatorSetOverlapSplit", "CeedXOperatorApplyPhase",
         "CeedXVectorPointwiseMult", "CeedXVectorAXPBY", "CeedXVectorDot", "CeedXVectorChebyshevUpdate",
         "CeedXGraphBeginCapture", "CeedXGraphEndCapture", "CeedXGraphLaunch", "CeedXGraphDestroy",
@@ -236,6 +236,12 @@ class Ceed:
 
     def synchronize(self):
         self.L.chk(self.L.lib.CeedXSynchronize(self.h))
+
+    def comm_size(self):
+        """(ranks, this rank) of the Ceed's RCCL communicator as RCCL reports them (CeedXCommGetSize); (0, -1) without one."""
+        n, r = C.c_int(), C.c_int()
+        self.L.chk(self.L.lib.CeedXCommGetSize(self.h, C.byref(n), C.byref(r)))
+        return n.value, r.value
 
     def capture(self, fn) -> "Graph":
         """Record the device work `fn()` queues on this Ceed into a hipGraph (CeedXGraph*)."""

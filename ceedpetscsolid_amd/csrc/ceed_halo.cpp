@@ -19,6 +19,8 @@ struct Rccl {
   int (*GetUniqueId)(rccl_unique_id *) = nullptr;
   int (*CommInitRank)(void **, int, rccl_unique_id, int) = nullptr;
   int (*CommDestroy)(void *) = nullptr;
+  int (*CommCount)(void *, int *) = nullptr;
+  int (*CommUserRank)(void *, int *) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -41,6 +43,8 @@ int rccl_load() {
   g_rccl.CommInitRank = (int (*)(void **, int, rccl_unique_id, int))sym("ncclCommInitRank");
   g_rccl.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
   g_rccl_comm_destroy = g_rccl.CommDestroy;
+  g_rccl.CommCount = (int (*)(void *, int *))sym("ncclCommCount");
+  g_rccl.CommUserRank = (int (*)(void *, int *))sym("ncclCommUserRank");
   g_rccl.GroupStart = (int (*)())sym("ncclGroupStart");
   g_rccl.GroupEnd = (int (*)())sym("ncclGroupEnd");
   g_rccl.Send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))sym("ncclSend");
@@ -80,6 +84,21 @@ extern "C" int CeedXCommInit(Ceed ceed, int nranks, int rank, const char id[128]
       HIPCHK(hipStreamCreateWithPriority(&ceed->comm_stream, hipStreamNonBlocking, hi));
     else HIPCHK(hipStreamCreateWithFlags(&ceed->comm_stream, hipStreamNonBlocking));
   }
+  return 0;
+}
+// Ranks in the communicator and this rank's number, READ BACK from RCCL (ncclCommCount / ncclCommUserRank), not the
+// values CeedXCommInit was given: what a job reports as "the exchange ran over N ranks" (bench.py: rccl_ranks).  No
+// communicator: 0 ranks, rank -1.
+extern "C" int CeedXCommGetSize(Ceed ceed, int *nranks, int *rank) {
+  if (nranks) *nranks = 0;
+  if (rank) *rank = -1;
+  if (!ceed->comm) return 0;
+  if (!g_rccl.CommCount || !g_rccl.CommUserRank) return ceed_error("librccl lacks ncclCommCount / ncclCommUserRank");
+  int n = 0, r = -1;
+  RCCLCHK(g_rccl.CommCount(ceed->comm, &n));
+  RCCLCHK(g_rccl.CommUserRank(ceed->comm, &r));
+  if (nranks) *nranks = n;
+  if (rank) *rank = r;
   return 0;
 }
 extern "C" int CeedXCommDestroy(Ceed ceed) {

@@ -141,6 +141,18 @@ static inline int node_shell_rank(int n, int P) {
 #ifdef __HIPCC__
 __host__ __device__
 #endif
+static inline int abl_node_kind(int n, int P) {   // (timing-only ablation -DCPS_ABLATE_MERGE, tools/r4_merge_bound.sh) 1: stored straight to y, 2: not stored
+#ifdef CPS_ABLATE_MERGE
+  const int i = n % P, j = (n / P) % P, k = n / (P * P);
+  if (i == P - 1) return 2;
+  if (i == 0 && j > 0 && j < P - 1 && k > 0 && k < P - 1) return 1;
+#endif
+  (void)n; (void)P;
+  return 0;
+}
+#ifdef __HIPCC__
+__host__ __device__
+#endif
 static inline int element_shell_size(int P) { return P * P * P - (P > 2 ? (P - 2) * (P - 2) * (P - 2) : 0); }
 
 struct TransferArgs {

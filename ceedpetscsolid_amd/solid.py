@@ -87,8 +87,11 @@ class SolidProblem:
     def __init__(self, ceed: cd.Ceed, mesh: HexMesh, degree: int, problem: str = "hyperFS",
                  nu: float = 0.3, E: float = 1.0, multigrid: str = "logarithmic", qextra: int = 0,
                  bc_sides: Optional[Sequence[int]] = None, bc_all_boundary: bool = False,
-                 fused_bc: bool = True, shared_multiplicity=None):
-        """``fused_bc=False``: build the operator graphs exactly as the reference does and call NO extension of this
+                 fused_bc: bool = True, shared_multiplicity=None, qf_callbacks=None):
+        """``qf_callbacks``: name -> user callback pointer handed to CeedQFunctionCreateInterior, as the reference hands
+        ``problemOptions[...].apply`` / ``.jacob`` (setuplibceed.c:470-474,822-824); a host backend calls it, this device
+        backend resolves the name after ':' in the source string to its precompiled functor and ignores the pointer.
+        ``fused_bc=False``: build the operator graphs exactly as the reference does and call NO extension of this
         backend (no Dirichlet flags folded into the offsets, no fused multiplicity scale): the drop-in form, in which the
         caller does what src/matops.c does around CeedOperatorApply.
         ``bc_sides``: side-set ids clamped (all three components; -bc_clamp, setupdm.c:171-190);
@@ -101,6 +104,7 @@ class SolidProblem:
         self.fine = len(self.degrees) - 1
         self.Q = degree + 1 + qextra
         self.fused_bc = fused_bc
+        self._qf_cb = qf_callbacks or (lambda name: None)
         self.levels: List[LevelData] = []
         for p in self.degrees:
             dm = build_dofmap(mesh, p)
@@ -141,7 +145,7 @@ class SolidProblem:
         if self.gradu is not None:
             self.gradu.set_value(0.0)
         # geometric factors (:370-393)
-        qf = c.qfunction("SetupGeo", source="qfunctions/common.h:SetupGeo")
+        qf = c.qfunction("SetupGeo", f=self._qf_cb("SetupGeo"), source="qfunctions/common.h:SetupGeo")
         qf.add_input("dx", 9, cd.EVAL_GRAD).add_input("weight", 1, cd.EVAL_WEIGHT).add_output("qdata", 10, cd.EVAL_NONE)
         op = c.operator(qf)
         op.set_field("dx", self.Erestrictx, self.basisx, "active")
@@ -152,7 +156,7 @@ class SolidProblem:
         op.destroy(); qf.destroy()
         # residual operator (:518-542)
         name = self.info["apply"]
-        self.qfApply = c.qfunction(name, source=f"qfunctions/{self.info['src']}:{name}")
+        self.qfApply = c.qfunction(name, f=self._qf_cb(name), source=f"qfunctions/{self.info['src']}:{name}")
         self.qfApply.add_input("du", 9, cd.EVAL_GRAD).add_input("qdata", 10, cd.EVAL_NONE).add_output("dv", 9, cd.EVAL_GRAD)
         if self.info["state"]:
             self.qfApply.add_output("gradu", 9, cd.EVAL_NONE)
@@ -194,7 +198,7 @@ class SolidProblem:
         lv.yceed = c.vector(lv.dofmap.lsize)
         # Jacobian (:818-839)
         name = self.info["jacob"]
-        lv.qfJacob = c.qfunction(name, source=f"qfunctions/{self.info['src']}:{name}")
+        lv.qfJacob = c.qfunction(name, f=self._qf_cb(name), source=f"qfunctions/{self.info['src']}:{name}")
         lv.qfJacob.add_input("deltadu", 9, cd.EVAL_GRAD).add_input("qdata", 10, cd.EVAL_NONE)
         if self.info["state"]:
             lv.qfJacob.add_input("gradu", 9, cd.EVAL_NONE)

@@ -374,6 +374,9 @@ typedef struct CeedXHalo_private *CeedXHalo;
 CEED_EXTERN int CeedXCommGetUniqueId(Ceed ceed, char id[128]);
 CEED_EXTERN int CeedXCommInit(Ceed ceed, int nranks, int rank, const char id[128]);
 CEED_EXTERN int CeedXCommDestroy(Ceed ceed);
+/* Ranks of the communicator and this rank's number as RCCL itself reports them   */
+/* (ncclCommCount / ncclCommUserRank); 0 and -1 without a communicator.           */
+CEED_EXTERN int CeedXCommGetSize(Ceed ceed, int *nranks, int *rank);
 CEED_EXTERN int CeedXHaloCreate(Ceed ceed, CeedInt nneigh, const int *neigh_rank,
                                 const CeedInt *count, const CeedInt *const *index,
                                 CeedXHalo *halo);

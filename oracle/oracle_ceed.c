@@ -1176,6 +1176,7 @@ struct CeedXHalo_private { int nneigh; };
 int CeedXCommGetUniqueId(Ceed ceed, char id[128]) { (void)ceed; (void)id; return oracle_error("no communicator in the CPU oracle"); }
 int CeedXCommInit(Ceed ceed, int nranks, int rank, const char id[128]) { (void)ceed; (void)rank; (void)id; return nranks == 1 ? 0 : oracle_error("no communicator in the CPU oracle"); }
 int CeedXCommDestroy(Ceed ceed) { (void)ceed; return 0; }
+int CeedXCommGetSize(Ceed ceed, int *nranks, int *rank) { (void)ceed; if (nranks) *nranks = 0; if (rank) *rank = -1; return 0; }
 int CeedXHaloCreate(Ceed ceed, CeedInt nneigh, const int *neigh_rank, const CeedInt *count, const CeedInt *const *index, CeedXHalo *halo) {
   (void)ceed; (void)neigh_rank; (void)count; (void)index;
   if (nneigh != 0) return oracle_error("the CPU oracle exchanges no halo (use ceedpetscsolid_amd.halo over gloo)");

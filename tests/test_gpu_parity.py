@@ -103,6 +103,22 @@ def test_all_operators_match_oracle(oracle, gpu, name, mk, degree, problem, bc):
             assert rel_err(cb.to_numpy(), ca.to_numpy()) < TOL
 
 
+@pytest.mark.parametrize("name", __import__("conftest").operator_golden_cases())
+def test_operators_match_reference_callbacks(gpu, name):
+    """The HIP path against vectors the REFERENCE's own compiled callbacks produced inside whole operators
+    (tests/golden/operators.npz, oracle/gen_operator_golden.py: hyperFS.h:147-464, hyperSS.h:60-321, linElas.h:39-280,
+    common.h:47-101 as object code): residual, stored state, Jacobian action and diagonal on every level at the parity bar;
+    meshes with general, swept and affine elements so that every geometry form of the fused kernel is compared."""
+    from conftest import check_against_operator_golden, operator_golden_problem
+    p, f = operator_golden_problem(gpu, name)
+    check_against_operator_golden(p, f, TOL)
+    want = {"affine": "affine elements", "swept": "swept elements", "general": "recomputed"}
+    for key, text in want.items():
+        if name.endswith(key):
+            assert text in p.levels[p.fine].opJacob.kernel_name, p.levels[p.fine].opJacob.kernel_name
+    p.destroy()
+
+
 def test_restriction_indices_bit_exact(oracle, gpu):
     """Gather through the offsets is a pure copy: the E-vectors must be bitwise identical."""
     mesh = distorted_box(3, 3, 2)

@@ -211,3 +211,15 @@ def test_diagnostic_operator_on_oracle(oracle, problem):
              (dp * 1)(ref.ctypes.data_as(dp))) == 0
     assert np.abs(out[:, :3] - u).max() < 1e-14
     assert np.abs(out[:, 3:] - ref[3:, 0][None, :]).max() < 1e-12 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name", __import__("conftest").operator_golden_cases())
+def test_restated_physics_inside_operators_matches_the_reference_callbacks(oracle, name):
+    """tests/golden/operators.npz holds residual / stored state / Jacobian action / diagonal computed by the oracle's operators
+    with the REFERENCE's own compiled QFunctions as user callbacks (oracle/gen_operator_golden.py).  The same operators with
+    the oracle's restated physics must reproduce them to rounding: the restatement is pinned end to end, not only at the 96
+    sample points of qfunctions.npz."""
+    from conftest import check_against_operator_golden, operator_golden_problem
+    p, f = operator_golden_problem(oracle, name)
+    check_against_operator_golden(p, f, 1e-13)
+    p.destroy()
