@@ -72,19 +72,60 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("BENCH_CPU_THREADS", "16"))))
 
 
+def isa_kernel_key(kernel_name: str):
+    """Name of the fused kernel's instantiation as tools/isa_guard.py lists it, from the operator's kernel name."""
+    import re
+    m = re.match(r"fused_grad<P=(\d+),Q=(\d+),([\w+]+)>", kernel_name)
+    if not m:
+        return None
+    P, Q, qf = int(m.group(1)), int(m.group(2)), m.group(3)
+    geo = 2 if "affine elements" in kernel_name else (3 if "swept elements" in kernel_name else (1 if "recomputed" in kernel_name else 0))
+    return f"k_fused_pencil<P={P},Q={Q},{qf},geo={geo},eo={1 if 4 <= Q <= 7 else 0}>"
+
+
+def isa_line(kernel_name: str, path: str):
+    """The instantiation's row of an ISA summary (registers, LDS bytes, instruction counts: tools/isa_guard.py), or None."""
+    want = isa_kernel_key(kernel_name)
+    if not want or not os.path.exists(path):
+        return None
+    for line in open(path):
+        f = line.rstrip("\n").split("\t")
+        if f[0] == want:
+            return f
+    return None
+
+
+BUILD_ISA = os.path.join(ROOT, "ceedpetscsolid_amd", "csrc", "build", "isa_summary.txt")
+
+
 def traffic_from_profile(kernel_name: str, nelem: int):
     """HBM bytes per operator apply from the newest committed PMC reduction (tools/collect_traffic.py ->
-    profiles/rNN_traffic.json), if it was taken on this workload; (bytes, provenance) or (None, reason).  The value is a
-    constant of that profile, NOT a measurement of this run: PMC counters cannot be read from inside bench.py."""
+    profiles/rNN_traffic.json), if it was taken on this workload AND on this kernel; (bytes, provenance) or (None, reason).
+    The value is a constant of that profile, NOT a measurement of this run (PMC counters cannot be read from inside
+    bench.py), so it is only reported while the profile still describes the library that runs: the kernel's row of the ISA
+    summary (registers, LDS, instruction counts) stored with the profile -- "kernel_isa" in the file, else the round's
+    profiles/rNN_isa_summary.txt -- must equal the row of THIS build (csrc/build/isa_summary.txt).  Otherwise: null,
+    "stale: ..." (VERDICT r3 item 8)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
             continue
-        if d.get("elements_per_gpu") == nelem and d.get("kernel") == kernel_name:
-            return d.get("hbm_bytes_per_apply"), f"profiles/{os.path.basename(path)} @{d.get('commit', 'round 1')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated on a known axpby)"
-    return None, "no committed PMC profile of this workload / kernel"
+        if d.get("elements_per_gpu") != nelem:
+            continue
+        base = os.path.basename(path)
+        if d.get("kernel") != kernel_name:
+            return None, f"stale: profiles/{base} was taken on kernel '{d.get('kernel')}', this run's is '{kernel_name}'"
+        now = isa_line(kernel_name, BUILD_ISA)
+        then = d.get("kernel_isa") or isa_line(kernel_name, os.path.join(ROOT, "profiles", base.split("_")[0] + "_isa_summary.txt"))
+        if now is None or then is None:
+            return None, f"stale: cannot tell whether profiles/{base} @{d.get('commit')} describes this build (no ISA row: {'build' if now is None else 'profile'})"
+        if list(now) != list(then):
+            return None, (f"stale: profiles/{base} @{d.get('commit')} was taken on another build of this kernel (VGPR/SGPR/LDS/VALU/ds_read/ds_write "
+                          f"then {then[1]}/{then[2]}/{then[3]}/{then[11]}/{then[12]}/{then[13]}, now {now[1]}/{now[2]}/{now[3]}/{now[11]}/{now[12]}/{now[13]}): re-run tools/refresh_profiles.sh")
+        return d.get("hbm_bytes_per_apply"), f"profiles/{base} @{d.get('commit', 'round 1')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated on a known axpby; same ISA row as this build)"
+    return None, "no committed PMC profile of this workload"
 
 
 def own_floor_bytes(nelem: int, P: int, Q: int, lsize: int, state: bool) -> int:
@@ -141,24 +182,14 @@ def valu_issue(kernel_name: str, ngroups: int, seconds: float):
     element group (static count from the build's disassembly, tools/isa_guard.py) x groups x 4 cycles (a wave64 VALU
     instruction occupies its SIMD's 16 lanes for 4 cycles) / (1024 SIMDs x 2.4 GHz) / time.  The kernel's binding limit
     (VERDICT r2, weak 3): 1.0 would be a vector pipe that never idles."""
-    import re
-    m = re.match(r"fused_grad<P=(\d+),Q=(\d+),([\w+]+)>", kernel_name)
-    if not m:
-        return None
-    P, Q, qf = int(m.group(1)), int(m.group(2)), m.group(3)
-    geo = 2 if "affine elements" in kernel_name else (3 if "swept elements" in kernel_name else (1 if "recomputed" in kernel_name else 0))
-    want = f"k_fused_pencil<P={P},Q={Q},{qf},geo={geo},eo={1 if 4 <= Q <= 7 else 0}>"
-    for path in (os.path.join(ROOT, "ceedpetscsolid_amd", "csrc", "build", "isa_summary.txt"), os.path.join(ROOT, "profiles", "r03_isa_summary.txt")):
-        if not os.path.exists(path):
-            continue
-        for line in open(path):
-            f = line.rstrip("\n").split("\t")
-            if f[0] == want:
-                valu = int(f[11])
-                t_valu = valu * ngroups * 4 / (1024 * 2.4e9)
-                return {"valu_instructions_per_group": valu, "groups": ngroups, "valu_issue_us": 1e6 * t_valu,
-                        "valu_issue_frac": t_valu / seconds, "of": "the whole apply's device time (kernel_avg_us), k_assemble included", "source": os.path.relpath(path, ROOT),
-                        "assumes": "4 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz (spec clock; the clock measured inside the kernel under this load is 2.0 GHz and two waves per SIMD issue one instruction per 4.5 cycles: profiles/r03_phase_timing.txt, DESIGN.md 7c); the count is the kernel's static one, prologue included"}
+    for path in (BUILD_ISA, os.path.join(ROOT, "profiles", "r04_isa_summary.txt")):
+        f = isa_line(kernel_name, path)
+        if f:
+            valu = int(f[11])
+            t_valu = valu * ngroups * 4 / (1024 * 2.4e9)
+            return {"valu_instructions_per_group": valu, "groups": ngroups, "valu_issue_us": 1e6 * t_valu,
+                    "valu_issue_frac": t_valu / seconds, "of": "the whole apply's device time (kernel_avg_us), k_assemble included", "source": os.path.relpath(path, ROOT),
+                    "assumes": "4 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz (spec clock; the clock measured inside the kernel under this load is 2.0 GHz and two waves per SIMD issue one f64 instruction per 4.4 cycles: profiles/r03_phase_timing.txt, profiles/r04_mfma_f64.txt); the count is the kernel's static one, prologue included"}
     return None
 
 
@@ -317,6 +348,10 @@ def main():
                          "apply with the waves' phase time stamps collected; mean shader cycles per phase of the fused kernel -> FILE")
     ap.add_argument("--calibrate-traffic", action="store_true",
                     help="also launch k_axpby over a 1 GiB vector (known byte count) for PMC calibration")
+    ap.add_argument("--scramble", default="none", choices=["none", "order", "all"],
+                    help="one GPU: the SAME mesh as an unstructured generator might hand it over (mesh.scramble_mesh) -- order: elements and "
+                         "vertices in random order; all: also every element's local axes relabelled by a random rotation (no common sweep "
+                         "direction: the general geometry path).  The stand-in for the absent cylinder8_99Ke_4ss_us.exo at its worst")
     ap.add_argument("--dry-run", action="store_true",
                     help="no device, no operator: the N ranks rendezvous on gloo, partition the mesh as the real run does and time the "
                          "interface sums of a test vector over torch.distributed; the line says \"dry_run\": true and \"value\": null")
@@ -378,6 +413,11 @@ def main():
     else:
         mesh = part_box(rank, world, args.nr, args.nth, args.nz) if strong else slab_box(rank, world, args.nr, args.nth, args.nz)
         bc = [s for s in (1, 2) if s in mesh.side_sets]
+    if args.scramble != "none":
+        if world != 1 or emu:
+            sys.exit("--scramble runs on one GPU")
+        from ceedpetscsolid_amd.mesh import scramble_mesh
+        mesh = scramble_mesh(mesh, 20261005, order=True, orient=args.scramble == "all")
     lead = interface_elements(mesh, virtual=vw)        # collective; all False on one rank
     overlap = (world > 1 or emu) and not args.no_overlap and lead.any() and not lead.all()
     if overlap:
@@ -572,6 +612,7 @@ def main():
                                     f"degree {args.degree}, Q={Q}, side sets {bc} clamped, Jacobian apply y=J(u)x") if args.workload == "mesh" else
                                    (f"config 5 shape: {args.problem}, box {args.nr}x{args.nth}x{args.nz} = {mesh.nelem} hex per GPU, "
                                     f"degree {args.degree}, Q={Q}, z faces clamped, Jacobian apply y=J(u)x"),
+                       "scramble": None if args.scramble == "none" else ("elements and vertices in random order" + (", every element's local axes rotated at random" if args.scramble == "all" else "")),
                        "global_dofs": n_global, "elements_per_gpu": mesh.nelem, "ldofs_per_gpu": n,
                        "halo_dofs_rank0": halo.n_shared_dofs, "kernel": op.kernel_name,
                        "assembly": assembly_form, "schedule": os.environ.get("CEED_MI355X_SCHED", "static"),

@@ -152,6 +152,7 @@ extern "C" int CeedXGraphBeginCapture(Ceed ceed) {
   ceed->stream = ceed->capture_stream;
   HIPCHK(hipStreamBeginCapture(ceed->stream, hipStreamCaptureModeRelaxed));
   ceed->capturing = true;
+  ceed->capture_deps.clear();
   return 0;
 }
 extern "C" int CeedXGraphEndCapture(Ceed ceed, CeedXGraph *graph) {
@@ -160,12 +161,19 @@ extern "C" int CeedXGraphEndCapture(Ceed ceed, CeedXGraph *graph) {
   hipError_t e = hipStreamEndCapture(ceed->stream, &g);
   ceed->stream = ceed->saved_stream;
   ceed->capturing = false;
-  if (e != hipSuccess || !g) return ceed_error("graph capture failed: %s", hipGetErrorString(e));
+  if (e != hipSuccess || !g) { ceed->capture_deps.clear(); return ceed_error("graph capture failed: %s", hipGetErrorString(e)); }
   CeedXGraph G = new CeedXGraph_private;
+  G->deps.swap(ceed->capture_deps);
+  for (GraphDep &d : G->deps) d.v->refcount++;     // the vectors outlive the graph that checks them
   G->ceed = ceed; G->graph = g;
   (void)hipGraphGetNodes(g, nullptr, &G->nodes);
   e = hipGraphInstantiate(&G->exec, g, nullptr, nullptr, 0);
-  if (e != hipSuccess) { (void)hipGraphDestroy(g); delete G; return ceed_error("hipGraphInstantiate: %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    for (GraphDep &d : G->deps) { CeedVector v = d.v; (void)CeedVectorDestroy(&v); }
+    delete G;
+    return ceed_error("hipGraphInstantiate: %s", hipGetErrorString(e));
+  }
   ceed_ref(ceed);
   ceed->live_graphs++;
   *graph = G;
@@ -173,6 +181,14 @@ extern "C" int CeedXGraphEndCapture(Ceed ceed, CeedXGraph *graph) {
 }
 extern "C" int CeedXGraphLaunch(CeedXGraph G) {
   if (G->ceed->capturing) return ceed_error("CeedXGraphLaunch during graph capture");
+  for (const GraphDep &d : G->deps) {
+    if (d.geo && d.v->geo != d.geo)
+      return ceed_error("CeedXGraphLaunch: a qdata vector this graph's operators recompute the geometry of was overwritten after the recording "
+                        "(its recorded kernels would still use the old element maps): record the graph again");
+    if (d.derived && !(d.v->derived_valid && d.v->derived == d.derived))
+      return ceed_error("CeedXGraphLaunch: the stored state a recorded HyperFSdF apply reads was overwritten outside the residual operator after "
+                        "the recording (its derived state is no longer valid): record the graph again");
+  }
   HIPCHK(hipGraphLaunch(G->exec, G->ceed->stream));
   return 0;
 }
@@ -182,6 +198,7 @@ extern "C" int CeedXGraphDestroy(CeedXGraph *graph) {
   (void)hipStreamSynchronize(G->ceed->stream);
   if (G->exec) (void)hipGraphExecDestroy(G->exec);
   if (G->graph) (void)hipGraphDestroy(G->graph);
+  for (GraphDep &d : G->deps) { CeedVector v = d.v; (void)CeedVectorDestroy(&v); }
   if (--G->ceed->live_graphs == 0 && !G->ceed->capturing) ceed_free_parked(G->ceed);   // the stream was drained above
   ceed_unref(G->ceed);
   delete G;
@@ -191,9 +208,9 @@ extern "C" int CeedXGraphDestroy(CeedXGraph *graph) {
 
 void vec_drop_geo(CeedVector v) {
   v->derived_valid = false;
-  if (v->geo) (void)hipFree(v->geo);
-  if (v->geo_aff) (void)hipFree(v->geo_aff);
-  if (v->geo_swept) (void)hipFree(v->geo_swept);
+  // retired, not freed: a recorded graph may hold these pointers in its kernel arguments (it refuses to replay --
+  // CeedXGraphLaunch checks its GraphDeps -- but its nodes must never point at freed memory)
+  ceed_retire(v->ceed, v->geo); ceed_retire(v->ceed, v->geo_aff); ceed_retire(v->ceed, v->geo_swept);
   v->geo = v->geo_aff = v->geo_swept = nullptr; v->geo_nelem = v->geo_Q = 0;
 }
 
@@ -347,7 +364,7 @@ extern "C" int CeedVectorDestroy(CeedVector *vec) {
   if (v == CEED_VECTOR_ACTIVE || v == CEED_VECTOR_NONE) return 0;
   if (--v->refcount > 0) return 0;
   vec_drop_host(v); vec_drop_dev(v); vec_drop_geo(v);
-  if (v->derived) (void)hipFree(v->derived);
+  ceed_retire(v->ceed, v->derived);
   ceed_unref(v->ceed);
   delete v;
   return 0;

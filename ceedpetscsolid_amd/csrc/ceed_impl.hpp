@@ -58,6 +58,11 @@ struct CeedOptions {
 // ---------------------------------------------------------------------------
 // object layouts
 // ---------------------------------------------------------------------------
+// What a recorded operator apply read BESIDE its vectors' arrays: the provenance buffers kept with a qdata vector (geometry
+// coefficients) or a stored-state vector (derived state of the tangent).  Any other write to such a vector drops its
+// provenance, and an eager apply then reads the array itself; a recorded apply would go on reading the old buffer -- so a graph
+// remembers what it depends on and CeedXGraphLaunch refuses to replay once it no longer holds.
+struct GraphDep { CeedVector v; const double *geo; const double *derived; };
 struct Ceed_private {
   int refcount = 1;
   std::string resource;
@@ -86,8 +91,10 @@ struct Ceed_private {
   // hipGraph capture (CeedXGraphBeginCapture): device work is recorded on `capture_stream`
   hipStream_t capture_stream = nullptr, saved_stream = nullptr;
   bool capturing = false;
+  std::vector<GraphDep> capture_deps;   // collected while recording (fused_prepare), handed to the graph at EndCapture
 };
 struct CeedXGraph_private {
+  std::vector<GraphDep> deps;
   Ceed ceed = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -223,6 +230,7 @@ struct CeedOperator_private {
   // contributors of the priority nodes, which come first in the operator's own transpose map
   int ovl_lead = 0;
   CsrMap ovl_csr;
+  long ovl_halo_checked = 0;     // serial of the halo whose entries were last checked to lie on priority rows of ovl_csr
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;

@@ -412,6 +412,7 @@ static int fused_prepare(CeedOperator op, CeedVector in, CeedVector out, bool ad
         sv->derived_nu == a.nu && sv->derived_E == a.E) {
       F.qfkind = QF_HYPERFS_DF_DS;
       a.state_in = sv->derived;
+      if (c->capturing) c->capture_deps.push_back(GraphDep{sv, nullptr, sv->derived});
     }
   }
   if (op->o_state >= 0) {
@@ -443,6 +444,7 @@ static int fused_prepare(CeedOperator op, CeedVector in, CeedVector out, bool ad
       a.geo_aff = qv->geo_aff;
       a.geo_swept = qv->geo_swept; a.geo_axis = qv->geo_axis;
       for (int i = 0; i < ai.basis->Q1d; i++) { a.qref[i] = qv->geo_qref[i]; a.qwt[i] = qv->geo_qwt[i]; }
+      if (c->capturing) c->capture_deps.push_back(GraphDep{qv, qv->geo, nullptr});
     }
   }
   lame_constants(a.nu, a.E, &a.lambda, &a.TwoMu);
@@ -658,6 +660,18 @@ static int apply_fused_with_halo(CeedOperator op, CeedVector in, CeedVector out,
   if (out->length < H->lsize_min) return ceed_error("CeedXOperatorApplyWithHalo: vector shorter than the halo's indices");
   const CsrMap *M = F.M;
   const int lead = op->ovl_lead, rest = F.r->nelem - lead;
+  // Contract of this form: the arrivals are added by the SAME launch that overwrites the non-priority rows, and
+  // the exchange starts when only the priority rows are complete -- so every entry of the halo must lie on a priority row of
+  // the split map.  Checked once per (operator, halo) on the host.
+  if (op->ovl_halo_checked != H->serial) {
+    std::vector<uint32_t> prio(M->h_node_off.begin(), M->h_node_off.begin() + M->nprio);
+    std::sort(prio.begin(), prio.end());
+    for (uint32_t d : H->h_idx)
+      if (!std::binary_search(prio.begin(), prio.end(), d - d % 3u))
+        return ceed_error("CeedXOperatorApplyWithHalo: entry %u of the halo is not on a priority node of the operator's overlap split "
+                          "(CeedXOperatorSetOverlapSplit): its partial sum would be exchanged before it is complete", d);
+    op->ovl_halo_checked = H->serial;
+  }
   if (!M->full_cover) CHK(dev_zero(c, F.py, (size_t)out->length));
   TimerScope ts(op, s);
   const CeedOptions &o = c->opt;
@@ -737,14 +751,14 @@ static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool 
         HIPCHK(hipMalloc((void **)&out->geo_swept, sizeof(double) * GEO_NSWEPT * (size_t)a.nelem));
         HIPCHK(hipMalloc((void **)&d_cnt, 4 * sizeof(int)));
         HIPCHK(hipMemsetAsync(d_cnt, 0, 4 * sizeof(int), s));
-        HIPCHK(launch_geo_swept(out->geo, out->geo_swept, a.nelem, d_cnt, s));
+        HIPCHK(launch_geo_swept(out->geo, out->geo_swept, a.nelem, d_cnt, -1, s));     // count: every direction an element qualifies for
         HIPCHK(hipMemcpyAsync(cnt, d_cnt, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));      // set-up time only
         (void)hipFree(d_cnt);
         int axis = -1;
-        for (int d = 0; d < 3; d++) if (cnt[d] == a.nelem) axis = d;
-        if (axis < 0) { (void)hipFree(out->geo_swept); out->geo_swept = nullptr; }   // mixed directions or general hexes: the general recompute
-        else out->geo_axis = axis;
+        for (int d = 2; d >= 0; d--) if (cnt[d] == a.nelem) axis = d;      // a direction ALL elements share
+        if (axis < 0) { (void)hipFree(out->geo_swept); out->geo_swept = nullptr; }   // no common direction or general hexes: the general recompute
+        else { HIPCHK(launch_geo_swept(out->geo, out->geo_swept, a.nelem, nullptr, axis, s)); out->geo_axis = axis; }
       }
       for (int i = 0; i < x.basis->Q1d && i < MAXN1D; i++) { out->geo_qref[i] = x.basis->qref1d[i]; out->geo_qwt[i] = x.basis->qweight1d[i]; }
     }
@@ -967,6 +981,7 @@ extern "C" int CeedXOperatorSetOverlapSplit(CeedOperator op, CeedInt n_leading_e
   if (op->plan != PLAN_FUSED_GRAD) return ceed_error("overlap split is provided for the residual / Jacobian operators");
   CeedElemRestriction r = op->in[op->i_active].rstr;
   op->ovl_csr.release();
+  op->ovl_halo_checked = 0;
   if (op->d_node_flags_ovl) { (void)hipFree(op->d_node_flags_ovl); op->d_node_flags_ovl = nullptr; }
   op->ovl_lead = 0;
   if (!priority) return 0;

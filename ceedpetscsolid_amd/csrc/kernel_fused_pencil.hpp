@@ -182,7 +182,32 @@ CPS_DEV void mac_sel(ktab_t tab, const double *in, double *out) {
   else pencil_mac<NOUT, NIN, LD, TR>(tab, in, out);
 }
 // round r of a pass with `ntask` tasks: is this lane's task t = lane + 64 r a real one?
-CPS_DEV bool pencil_ok(int lane, int r, int ntask) { return (r + 1) * 64 <= ntask ? true : lane + 64 * r < ntask; }
+CPS_DEV bool pencil_ok(int lane, int r, int ntask) { return ntask == 0 ? lane < 0 : ((r + 1) * 64 <= ntask ? true : lane + 64 * r < ntask); }
+// Task -> lane mapping of a pass.  FLAT: task t = lane + 64 r over (element, component, b, a), a fastest.  BLOCKED (round 4): every
+// (element, component) block of n = NA NB pencils starts on a 32- or 64-lane boundary, the lanes behind its last pencil idle --
+// taken where that padding costs no extra round (Q = 5: 6 blocks of 25 in 6 half-waves = the same 3 rounds; Q = 7: 3 blocks of 49 in
+// 3 waves).  A ds_read_b64 is served in the lane groups {0-31}, {32-63} (MI355X_MICROARCH.md, LDS): with the blocks aligned to them a
+// group reads ONE component's pencils -- consecutive or evenly strided words, conflict-free along i and k -- instead of the tail of
+// one component and the head of the next, 125 words further on, whose banks collide (tools/lds_conflict_model.py: LDS-array cycles
+// per group of two elements 2 021 -> 1 896 at Q = 5).  Validity keeps the form of pencil_ok: the pass is handed a VIRTUAL lane
+// (negative for the lanes of a real block, huge for idle ones) and ntask = 0, so that `vlane + 64 r < 0` holds exactly for the
+// rounds in which the lane's block exists.
+// Only the STORES of a blocked pass are predicated: an idle lane holds the address of its block's last pencil (identical addresses
+// broadcast: no bank conflict) and loads and multiplies like its neighbours -- predicated loads would keep every round's registers
+// live across the others' (256 VGPRs and scratch when tried).  Hence ntask = 0 means: every block exists (3 E blk = 64 rounds exactly).
+#ifndef CPS_PENCIL_BLOCKED
+#define CPS_PENCIL_BLOCKED 1
+#endif
+constexpr int pencil_blk(int n, int E) {   // lanes per block, or 0: flat
+  if (!CPS_PENCIL_BLOCKED) return 0;
+  const int flat = (3 * E * n + 63) / 64, b = n <= 32 ? 32 : (n <= 64 ? 64 : 0);
+  return (b && b != n && (3 * E * b) % 64 == 0 && (3 * E * b) / 64 == flat) ? b : 0;
+}
+// loads and arithmetic of round r: real task, or any lane of a blocked pass
+#ifndef CPS_BLOCKED_IDLE_MATH
+#define CPS_BLOCKED_IDLE_MATH 0   // 1: the idle lanes of a blocked pass load and multiply too (only their stores are masked)
+#endif
+CPS_DEV bool pencil_ok_ld(int lane, int r, int ntask) { return (ntask == 0 && CPS_BLOCKED_IDLE_MATH) ? true : pencil_ok(lane, r, ntask); }
 
 // One single-input pass: every task reads its pencil (NIN entries at stride SB bytes from array SRC),
 // applies the NOUT x NIN matrix and writes NOUT entries to array DST (DST == SRC: in place).  All
@@ -213,24 +238,24 @@ CPS_DEV void mac_rounds(ktab_t table, const double (&in)[R][NIN], double (&out)[
     const ktab_t t = (S > 0 || DEP0) ? ktab_fresh_after<R * NOUT>(table, &out[0][0]) : ktab_fresh(table);
 #pragma unroll
     for (int r = 0; r < R; r++)
-      if (pencil_ok(lane, r, ntask)) pencil_mac_rows<S * H, ((S + 1) * H < NOUT ? (S + 1) * H : NOUT), NIN, LD, TR>(t, in[r], out[r]);
+      if (pencil_ok_ld(lane, r, ntask)) pencil_mac_rows<S * H, ((S + 1) * H < NOUT ? (S + 1) * H : NOUT), NIN, LD, TR>(t, in[r], out[r]);
     mac_rounds<NOUT, NIN, LD, TR, R, DEP0, S + 1>(table, in, out, lane, ntask);
   }
 }
 template <int NIN, int NOUT, int LD, bool TR, int SB, int SRC, int DST, int SGN, bool EO, int R>
-CPS_DEV void pencil_pass(ktab_t table, const ldsp_t (&addr)[R], int lane, int ntask) {
+CPS_DEV void pencil_pass_impl(ktab_t table, const ldsp_t (&addr)[R], int lane, int ntask) {
   double in[R][NIN];
 #pragma unroll
   for (int r = 0; r < R; r++)
-    if (pencil_ok(lane, r, ntask)) pencil_ld<NIN, SB, SRC>(addr[r], in[r]);
+    if (pencil_ok_ld(lane, r, ntask)) pencil_ld<NIN, SB, SRC>(addr[r], in[r]);
   if constexpr (table_splits<NOUT, NIN, EO>() == 1) {
     const ktab_t t = ktab_fresh(table);
 #pragma unroll
     for (int r = 0; r < R; r++)
-      if (pencil_ok(lane, r, ntask)) {
+      if (pencil_ok_ld(lane, r, ntask)) {
         double out[NOUT] = {};
         mac_sel<NOUT, NIN, LD, TR, SGN, EO>(t, in[r], out);
-        pencil_st<NOUT, SB, DST>(addr[r], out);
+        if (pencil_ok(lane, r, ntask)) pencil_st<NOUT, SB, DST>(addr[r], out);
       }
   } else {
     double out[R][NOUT];
@@ -243,6 +268,15 @@ CPS_DEV void pencil_pass(ktab_t table, const ldsp_t (&addr)[R], int lane, int nt
     for (int r = 0; r < R; r++)
       if (pencil_ok(lane, r, ntask)) pencil_st<NOUT, SB, DST>(addr[r], out[r]);
   }
+}
+
+// blocked pass (ntask = 0, lane = the virtual lane): ONE exec region around the whole pass for the lanes that own a pencil, every
+// round unconditional inside it (per-round predicates on loads and products cost 256 VGPRs and scratch when tried)
+template <int NIN, int NOUT, int LD, bool TR, int SB, int SRC, int DST, int SGN, bool EO, int R>
+CPS_DEV void pencil_pass(ktab_t table, const ldsp_t (&addr)[R], int lane, int ntask) {
+  if (ntask == 0) {
+    if (CPS_BLOCKED_IDLE_MATH || lane < 0) pencil_pass_impl<NIN, NOUT, LD, TR, SB, SRC, DST, SGN, EO, R>(table, addr, CPS_BLOCKED_IDLE_MATH ? lane : 0, CPS_BLOCKED_IDLE_MATH ? 0 : 64 * R);
+  } else pencil_pass_impl<NIN, NOUT, LD, TR, SB, SRC, DST, SGN, EO, R>(table, addr, lane, ntask);
 }
 
 #ifndef CPS_PENCIL_MINW
@@ -314,25 +348,36 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
   // pencil passes: task t = lane + 64 r over (element, component, b, a), a fastest; address of the
   // pencil's first entry.  Five families: direction i over nodal / quadrature (j,k), direction j over
   // (i', nodal / quadrature k), direction k over (i', j').
-  auto pencil_addr = [&](int t, int NA, int NB, int sa, int sb) -> ldsp_t {
-    const int T = 3 * NA * NB;
-    const int el = t / T, tt = t % T, c = tt / (NA * NB), pen = tt % (NA * NB), ia = pen % NA, ib = pen / NA;
+  auto pencil_addr = [&](int t, int NA, int NB, int sa, int sb, int blk) -> ldsp_t {
+    const int n = NA * NB;
+    const int bl = blk ? t / blk : t / n, pen = blk ? min(t % blk, n - 1) : t % n;      // (idle lanes of a block: any address in it)
+    const int el = min(bl / 3, E - 1), c = bl % 3, ia = pen % NA, ib = pen / NA;
     return lds0 + (el * SE + c * SC + (ia * sa + ib * sb) / 8);
   };
+  // virtual lane of pencil_ok for a blocked family (see pencil_blk): real block <=> vlane + 64 r < 0
+  auto pencil_vlane = [&](int n, int blk) -> int { return blk == 0 ? lane : ((lane % blk) < n ? blk * (lane / blk) - blk * 3 * E : (1 << 24)); };
   constexpr int T_IP = 3 * P * P, T_IQ = 3 * Q * Q, T_JP = 3 * Q * P, T_JQ = 3 * Q * Q, T_K = 3 * Q * Q;
+  constexpr int B_PP = pencil_blk(P * P, E), B_QP = pencil_blk(Q * P, E), B_QQ = pencil_blk(Q * Q, E);
   constexpr int R_IP = (E * T_IP + 63) / 64, R_IQ = (E * T_IQ + 63) / 64, R_JP = (E * T_JP + 63) / 64,
                 R_JQ = (E * T_JQ + 63) / 64, R_K = (E * T_K + 63) / 64;
+  // what the passes are handed as (lane, ntask): the real ones (flat) or (virtual lane, 0) (blocked)
+  constexpr int N_IP = B_PP ? 0 : E * T_IP, N_JP = B_QP ? 0 : E * T_JP, N_QQ = B_QQ ? 0 : E * T_IQ;
+  const int lPP = pencil_vlane(P * P, B_PP), lQP = pencil_vlane(Q * P, B_QP), lQQ = pencil_vlane(Q * Q, B_QQ);
+  // the k passes and the two-input j pass are written out below: a blocked one sits in ONE exec region (lQQ < 0), all its rounds unconditional
+  constexpr bool PIN_ALL = !B_QQ || CPS_BLOCKED_IDLE_MATH;
+  const int lQQi = PIN_ALL ? lQQ : 0;
+  constexpr int N_QQi = PIN_ALL ? N_QQ : 64 * R_K;
   ldsp_t aIP[R_IP], aIQ[R_IQ], aJP[R_JP], aJQ[R_JQ], aK[R_K];
 #pragma unroll
-  for (int r = 0; r < R_IP; r++) aIP[r] = pencil_addr(lane + 64 * r, P, P, BJ, BK);
+  for (int r = 0; r < R_IP; r++) aIP[r] = pencil_addr(lane + 64 * r, P, P, BJ, BK, B_PP);
 #pragma unroll
-  for (int r = 0; r < R_IQ; r++) aIQ[r] = pencil_addr(lane + 64 * r, Q, Q, BJ, BK);
+  for (int r = 0; r < R_IQ; r++) aIQ[r] = pencil_addr(lane + 64 * r, Q, Q, BJ, BK, B_QQ);
 #pragma unroll
-  for (int r = 0; r < R_JP; r++) aJP[r] = pencil_addr(lane + 64 * r, Q, P, BI, BK);
+  for (int r = 0; r < R_JP; r++) aJP[r] = pencil_addr(lane + 64 * r, Q, P, BI, BK, B_QP);
 #pragma unroll
-  for (int r = 0; r < R_JQ; r++) aJQ[r] = pencil_addr(lane + 64 * r, Q, Q, BI, BK);
+  for (int r = 0; r < R_JQ; r++) aJQ[r] = pencil_addr(lane + 64 * r, Q, Q, BI, BK, B_QQ);
 #pragma unroll
-  for (int r = 0; r < R_K; r++) aK[r] = pencil_addr(lane + 64 * r, Q, Q, BI, BJ);
+  for (int r = 0; r < R_K; r++) aK[r] = pencil_addr(lane + 64 * r, Q, Q, BI, BJ, B_QQ);
   // point owners: q = lane + 64 r over (element, k, j, i); node owners likewise over P^3
   ldsp_t aPt[RQ], aNd[RN];
 #pragma unroll
@@ -474,32 +519,32 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     // ---- B: nodes -> points, in place -----------------------------------------------------------------
     set_prio<CPS_PRIO_PASS>();
     CPS_PH(1);
-    pencil_pass<P, Q, P, false, BI, oA, oA, +1, EO>(tBf, aIP, lane, E * T_IP);   // F1: along i at nodal (j, k)
+    pencil_pass<P, Q, P, false, BI, oA, oA, +1, EO>(tBf, aIP, lPP, N_IP);   // F1: along i at nodal (j, k)
     CPS_PH(2);
-    pencil_pass<P, Q, P, false, BJ, oA, oA, +1, EO>(tBf, aJP, lane, E * T_JP);   // F2: along j at (i', nodal k)
+    pencil_pass<P, Q, P, false, BJ, oA, oA, +1, EO>(tBf, aJP, lQP, N_JP);   // F2: along j at (i', nodal k)
     CPS_PH(3);
-    {  // F3: along k at (i', j'): U -> A in place and dU/dz -> BZ (grad1d on the nodal values), one
+    if (PIN_ALL || lQQ < 0) {  // F3: along k at (i', j'): U -> A in place and dU/dz -> BZ (grad1d on the nodal values), one
        // table at a time (both = 100 SGPRs = SGPR spills)
       double in[R_K][P];
 #pragma unroll
       for (int r = 0; r < R_K; r++)
-        if (pencil_ok(lane, r, E * T_K)) pencil_ld<P, BK, oA>(aK[r], in[r]);
+        if (pencil_ok_ld(lQQi, r, N_QQi)) pencil_ld<P, BK, oA>(aK[r], in[r]);
       if constexpr (table_splits<Q, P, EO>() == 1) {
         const ktab_t tB = ktab_fresh(tBf);
 #pragma unroll
         for (int r = 0; r < R_K; r++)
-          if (pencil_ok(lane, r, E * T_K)) {
+          if (pencil_ok_ld(lQQi, r, N_QQi)) {
             double out[Q] = {};
             mac_sel<Q, P, P, false, +1, EO>(tB, in[r], out);
-            pencil_st<Q, BK, oA>(aK[r], out);
+            if (pencil_ok(lQQi, r, N_QQi)) pencil_st<Q, BK, oA>(aK[r], out);
           }
         const ktab_t tG = ktab_fresh(tGf);
 #pragma unroll
         for (int r = 0; r < R_K; r++)
-          if (pencil_ok(lane, r, E * T_K)) {
+          if (pencil_ok_ld(lQQi, r, N_QQi)) {
             double dz[Q] = {};
             mac_sel<Q, P, P, false, -1, EO>(tG, in[r], dz);
-            pencil_st<Q, BK, oBZ>(aK[r], dz);
+            if (pencil_ok(lQQi, r, N_QQi)) pencil_st<Q, BK, oBZ>(aK[r], dz);
           }
       } else {  // large tables: row blocks (mac_rounds), one product after the other
         double out[R_K][Q];
@@ -509,10 +554,10 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
           for (int r = 0; r < R_K; r++)
 #pragma unroll
             for (int o = 0; o < Q; o++) out[r][o] = 0.;
-          mac_rounds<Q, P, P, false, R_K>(pass == 0 ? ktB : ktG, in, out, lane, E * T_K);
+          mac_rounds<Q, P, P, false, R_K>(pass == 0 ? ktB : ktG, in, out, lQQi, N_QQi);
 #pragma unroll
           for (int r = 0; r < R_K; r++)
-            if (pencil_ok(lane, r, E * T_K)) {
+            if (pencil_ok(lQQi, r, N_QQi)) {
               if (pass == 0) pencil_st<Q, BK, oA>(aK[r], out[r]);
               else pencil_st<Q, BK, oBZ>(aK[r], out[r]);
             }
@@ -521,9 +566,9 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     }
     // ---- collocated gradient on the quadrature points -----------------------------------------------------
     CPS_PH(4);
-    pencil_pass<Q, Q, Q, false, BI, oA, oBX, -1, EO>(tDf, aIQ, lane, E * T_IQ);  // F4: d/dx: A -> BX
+    pencil_pass<Q, Q, Q, false, BI, oA, oBX, -1, EO>(tDf, aIQ, lQQ, N_QQ);  // F4: d/dx: A -> BX
     CPS_PH(5);
-    pencil_pass<Q, Q, Q, false, BJ, oA, oA, -1, EO>(tDf, aJQ, lane, E * T_JQ);   // F5: d/dy: A -> A in place
+    pencil_pass<Q, Q, Q, false, BJ, oA, oA, -1, EO>(tDf, aJQ, lQQ, N_QQ);   // F5: d/dy: A -> A in place
     CPS_PH(6);
 
     set_prio<CPS_PRIO_PHYS>();
@@ -651,23 +696,23 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     // ---- gradient^T --------------------------------------------------------------------------------------
     set_prio<CPS_PRIO_PASS_B>();
     CPS_PH(16);
-    pencil_pass<Q, Q, Q, true, BI, oBX, oBX, -1, EO>(tDt, aIQ, lane, E * T_IQ);  // B1: W1 = Dx^T g0, BX in place
+    pencil_pass<Q, Q, Q, true, BI, oBX, oBX, -1, EO>(tDt, aIQ, lQQ, N_QQ);  // B1: W1 = Dx^T g0, BX in place
     CPS_PH(17);
-    {  // B2: W2 = W1 + Dy^T g1, A in place.  Two inputs per task: software-pipelined over the rounds
+    if (PIN_ALL || lQQ < 0) {  // B2: W2 = W1 + Dy^T g1, A in place.  Two inputs per task: software-pipelined over the rounds
        // (two rounds of inputs live instead of all)
       if constexpr (table_splits<Q, Q, EO>() == 1) {
         const ktab_t tD = ktab_fresh(tDt);
         double in[2][Q], acc[2][Q];
-        if (pencil_ok(lane, 0, E * T_JQ)) { pencil_ld<Q, BJ, oA>(aJQ[0], in[0]); pencil_ld<Q, BJ, oBX>(aJQ[0], acc[0]); }
+        if (pencil_ok_ld(lQQi, 0, N_QQi)) { pencil_ld<Q, BJ, oA>(aJQ[0], in[0]); pencil_ld<Q, BJ, oBX>(aJQ[0], acc[0]); }
 #pragma unroll
         for (int r = 0; r < R_JQ; r++) {
-          if (r + 1 < R_JQ && pencil_ok(lane, r + 1, E * T_JQ)) {
+          if (r + 1 < R_JQ && pencil_ok_ld(lQQi, r + 1, N_QQi)) {
             pencil_ld<Q, BJ, oA>(aJQ[r + 1], in[(r + 1) & 1]);
             pencil_ld<Q, BJ, oBX>(aJQ[r + 1], acc[(r + 1) & 1]);
           }
-          if (pencil_ok(lane, r, E * T_JQ)) {
+          if (pencil_ok_ld(lQQi, r, N_QQi)) {
             mac_sel<Q, Q, Q, true, -1, EO>(tD, in[r & 1], acc[r & 1]);
-            pencil_st<Q, BJ, oA>(aJQ[r], acc[r & 1]);
+            if (pencil_ok(lQQi, r, N_QQi)) pencil_st<Q, BJ, oA>(aJQ[r], acc[r & 1]);
           }
         }
       } else {  // large tables: all rounds live, the table in row blocks
@@ -676,16 +721,16 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
         for (int r = 0; r < R_JQ; r++) {
 #pragma unroll
           for (int o = 0; o < Q; o++) acc[r][o] = 0.;
-          if (pencil_ok(lane, r, E * T_JQ)) { pencil_ld<Q, BJ, oA>(aJQ[r], in[r]); pencil_ld<Q, BJ, oBX>(aJQ[r], acc[r]); }
+          if (pencil_ok_ld(lQQi, r, N_QQi)) { pencil_ld<Q, BJ, oA>(aJQ[r], in[r]); pencil_ld<Q, BJ, oBX>(aJQ[r], acc[r]); }
         }
-        mac_rounds<Q, Q, Q, true, R_JQ>(ktD, in, acc, lane, E * T_JQ);
+        mac_rounds<Q, Q, Q, true, R_JQ>(ktD, in, acc, lQQi, N_QQi);
 #pragma unroll
         for (int r = 0; r < R_JQ; r++)
-          if (pencil_ok(lane, r, E * T_JQ)) pencil_st<Q, BJ, oA>(aJQ[r], acc[r]);
+          if (pencil_ok(lQQi, r, N_QQi)) pencil_st<Q, BJ, oA>(aJQ[r], acc[r]);
       }
     }
     CPS_PH(18);
-    {  // B3: along k: A[k<P] = B^T W2 + G^T g2, in two sweeps so that one coefficient table is live at a time
+    if (PIN_ALL || lQQ < 0) {  // B3: along k: A[k<P] = B^T W2 + G^T g2, in two sweeps so that one coefficient table is live at a time
       double out[R_K][P];
       if constexpr (table_splits<P, Q, EO>() > 1) {  // large tables: all rounds live, the tables in row blocks
         double in[R_K][Q];
@@ -693,40 +738,40 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
         for (int r = 0; r < R_K; r++) {
 #pragma unroll
           for (int m = 0; m < P; m++) out[r][m] = 0.;
-          if (pencil_ok(lane, r, E * T_K)) pencil_ld<Q, BK, oA>(aK[r], in[r]);
+          if (pencil_ok_ld(lQQi, r, N_QQi)) pencil_ld<Q, BK, oA>(aK[r], in[r]);
         }
-        mac_rounds<P, Q, P, true, R_K>(ktB, in, out, lane, E * T_K);
+        mac_rounds<P, Q, P, true, R_K>(ktB, in, out, lQQi, N_QQi);
 #pragma unroll
         for (int r = 0; r < R_K; r++)
-          if (pencil_ok(lane, r, E * T_K)) pencil_ld<Q, BK, oBZ>(aK[r], in[r]);
-        mac_rounds<P, Q, P, true, R_K, true>(ktG, in, out, lane, E * T_K);
+          if (pencil_ok_ld(lQQi, r, N_QQi)) pencil_ld<Q, BK, oBZ>(aK[r], in[r]);
+        mac_rounds<P, Q, P, true, R_K, true>(ktG, in, out, lQQi, N_QQi);
 #pragma unroll
         for (int r = 0; r < R_K; r++)
-          if (pencil_ok(lane, r, E * T_K)) pencil_st<P, BK, oA>(aK[r], out[r]);
+          if (pencil_ok(lQQi, r, N_QQi)) pencil_st<P, BK, oA>(aK[r], out[r]);
       } else {
       {
         const ktab_t tB = ktab_fresh(tBt);
         double in[2][Q];
-        if (pencil_ok(lane, 0, E * T_K)) pencil_ld<Q, BK, oA>(aK[0], in[0]);
+        if (pencil_ok_ld(lQQi, 0, N_QQi)) pencil_ld<Q, BK, oA>(aK[0], in[0]);
 #pragma unroll
         for (int r = 0; r < R_K; r++) {
-          if (r + 1 < R_K && pencil_ok(lane, r + 1, E * T_K)) pencil_ld<Q, BK, oA>(aK[r + 1], in[(r + 1) & 1]);
+          if (r + 1 < R_K && pencil_ok_ld(lQQi, r + 1, N_QQi)) pencil_ld<Q, BK, oA>(aK[r + 1], in[(r + 1) & 1]);
 #pragma unroll
           for (int m = 0; m < P; m++) out[r][m] = 0.;
-          if (pencil_ok(lane, r, E * T_K)) mac_sel<P, Q, P, true, +1, EO>(tB, in[r & 1], out[r]);
+          if (pencil_ok_ld(lQQi, r, N_QQi)) mac_sel<P, Q, P, true, +1, EO>(tB, in[r & 1], out[r]);
         }
       }
       {
         // not before the first sweep has used its table: both at once do not fit the SGPR file (they were spilled)
         const ktab_t tG = ktab_fresh_after<R_K * P>(tGt, &out[0][0]);
         double in2[2][Q];
-        if (pencil_ok(lane, 0, E * T_K)) pencil_ld<Q, BK, oBZ>(aK[0], in2[0]);
+        if (pencil_ok_ld(lQQi, 0, N_QQi)) pencil_ld<Q, BK, oBZ>(aK[0], in2[0]);
 #pragma unroll
         for (int r = 0; r < R_K; r++) {
-          if (r + 1 < R_K && pencil_ok(lane, r + 1, E * T_K)) pencil_ld<Q, BK, oBZ>(aK[r + 1], in2[(r + 1) & 1]);
-          if (pencil_ok(lane, r, E * T_K)) {
+          if (r + 1 < R_K && pencil_ok_ld(lQQi, r + 1, N_QQi)) pencil_ld<Q, BK, oBZ>(aK[r + 1], in2[(r + 1) & 1]);
+          if (pencil_ok_ld(lQQi, r, N_QQi)) {
             mac_sel<P, Q, P, true, -1, EO>(tG, in2[r & 1], out[r]);
-            pencil_st<P, BK, oA>(aK[r], out[r]);
+            if (pencil_ok(lQQi, r, N_QQi)) pencil_st<P, BK, oA>(aK[r], out[r]);
           }
         }
       }
@@ -737,9 +782,9 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
                           // are not live across the physics and the register-hungry passes; B4, B5, the
                           // final store and the next gather's address work hide most of its latency
     // ---- B^T: points -> nodes ---------------------------------------------------------------------------
-    pencil_pass<Q, P, P, true, BJ, oA, oA, +1, EO>(tBt, aJP, lane, E * T_JP);    // B4: along j
+    pencil_pass<Q, P, P, true, BJ, oA, oA, +1, EO>(tBt, aJP, lQP, N_JP);    // B4: along j
     CPS_PH(20);
-    pencil_pass<Q, P, P, true, BI, oA, oA, +1, EO>(tBt, aIP, lane, E * T_IP);    // B5: along i
+    pencil_pass<Q, P, P, true, BI, oA, oA, +1, EO>(tBt, aIP, lPP, N_IP);    // B5: along i
     CPS_PH(21);
     // ---- final: node owners -> y (element-interior nodes) / shell E-vector (plain coalesced stores) ------------------
     set_prio<CPS_PRIO_TOP>();

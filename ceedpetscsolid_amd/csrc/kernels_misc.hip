@@ -108,7 +108,9 @@ hipError_t launch_geo_affine(const double *geo, double *aff, int nelem, int *n_n
   return hipGetLastError();
 }
 
-__global__ void k_geo_swept(const double *geo, double *sw, int nelem, int *count) {
+// axis < 0: COUNT -- count[s]++ for EVERY direction s the element is swept along (an axis-aligned brick qualifies for all three), count[3]++
+// if for none; axis >= 0: FILL sw[] for that direction (the host has found every element to qualify for it).
+__global__ void k_geo_swept(const double *geo, double *sw, int nelem, int *count, int axis) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nelem) return;
   const double *g = geo + (size_t)e * GEO_NCOEF;   // [c][m], m: 0 xi, 1 eta, 2 zeta, 3 xi eta, 4 xi zeta, 5 eta zeta, 6 xi eta zeta
@@ -130,10 +132,11 @@ __global__ void k_geo_swept(const double *geo, double *sw, int nelem, int *count
 #pragma unroll
     for (int c = 0; c < 2; c++)
       ok = ok && fabs(g[c * 7 + s]) <= tol && fabs(g[c * 7 + p0]) <= tol && fabs(g[c * 7 + p1]) <= tol && fabs(g[c * 7 + 6]) <= tol;
+    if (ok && axis < 0) atomicAdd(count + s, 1);
     if (ok && found == 3) found = s;
   }
-  atomicAdd(count + found, 1);
-  if (found == 3) return;
+  if (axis < 0) { if (found == 3) atomicAdd(count + 3, 1); return; }
+  found = axis;
   const int a = found == 0 ? 1 : 0, b = found == 2 ? 1 : 2, ab = (a == 0 && b == 1) ? 3 : ((a == 0 && b == 2) ? 4 : 5);
   double *o = sw + (size_t)e * GEO_NSWEPT;
   o[0] = g[a]; o[1] = g[b]; o[2] = g[ab];
@@ -142,9 +145,9 @@ __global__ void k_geo_swept(const double *geo, double *sw, int nelem, int *count
   o[6] = found == 1 ? -zs : zs;
   o[7] = 1. / zs;
 }
-hipError_t launch_geo_swept(const double *geo, double *sw, int nelem, int *count, hipStream_t s) {
+hipError_t launch_geo_swept(const double *geo, double *sw, int nelem, int *count, int axis, hipStream_t s) {
   if (nelem <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_geo_swept, dim3((unsigned)((nelem + 255) / 256)), dim3(256), 0, s, geo, sw, nelem, count);
+  hipLaunchKernelGGL(k_geo_swept, dim3((unsigned)((nelem + 255) / 256)), dim3(256), 0, s, geo, sw, nelem, count, axis);
   return hipGetLastError();
 }
 

@@ -451,6 +451,59 @@ def reorder_elements_first(mesh: HexMesh, first: np.ndarray) -> HexMesh:
     return HexMesh(mesh.coords, mesh.cells[perm], ss, vertex_gid=mesh.vertex_gid, name=mesh.name + "[reordered]")
 
 
+def hex_rotations():
+    """The 24 orientation-preserving relabellings of a hexahedron's local axes: (perm, sign) with new axis d = sign[d] x old axis
+    perm[d] and det = +1; for each the old tensor-order vertex index of every new one and the old local face of every new one."""
+    import itertools
+    out = []
+    for perm in itertools.permutations(range(3)):
+        par = 1 if perm in ((0, 1, 2), (1, 2, 0), (2, 0, 1)) else -1
+        for sg in itertools.product((1, -1), repeat=3):
+            if par * sg[0] * sg[1] * sg[2] != 1:
+                continue
+            vmap = np.zeros(8, dtype=np.int64)
+            for c in range(8):
+                old = 0
+                for d in range(3):
+                    b = (c >> d) & 1
+                    old |= (b if sg[d] > 0 else 1 - b) << perm[d]
+                vmap[c] = old
+            fmap = np.array([2 * perm[f // 2] + ((f % 2) if sg[f // 2] > 0 else 1 - (f % 2)) for f in range(6)], dtype=np.int64)
+            out.append((vmap, fmap))
+    return out
+
+
+def scramble_mesh(mesh: HexMesh, seed: int = 0, order: bool = True, orient: bool = False) -> HexMesh:
+    """The same mesh as an unstructured generator might hand it over: ``order`` -- elements and vertices in random order (no
+    locality left in either numbering); ``orient`` -- every element's local axes relabelled by a random one of the 24 rotations
+    (neighbours no longer agree on which local direction is which: no common sweep direction, no aligned faces).  Geometry, side
+    sets and the discrete problem are unchanged."""
+    rng = np.random.default_rng(seed)
+    cells, coords, gid = mesh.cells.copy(), mesh.coords, mesh.gid()
+    ss = {sid: np.array(fs, dtype=np.int64).reshape(-1, 2).copy() for sid, fs in mesh.side_sets.items()}
+    if orient:
+        rots = hex_rotations()
+        which = rng.integers(0, len(rots), mesh.nelem)
+        vm = np.stack([r[0] for r in rots])[which]                  # (ne, 8): old vertex slot of every new slot
+        cells = np.take_along_axis(cells, vm, axis=1)
+        inv_f = np.stack([np.argsort(r[1]) for r in rots])          # old face -> new face
+        for sid, fs in ss.items():
+            if len(fs):
+                fs[:, 1] = inv_f[which[fs[:, 0]], fs[:, 1]]
+    if order:
+        vperm = rng.permutation(mesh.nvert)                          # new vertex v is old vertex vperm[v]
+        vinv = np.empty_like(vperm); vinv[vperm] = np.arange(vperm.size)
+        coords, gid, cells = coords[vperm], gid[vperm], vinv[cells]
+        eperm = rng.permutation(mesh.nelem)
+        einv = np.empty_like(eperm); einv[eperm] = np.arange(eperm.size)
+        cells = cells[eperm]
+        for sid, fs in ss.items():
+            if len(fs):
+                fs[:, 0] = einv[fs[:, 0]]
+    return HexMesh(coords, cells.astype(np.int64), ss, vertex_gid=gid if (order or mesh.vertex_gid is not None) else None,
+                   name=mesh.name + "[scrambled" + (" order" if order else "") + (" orientation" if orient else "") + "]")
+
+
 def key_bytes(keys: np.ndarray) -> np.ndarray:
     """Topological keys as fixed-size byte strings (hashable / sortable across ranks)."""
     k = np.ascontiguousarray(keys, dtype=np.int64)

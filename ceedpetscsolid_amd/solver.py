@@ -79,12 +79,19 @@ class NewtonPMG:
                  halo=None, rccl="auto", lead_elements: int = 0, smooth_its: int = 3, coarse_rtol: float = 1e-3, coarse_maxit: int = 200,
                  coarse: str = "cg", coarse_cheb_its: int = 40, coarse_cheb_ratio: float = 100.0, graph: bool = False,
                  amg_smooth_its: int = 3, amg_smooth_ratio: float = 10.0, amg_max_coarse_dofs: int = 1500, amg_coarse_cycles: int = 1,
-                 ksp_rtol: float = 1e-10, snes_rtol: float = 1e-8, snes_maxit: int = 50, verbose: bool = False):
+                 ksp_rtol: float = 1e-10, snes_rtol: float = 1e-8, snes_maxit: int = 50, verbose: bool = False,
+                 line_search: str = "cp"):
         """``clamp``: {side_set_id: dict(translate=(..), axis=(..), angle_over_pi=..)} as
         -bc_clamp_<id>_translate / _rotate (cloptions.c:86-131); ids present in the problem's Dirichlet
         set but absent here are held at zero."""
         self.p, self.ceed, self.L = prob, prob.ceed, prob.ceed.L
         self.clamp, self.mms, self.halo = clamp or {}, mms, halo
+        # "cp": critical-point secant search, up to three secant steps, a step outside (0, 10] ends the search (this build's default);
+        # "cp-petsc": SNESLINESEARCHCP as PETSc runs it by default (elasticity.c:596-601 sets the type and nothing else): ONE secant
+        # step from (0, 1), the result CLAMPED to [1e-12, 1e8], never a rejection; "full": lambda = 1 (SNESLINESEARCHBASIC)
+        if line_search not in ("cp", "cp-petsc", "full"):
+            raise ValueError(f"line_search {line_search!r}")
+        self.line_search = line_search
         self.smooth_its, self.coarse_rtol, self.coarse_maxit = smooth_its, coarse_rtol, coarse_maxit
         # coarse solver: "cg" (Jacobi-PCG to coarse_rtol: accurate, but two host-synchronised dots per
         # iteration) or "chebyshev" (fixed polynomial over [emax/ratio, 1.1 emax]: no reductions, no host
@@ -601,11 +608,12 @@ class NewtonPMG:
         return its
 
     # ---- Newton with load increments ---------------------------------------------------------------
-    def solve(self, num_increments: int = 10) -> SolveStats:
+    def solve(self, num_increments: int = 10, stop_after: Optional[int] = None) -> SolveStats:
+        """``stop_after``: run only the first so many of the ``num_increments`` load increments (load studies)."""
         st = self.stats
         t0 = time.perf_counter()
         self.U.set_value(0.0)
-        for inc in range(1, num_increments + 1):
+        for inc in range(1, (stop_after or num_increments) + 1):
             load = inc / num_increments
             self.load = load
             self._set(self.bcv, self.bc_values(load))
@@ -625,13 +633,17 @@ class NewtonPMG:
                 # critical-point line search (SNESLINESEARCHCP): secant on phi(l) = dU . R(U + l dU)
                 lam, lam_old = 1.0, 0.0
                 phi_old = self.dot(self.dU, self.R, True)
-                for _ in range(3):
+                for _ in range(0 if self.line_search == "full" else (1 if self.line_search == "cp-petsc" else 3)):
                     self.copy(self.Utry, self.U); self.axpby(self.Utry, lam, self.dU, 1.0)
                     self.residual(self.Utry, self.Rtry)
                     phi = self.dot(self.dU, self.Rtry, True)
                     if abs(phi) <= 1e-8 * abs(phi_old) or abs(phi - phi_old) < 1e-300:
                         break
                     lam_new = lam - phi * (lam - lam_old) / (phi - phi_old)
+                    if self.line_search == "cp-petsc":
+                        if np.isfinite(lam_new):
+                            lam = min(max(lam_new, 1e-12), 1e8)
+                        break
                     if not np.isfinite(lam_new) or abs(lam_new - lam) < 1e-8 or lam_new <= 0.0 or lam_new > 10.0:
                         break
                     lam_old, phi_old, lam = lam, phi, lam_new

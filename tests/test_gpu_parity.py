@@ -444,6 +444,87 @@ def _one_call_routes(ceed, mesh, vw, lead, degree, bc, record):
     return last
 
 
+def test_split_phase_exchange_refuses_a_halo_outside_the_priority_rows(product_lib):
+    """The split-phase one-call forms (CEED_MI355X_OVL_MODE 1 / 2) add the arrivals in the launch that overwrites the non-priority
+    rows and start the exchange when only the priority rows are complete: a halo entry on a node outside the operator's priority
+    set would be exchanged half-summed and overwritten.  Checked once per (operator, halo): an error, not a wrong sum."""
+    import ctypes as C
+    from ceedpetscsolid_amd.halo import HaloExchange, RcclHalo, interface_elements, part_cylinder, virtual_world
+    from ceedpetscsolid_amd.harness import SolidApp
+    from ceedpetscsolid_amd.mesh import reorder_elements_first
+    ceed = _ceed_with_env(product_lib, "CEED_MI355X_OVL_MODE", "1")
+    part = lambda r: part_cylinder(r, 4, 3, 12, 8)
+    mesh = part(1)
+    vw = virtual_world(1, 4, mesh, part, 2)
+    lead = interface_elements(mesh, virtual=vw)
+    mesh = reorder_elements_first(mesh, lead)
+    app = SolidApp(ceed, mesh, 2, "hyperFS", nu=0.3, E=1.0, bc_sides=[], multigrid="none")
+    dm = app.dofmaps[app.fine]
+    halo = HaloExchange(mesh, dm, device="cuda", virtual=vw)
+    good = RcclHalo(ceed, halo, emulate_self=True)
+    n = app.lsize()
+    X, Y = ceed.vector(n), ceed.vector(n)
+    X.set_array(smooth_displacement(dm.node_coords, 0.05)); app.form_residual(X, Y)
+    op = app.opJacob[app.fine]
+    op.set_overlap_split(int(lead.sum()), halo.interface_dof_mask())
+    op.apply_with_halo(X, Y, good)                      # the matching halo passes the check
+    # a halo with one entry on an interior (non-priority) node
+    prio = halo.interface_dof_mask()
+    free = np.flatnonzero(prio == 0); stray = int(free[len(free) // 2])
+    idx = np.array([stray], dtype=np.int32)
+    h = C.c_void_p()
+    ceed.L.chk(ceed.L.lib.CeedXHaloCreate(ceed.h, 1, (C.c_int * 1)(0), (C.c_int * 1)(1), (C.POINTER(C.c_int) * 1)(idx.ctypes.data_as(C.POINTER(C.c_int))), C.byref(h)))
+    with pytest.raises(cd.CeedError, match="not on a priority node"):
+        op.apply_with_halo(X, Y, h)
+    op.apply_with_halo(X, Y, good)                      # still usable
+    ceed.L.chk(ceed.L.lib.CeedXHaloDestroy(C.byref(h)))
+    good.destroy()
+
+
+def test_recorded_graph_refuses_to_replay_on_dropped_provenance(product_lib):
+    """A recorded apply holds the provenance buffers of its passive vectors in its kernel arguments: the derived state beside grad u
+    (HyperFSdF from Q = 6 on) and the element-map coefficients beside qdata.  A write to such a vector outside the operators drops the
+    provenance -- an eager apply then reads the array itself, a replay would silently go on reading the old buffer.  CeedXGraphLaunch
+    refuses instead; the buffers themselves are retired, never freed under a live graph."""
+    ceed = cd.Ceed(product_lib, "/gpu/hip/mi355x")
+    mesh = distorted_box(2, 2, 2)
+    p = SolidProblem(ceed, mesh, 6, "hyperFS", nu=0.3, E=1.0, bc_sides=[1], multigrid="none")
+    n = p.lsize()
+    X, Y, Yg = ceed.vector(n), ceed.vector(n), ceed.vector(n)
+    u = p.smooth_state(0.1)
+    X.set_array(u); p.form_residual(X, Y)
+    X.set_array(np.random.default_rng(2).uniform(-1, 1, n)); X.device_pointer()
+    p.apply_jacobian(p.fine, X, Y)
+    assert "derived" in p.levels[p.fine].opJacob.kernel_name
+    g = ceed.capture(lambda: p.apply_jacobian(p.fine, X, Yg))
+    g.launch()
+    assert np.array_equal(Yg.to_numpy(), Y.to_numpy())
+    # the state overwritten by the caller: the eager apply falls back to the stored grad u, the replay is refused
+    gu = p.gradu.to_numpy()
+    p.gradu.set_array(gu)
+    with pytest.raises(cd.CeedError, match="record the graph again"):
+        g.launch()
+    p.apply_jacobian(p.fine, X, Y)
+    assert "derived" not in p.levels[p.fine].opJacob.kernel_name
+    assert rel_err(Y.to_numpy(), Yg.to_numpy()) < 1e-12
+    # the residual evaluated again: the derived state is valid again in the SAME buffer -> the old recording may replay
+    Xu = ceed.vector(n).set_array(u)
+    p.form_residual(Xu, Y)
+    Yg.set_value(0.0)
+    g.launch()
+    p.apply_jacobian(p.fine, X, Y)
+    assert np.array_equal(Yg.to_numpy(), Y.to_numpy())
+    # qdata overwritten by the caller: the geometry is read from the array from now on, the recording is stale for good
+    p.qdata.set_array(p.qdata.to_numpy())
+    with pytest.raises(cd.CeedError, match="record the graph again"):
+        g.launch()
+    p.apply_jacobian(p.fine, X, Y)
+    assert "qdata read" in p.levels[p.fine].opJacob.kernel_name
+    assert rel_err(Y.to_numpy(), Yg.to_numpy()) < 1e-12
+    g.destroy()
+    p.destroy()
+
+
 def test_halo_exchange_through_rccl_on_one_gpu(product_lib):
     """CeedXHalo* end to end on ONE GPU: a one-rank RCCL communicator whose only neighbour is the rank itself (ncclSend /
     ncclRecv to self inside one group is legal), so the library's pack kernel, RCCL's send and receive on the
@@ -642,6 +723,80 @@ def test_pipelined_assembly_equals_serial_assembly_bitwise(product_lib, mk, degr
             g.launch()
             assert np.array_equal(Yg.to_numpy(), vecs[1][1].to_numpy())
         g.destroy()
+
+
+def _tangent_properties(probs, vecs, levels, rng, n_of, bitwise_label):
+    """Size-independent properties of the Jacobian apply on every level in `levels`, for the problems in `probs` (the first is the
+    one under test, the others must agree with it BITWISE): symmetry of the tangent, linearity, rigid translations in the null
+    space (no BCs)."""
+    for lv in levels:
+        n = n_of(lv)
+        v, w = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+
+        def J(z):
+            outs = []
+            for (X, Y), p in zip(vecs[lv], probs):
+                X.set_array(z); p.apply_jacobian(lv, X, Y); outs.append(Y.to_numpy())
+            for o in outs[1:]:
+                assert np.array_equal(o, outs[0]), f"{bitwise_label}, level {lv}"
+            return outs[0]
+        jv, jw = J(v), J(w)
+        assert abs(v @ jw - w @ jv) < 1e-11 * abs(v @ jw), lv
+        assert rel_err(J(2.0 * v - 0.5 * w), 2.0 * jv - 0.5 * jw) < 1e-12, lv
+        t = np.tile([0.3, -1.0, 2.0], n // 3)
+        assert np.abs(J(t)).max() < 1e-11 * np.abs(jv).max(), lv
+
+
+def test_full_size_properties_config5_whole_box(product_lib):
+    """The WHOLE of BASELINE config 5 on one GPU -- box 64^3, degree 6, hyperFS: 262 144 hexes, 170 M dofs, the apply pipelined in
+    15 segments over two streams (benchmarked in round 3, never checked).  Far beyond the oracle, so: the
+    pipelined apply BITWISE equal to the serial form (k_assemble after one fused launch) on the same inputs, and the
+    size-independent properties of the tangent (symmetry, linearity, rigid-translation null space)."""
+    mesh = box_mesh(64, 64, 64)
+    pipe = cd.Ceed(product_lib, "/gpu/hip/mi355x")
+    serial = _ceed_with_env(product_lib, "CEED_MI355X_ASSEMBLE", "serial")
+    probs = [SolidProblem(c, mesh, 6, "hyperFS", nu=0.3, E=1.0, multigrid="none") for c in (pipe, serial)]
+    n = probs[0].lsize()
+    assert n == 3 * 385 ** 3
+    vecs = {0: [(c.vector(n), c.vector(n)) for c in (pipe, serial)]}
+    u = probs[0].smooth_state(0.1)
+    res = []
+    for (X, Y), p in zip(vecs[0], probs):
+        X.set_array(u); p.form_residual(X, Y); res.append(Y.to_numpy())
+    assert np.array_equal(res[0], res[1])
+    del res
+    _tangent_properties(probs, vecs, [0], np.random.default_rng(17), lambda lv: n, "pipelined (15 segments) vs serial")
+    info = [p.levels[0].opJacob.launch_info() for p in probs]
+    assert info[0]["segments"] >= 12 and info[0]["streams"] == 2 and info[1]["segments"] == 1, info
+    for p in probs:
+        p.destroy()
+
+
+def test_properties_unstructured_cylinder_all_levels_pipelined(product_lib):
+    """The reference's cylinder8_44928e_2ss_us (CUBIT element order) at degree 4 with its multigrid ladder (levels of degree
+    1, 2, 4, all on the fine quadrature): every level's Jacobian apply forced into the pipelined form (44 928 hexes are
+    10.97 rounds of the waves: two segments with a non-trivial remainder in the first) against the serial form, BITWISE, plus the
+    tangent's properties on every level."""
+    mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_44928e_2ss_us.npz"))
+    os.environ["CEED_MI355X_PIPE_MIN_TOTAL"] = "0"
+    try:
+        pipe = cd.Ceed(product_lib, "/gpu/hip/mi355x")
+    finally:
+        os.environ.pop("CEED_MI355X_PIPE_MIN_TOTAL", None)
+    serial = _ceed_with_env(product_lib, "CEED_MI355X_ASSEMBLE", "serial")
+    probs = [SolidProblem(c, mesh, 4, "hyperFS", nu=0.3, E=1.0) for c in (pipe, serial)]
+    nl = len(probs[0].levels)
+    assert [lv.degree for lv in probs[0].levels] == [1, 2, 4]
+    vecs = {lv: [(c.vector(probs[0].lsize(lv)), c.vector(probs[0].lsize(lv))) for c in (pipe, serial)] for lv in range(nl)}
+    u = probs[0].smooth_state(0.1)
+    for (X, Y), p in zip(vecs[nl - 1], probs):
+        X.set_array(u); p.form_residual(X, Y)
+    _tangent_properties(probs, vecs, range(nl), np.random.default_rng(23), lambda lv: probs[0].lsize(lv), "pipelined vs serial")
+    for lv in range(nl):
+        info = [p.levels[lv].opJacob.launch_info() for p in probs]
+        assert info[0]["segments"] >= 2 and info[1]["segments"] == 1, (lv, info)
+    for p in probs:
+        p.destroy()
 
 
 def test_recorded_graph_survives_growth_of_the_scratch(product_lib):

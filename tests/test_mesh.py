@@ -162,3 +162,33 @@ def test_node_sets_become_side_sets_in_the_exodus_reader(tmp_path):
     z0 = side_set_nodes(r, dm, [11]); x1 = side_set_nodes(r, dm, [12])
     assert z0.size == 7 * 7 and np.all(dm.node_coords[z0][:, 2] == 0.0)          # the whole z- face of the 2x2x1 box at degree 3
     assert x1.size == 7 * 4 and np.all(dm.node_coords[x1][:, 0] == 1.0)
+
+
+def test_scrambled_mesh_is_the_same_discrete_problem(oracle):
+    """mesh.scramble_mesh (bench.py --scramble): random element and vertex order, random rotation of every element's local axes.
+    Same geometry, side sets and operator: with inputs that depend on the node coordinates only, the residual and the Jacobian action
+    agree node for node (matched through the coordinates) with the structured mesh's."""
+    from ceedpetscsolid_amd.mesh import hex_rotations, hollow_cylinder_mesh, scramble_mesh
+    from ceedpetscsolid_amd.solid import SolidProblem, smooth_displacement
+    assert len(hex_rotations()) == 24
+    m0 = hollow_cylinder_mesh(2, 8, 3)
+    outs = []
+    for m in (m0, scramble_mesh(m0, 3, order=True, orient=False), scramble_mesh(m0, 4, order=True, orient=True), scramble_mesh(m0, 5, order=False, orient=True)):
+        p = SolidProblem(oracle, m, 2, "hyperFS", nu=0.3, E=1.0, bc_sides=[998], multigrid="none")
+        X = p.levels[p.fine].dofmap.node_coords
+        n = p.lsize()
+        u = smooth_displacement(X, 0.1, origin=(-1., -1., -5.), span=(2., 2., 10.))
+        c = p.ceed
+        U, Y = c.vector(n).set_array(u), c.vector(n)
+        p.form_residual(U, Y)
+        r = Y.to_numpy().reshape(-1, 3)
+        x = (np.sin(X @ np.array([[1.3, 0.7, 2.1], [0.4, 1.9, 0.3], [2.2, 0.5, 1.1]])) * (p.levels[p.fine].mask.reshape(-1, 3) == 0)).reshape(-1)
+        U.set_array(x); p.apply_jacobian(p.fine, U, Y)
+        j = Y.to_numpy().reshape(-1, 3)
+        key = np.lexsort(np.round(X, 9).T)
+        outs.append((X[key], r[key], j[key]))
+        p.destroy()
+    for X, r, j in outs[1:]:
+        assert np.allclose(X, outs[0][0], atol=1e-12)
+        assert np.linalg.norm(r - outs[0][1]) < 1e-12 * np.linalg.norm(outs[0][1])
+        assert np.linalg.norm(j - outs[0][2]) < 1e-12 * np.linalg.norm(outs[0][2])

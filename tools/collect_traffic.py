@@ -49,6 +49,15 @@ for name in (os.environ.get("KPAT", "k_fused_pencil<5, 5, 6"), "k_assemble("):
     out["per_kernel"][name] = {"fetch_bytes": fb, "write_bytes": wb, "launches_per_apply": SEG}
     tot += fb + wb
 out["hbm_bytes_per_apply"] = tot
+# the kernel's row of this build's ISA summary travels with the numbers: bench.py reports them only while the running
+# library still has the same row
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench as _b
+    out["kernel_isa"] = _b.isa_line(out["kernel"], _b.BUILD_ISA)
+except Exception as e:   # noqa: BLE001
+    out["kernel_isa"] = None
+    out["kernel_isa_error"] = repr(e)
 out["algorithmic_bytes_per_apply"] = bench["roofline"]["algorithmic_bytes_per_launch"]
 json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", tag + "_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
