@@ -352,6 +352,9 @@ def main():
                     help="one GPU: the SAME mesh as an unstructured generator might hand it over (mesh.scramble_mesh) -- order: elements and "
                          "vertices in random order; all: also every element's local axes relabelled by a random rotation (no common sweep "
                          "direction: the general geometry path).  The stand-in for the absent cylinder8_99Ke_4ss_us.exo at its worst")
+    ap.add_argument("--reorder", action="store_true",
+                    help="sort the elements along a Morton curve through their centroids before numbering the nodes (mesh.reorder_elements_locality): "
+                         "what the mesh layer can do for a badly ordered mesh (use with --scramble or --workload mesh)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no device, no operator: the N ranks rendezvous on gloo, partition the mesh as the real run does and time the "
                          "interface sums of a test vector over torch.distributed; the line says \"dry_run\": true and \"value\": null")
@@ -418,6 +421,9 @@ def main():
             sys.exit("--scramble runs on one GPU")
         from ceedpetscsolid_amd.mesh import scramble_mesh
         mesh = scramble_mesh(mesh, 20261005, order=True, orient=args.scramble == "all")
+    if args.reorder:
+        from ceedpetscsolid_amd.mesh import reorder_elements_locality
+        mesh = reorder_elements_locality(mesh)
     lead = interface_elements(mesh, virtual=vw)        # collective; all False on one rank
     overlap = (world > 1 or emu) and not args.no_overlap and lead.any() and not lead.all()
     if overlap:
@@ -612,6 +618,7 @@ def main():
                                     f"degree {args.degree}, Q={Q}, side sets {bc} clamped, Jacobian apply y=J(u)x") if args.workload == "mesh" else
                                    (f"config 5 shape: {args.problem}, box {args.nr}x{args.nth}x{args.nz} = {mesh.nelem} hex per GPU, "
                                     f"degree {args.degree}, Q={Q}, z faces clamped, Jacobian apply y=J(u)x"),
+                       "reorder": "elements sorted along a Morton curve through their centroids" if args.reorder else None,
                        "scramble": None if args.scramble == "none" else ("elements and vertices in random order" + (", every element's local axes rotated at random" if args.scramble == "all" else "")),
                        "global_dofs": n_global, "elements_per_gpu": mesh.nelem, "ldofs_per_gpu": n,
                        "halo_dofs_rank0": halo.n_shared_dofs, "kernel": op.kernel_name,

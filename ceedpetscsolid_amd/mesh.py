@@ -504,6 +504,24 @@ def scramble_mesh(mesh: HexMesh, seed: int = 0, order: bool = True, orient: bool
                    name=mesh.name + "[scrambled" + (" order" if order else "") + (" orientation" if orient else "") + "]")
 
 
+def reorder_elements_locality(mesh: HexMesh, bits: int = 10) -> HexMesh:
+    """Elements sorted along a Morton (Z-order) curve through their centroids: what the step before the path can do for a mesh whose
+    generator numbered its elements without locality ("enables cache-friendly element / dof ordering").  The
+    high-order nodes are numbered in first-touch order over the element sweep (build_dofmap), so consecutive elements then share
+    their nodes through one L2 and their E-vector blocks sit next to each other.  Geometry, side sets and the problem are unchanged."""
+    cen = mesh.coords[mesh.cells].mean(axis=1)
+    lo, hi = cen.min(axis=0), cen.max(axis=0)
+    q = np.minimum(((cen - lo) / np.maximum(hi - lo, 1e-300) * (1 << bits)).astype(np.uint64), (1 << bits) - 1)
+    code = np.zeros(mesh.nelem, dtype=np.uint64)
+    for b in range(bits):
+        for d in range(3):
+            code |= ((q[:, d] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + d)
+    perm = np.argsort(code, kind="stable")
+    inv = np.empty_like(perm); inv[perm] = np.arange(perm.size)
+    ss = {sid: (np.stack([inv[np.asarray(fs)[:, 0]], np.asarray(fs)[:, 1]], axis=1) if len(fs) else np.asarray(fs)) for sid, fs in mesh.side_sets.items()}
+    return HexMesh(mesh.coords, mesh.cells[perm], ss, vertex_gid=mesh.vertex_gid, name=mesh.name + "[morton]")
+
+
 def key_bytes(keys: np.ndarray) -> np.ndarray:
     """Topological keys as fixed-size byte strings (hashable / sortable across ranks)."""
     k = np.ascontiguousarray(keys, dtype=np.int64)

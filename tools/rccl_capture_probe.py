@@ -19,6 +19,9 @@ def child(inline: str):
     import ctypes as C
     import numpy as np
     import torch  # noqa: F401  (loads the HIP runtime and RCCL this library binds to)
+    bt = os.path.join(ROOT, "tools", "libsegv_bt.so")   # (round 4) C backtrace of the crash: module(+offset) per frame on stderr
+    if os.path.exists(bt):
+        C.CDLL(bt).segv_backtrace_install()
     from ceedpetscsolid_amd import ceed as cd
     ceed = cd.Ceed(cd.CeedLib(cd.PRODUCT_LIB), "/gpu/hip/mi355x")
     L = ceed.L
@@ -55,3 +58,5 @@ if __name__ == "__main__":
         last = [l for l in p.stdout.splitlines() if l and not l.startswith(("RCCL", "HIP", "ROCm", "Hostname", "Librccl"))]
         print(f"COMM_INLINE={inline}: exit {p.returncode} ({'signal ' + str(-p.returncode) if p.returncode < 0 else 'ok' if p.returncode == 0 else 'error'}); "
               f"got as far as: {last[-1] if last else '(nothing)'}; stderr tail: {p.stderr.strip().splitlines()[-1][:200] if p.stderr.strip() else ''}")
+        if "=== SIGSEGV backtrace" in p.stderr:
+            print(p.stderr[p.stderr.index("=== SIGSEGV backtrace"):])
