@@ -79,8 +79,7 @@ def test_config3_full_solve_on_the_device(gpu):
     of every increment, the Newton count (3 per increment), a Krylov count in the band the matrix-free and the assembled
     coarse solve both give, the clamp displacement reached, and a final residual at the solver's tolerance.
     THE LOAD the pinned counts belong to: -bc_clamp_998_translate 0,-0.05,0.1 -- a TENTH of the README's 0,-0.5,1
-    (README.rst:63, whose minimal command runs linElas).  At the README's load linElas converges (10 / 210 iterations) and
-    neither hyperelastic model gets through the first of 10 or 40 increments (profiles/r03_config3_readme_load.txt)."""
+    (README.rst:63, whose minimal command runs linElas); the README's load itself: test_config3_readme_load_on_the_device."""
     mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_5580e_4ss_us.npz"))
     p = SolidProblem(gpu, mesh, 4, "hyperSS", nu=0.3, E=1e3, bc_sides=[998, 999])
     assert p.degrees == [1, 2, 4] and p.n_free() == 1150068
@@ -98,6 +97,26 @@ def test_config3_full_solve_on_the_device(gpu):
     umax = np.abs(u.reshape(-1, 3)).max(axis=0)
     # the free nodes next to the translated clamp (0, -0.05, 0.1) follow it (recorded on the device: 0.0031, 0.0515, 0.0998)
     assert 0.09 < umax[2] <= 0.1 + 1e-9 and 0.045 < umax[1] < 0.06 and umax[0] < 0.01, umax
+
+
+@pytest.mark.gpu
+def test_config3_readme_load_on_the_device(gpu):
+    """BASELINE config 3 at the load SURVEY 8(d) states -- -bc_clamp 998,999 -bc_clamp_998_translate 0,-0.5,1 (README.rst:63) -- with
+    hyperSS at degree 4 on the reference's own mesh.  What decides convergence is the size of a load increment, not the line search
+    (profiles/r04_config3_readme_load.txt: the first increment of 10, 20 or 40 inverts the first layer of degree-4 elements at the clamp
+    -- det F < 0, tr eps < -1 -- whichever of the three line searches runs, PETSc's never-rejecting SNESLINESEARCHCP included; a
+    hundredth of the translation per increment converges with all three).  With -num_steps 100 the whole solve converges: recorded on
+    the device 300 Newton / 4 929 Krylov iterations, clamp displacement reached (0.0316, 0.5155, 0.9984)."""
+    mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_5580e_4ss_us.npz"))
+    p = SolidProblem(gpu, mesh, 4, "hyperSS", nu=0.3, E=1e3, bc_sides=[998, 999])
+    s = NewtonPMG(p, clamp={998: dict(translate=(0.0, -0.5, 1.0)), 999: dict()}, coarse="amg", graph=True)
+    st = s.solve(100)
+    assert st.converged and st.increments == 100
+    assert 280 <= st.newton_its <= 330, st.newton_its
+    assert 4000 <= st.ksp_its <= 6000, st.ksp_its
+    umax = np.abs(s.U.to_numpy().reshape(-1, 3)).max(axis=0)
+    assert 0.99 < umax[2] <= 1.0 + 1e-9 and 0.5 < umax[1] < 0.53 and umax[0] < 0.05, umax
+    assert st.history[-1][4] < 1e-6
 
 
 def test_chebyshev_coarse_solver_converges_on_oracle(oracle):

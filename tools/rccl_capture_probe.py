@@ -20,8 +20,6 @@ def child(inline: str):
     import numpy as np
     import torch  # noqa: F401  (loads the HIP runtime and RCCL this library binds to)
     bt = os.path.join(ROOT, "tools", "libsegv_bt.so")   # (round 4) C backtrace of the crash: module(+offset) per frame on stderr
-    if os.path.exists(bt):
-        C.CDLL(bt).segv_backtrace_install()
     from ceedpetscsolid_amd import ceed as cd
     ceed = cd.Ceed(cd.CeedLib(cd.PRODUCT_LIB), "/gpu/hip/mi355x")
     L = ceed.L
@@ -40,6 +38,8 @@ def child(inline: str):
         L.chk(L.lib.CeedXHaloStart(h, Y.h)); L.chk(L.lib.CeedXHaloFinish(h, Y.h))
     exchange()
     print("eager exchange ok", flush=True)
+    if os.path.exists(bt):      # installed LAST (the runtimes loaded above may set handlers of their own), on a stack of its own
+        C.CDLL(bt).segv_backtrace_install()
     g = ceed.capture(exchange)
     print("captured", flush=True)
     g.launch(); ceed.synchronize()
