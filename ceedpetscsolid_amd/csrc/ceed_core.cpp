@@ -86,7 +86,6 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   o.ovl_groups1 = std::max(0, env_int("CEED_MI355X_OVL_G1", o.ovl_groups1));
   o.comm_priority = env_int("CEED_MI355X_COMM_PRIO", o.comm_priority);
   o.comm_inline = env_int("CEED_MI355X_COMM_INLINE", o.comm_inline);
-  o.halo_capture = env_int("CEED_MI355X_HALO_CAPTURE", o.halo_capture);
   o.fold_pack = env_int("CEED_MI355X_FOLD_PACK", o.fold_pack);
   *ceed = c;
   return 0;

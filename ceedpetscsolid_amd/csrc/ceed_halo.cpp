@@ -198,12 +198,17 @@ int halo_pack_and_send(CeedXHalo H, const double *py, hipStream_t pack_stream) {
 // the RCCL group alone: the send buffer has been filled on `pack_stream` (by k_halo_pack or by the rows' launch, HaloPackFold)
 int halo_send(CeedXHalo H, hipStream_t pack_stream) {
   Ceed c = H->ceed;
-  // Recording into a hipGraph (tools/rccl_capture_probe.py, RCCL 2.26.6 as shipped with this image's torch): the group
-  // issued IN ORDER on the capturing stream records and replays correctly; issued on the communicator's stream, joined to
-  // the capture by events, it crashes the process (segmentation fault inside the capture) -- refused.
-  if (c->capturing && !c->opt.comm_inline && !c->opt.halo_capture)
-    return ceed_error("the halo exchange on a stream of its own (CEED_MI355X_COMM_INLINE=0) cannot be recorded into a hipGraph with this RCCL "
-                      "(it crashes inside the capture: tools/rccl_capture_probe.py); the default in-order form can");
+  // Recording into a hipGraph (RCCL 2.26.6 / HIP runtime as shipped with this image's torch): the group issued IN ORDER on the
+  // capturing stream records and replays correctly.  Issued on the communicator's stream, joined to the capture by events, the
+  // PROCESS dies -- cause established in round 4 (profiles/r04_rccl_capture_probe.txt): not in RCCL's kernels but at
+  // hipStreamEndCapture, a stack overflow in libamdhip64.so's self-recursive reset of a capture's forked streams
+  // (hip::Stream::EndCapture walking parallelCaptureStreams_: the frame libamdhip64.so+0x2d34a8 repeated until the guard page).
+  // RCCL forks an internal stream from the stream it is called on; called on a stream that is itself a fork of the capturing
+  // stream, the runtime's lists of forked streams no longer form a tree.  Nothing this library can repair from outside: the form is
+  // refused while recording, unconditionally (the CEED_MI355X_HALO_CAPTURE override of round 3 is gone).
+  if (c->capturing && !c->opt.comm_inline)
+    return ceed_error("the halo exchange on a stream of its own (CEED_MI355X_COMM_INLINE=0) cannot be recorded into a hipGraph: hipStreamEndCapture "
+                      "overflows its stack on the forked streams RCCL adds (profiles/r04_rccl_capture_probe.txt); the default in-order form can");
   hipStream_t cs = c->opt.comm_inline ? pack_stream : c->comm_stream;
   if (cs != pack_stream) {
     HIPCHK(hipEventRecord(H->packed, pack_stream));

@@ -50,7 +50,6 @@ struct CeedOptions {
                                  // sequence); 2 split-phase on two streams (both phases' fused kernels side by side)
   int ovl_groups0 = 1, ovl_groups1 = 0;   // CEED_MI355X_OVL_G0 / _G1: groups per wave of the two phases (0: persistent grid)
   int fold_pack = 1;             // CEED_MI355X_FOLD_PACK=0: the exchange's pack as a launch of its own (A/B)
-  int halo_capture = 0;          // CEED_MI355X_HALO_CAPTURE=1: let the exchange on the communicator's own stream be recorded too (crashes inside RCCL 2.26.6)
   int comm_inline = 1;           // CEED_MI355X_COMM_INLINE=0: the exchange's sends / receives on a stream of their own (see halo_pack_and_send)
   int comm_priority = 0;         // CEED_MI355X_COMM_PRIO=1: the exchange on a highest-priority stream -- measured 4x SLOWER (see CeedXCommInit)
 };

@@ -2,6 +2,10 @@
 """Can this RCCL's point-to-point calls be recorded into a hipGraph?  Each attempt runs in a CHILD process (the failure
 mode found in round 3 is a segmentation fault of the host process inside the capture, RCCL 2.26.6 as shipped with
 torch 2.10 + rocm 7.0).  Prints one line per form: inline (RCCL on the capturing stream) / own stream (joined by events).
+Round 4: the crash's C backtrace was taken with tools/segv_backtrace.c (profiles/r04_rccl_capture_probe.txt: a stack overflow in
+libamdhip64.so at hipStreamEndCapture); the library now refuses the own-stream form while recording unconditionally, so the second
+child is expected to end with that CeedError -- the crash itself is reproduced without this library by
+tools/microbench/capture_fork_repro.hip.
 
     python3 tools/rccl_capture_probe.py            # parent: spawns the children BEFORE touching the GPU itself
 """
@@ -14,7 +18,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def child(inline: str):
     sys.path.insert(0, ROOT)
-    os.environ["CEED_MI355X_HALO_CAPTURE"] = "1"
     os.environ["CEED_MI355X_COMM_INLINE"] = inline
     import ctypes as C
     import numpy as np
