@@ -106,12 +106,6 @@ int build_csr(CeedElemRestriction r, CsrMap &M, const unsigned char *prio, int s
   if (skipP > 0)
     for (size_t i = 0; i < n; i++)
       if (node_is_element_interior((int)(i % (size_t)r->elemsize), skipP)) { cnt[(size_t)r->h_offsets[i]] = 0; M.nskipped++; }   // stored by the fused kernel itself
-#ifdef CPS_ABLATE_MERGE
-  if (skipP > 0) {
-    for (size_t i = 0; i < n; i++) if (abl_node_kind((int)(i % (size_t)r->elemsize), skipP) == 2 && cnt[(size_t)r->h_offsets[i]] > 0) cnt[(size_t)r->h_offsets[i]]--;
-    for (size_t i = 0; i < n; i++) if (abl_node_kind((int)(i % (size_t)r->elemsize), skipP) == 1) cnt[(size_t)r->h_offsets[i]] = 0;
-  }
-#endif
   std::vector<uint32_t> slot((size_t)r->lsize, 0xFFFFFFFFu);
   std::vector<uint32_t> &rowptr = M.h_rowptr, &cols = M.h_cols;
   M.h_node_off.clear(); rowptr.clear();
@@ -132,9 +126,6 @@ int build_csr(CeedElemRestriction r, CsrMap &M, const unsigned char *prio, int s
   for (size_t i = 0; i < n; i++) {  // element order => each node's contributors are sorted by element
     const uint32_t sl = slot[(size_t)r->h_offsets[i]];
     if (sl == 0xFFFFFFFFu) continue;
-#ifdef CPS_ABLATE_MERGE
-    if (skipP > 0 && abl_node_kind((int)(i % (size_t)r->elemsize), skipP) == 2) continue;
-#endif
     // E position: e * elemsize + n, or in the shell-only E-vector of the direct-store mode e * shell size + shell rank
     const size_t e = i / (size_t)r->elemsize; const int ln = (int)(i % (size_t)r->elemsize);
     cols[cursor[sl]++] = skipP > 0 ? (uint32_t)(e * (size_t)element_shell_size(skipP) + (size_t)node_shell_rank(ln, skipP)) : (uint32_t)i;

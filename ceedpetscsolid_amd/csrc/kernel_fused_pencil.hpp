@@ -406,10 +406,6 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
     const int t = lane + 64 * r, el = t / P3, n = t % P3;
     aNd[r] = lds0 + (el * SE + (n / (P * P)) * SK + ((n / P) % P) * SJ + n % P);
     if (a.direct && node_is_element_interior(n, P)) nd_interior |= 1u << r;
-#ifdef CPS_ABLATE_MERGE
-    if (a.direct && abl_node_kind(n, P) == 1) nd_interior |= 1u << r;
-    if (a.direct && abl_node_kind(n, P) == 2) nd_interior |= 1u << (16 + r);   // not stored at all
-#endif
     // [element][shell rank or node][3], the element blocks a.evec_stride doubles apart
     ev_idx[r / 2] |= (uint32_t)(min(el, E - 1) * a.evec_stride + (a.direct ? node_shell_rank(n, P) : n) * 3) << (16 * (r % 2));
   }
@@ -805,9 +801,6 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
             const uint32_t fl = ka->mask_out ? (off[r] >> OFF_FLAG_SHIFT) : 0u;
             double *yb = ka->y;
             yb[base] = (fl & 1u) ? 0. : v[r][0]; (yb + 1)[base] = (fl & 2u) ? 0. : v[r][1]; (yb + 2)[base] = (fl & 4u) ? 0. : v[r][2];
-#ifdef CPS_ABLATE_MERGE
-          } else if ((nd_interior >> (16 + r)) & 1u) {
-#endif
           } else {
             double *eb = ka->evec + (size_t)(ka->elem_begin + grp * E) * ka->evec_stride;
             const uint32_t ve = (r % 2) ? (ev_idx[r / 2] >> 16) : (ev_idx[r / 2] & 0xFFFFu);

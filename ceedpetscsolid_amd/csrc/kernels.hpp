@@ -118,15 +118,8 @@ static inline bool node_is_element_interior(int n, int P) {
 #ifdef __HIPCC__
 __host__ __device__
 #endif
-static inline int merge_shell_rank(int n, int P, int d);
-#ifdef __HIPCC__
-__host__ __device__
-#endif
 static inline int node_shell_rank(int n, int P) {
   const int m = P - 2, i = n % P, j = (n / P) % P, k = n / (P * P);
-#ifdef CPS_ABLATE_MERGE
-  return merge_shell_rank(n, P, 0);
-#endif
 #ifdef CPS_SHELL_LEX
 #define CPS_CLAMPM(v) ((v) < 0 ? 0 : ((v) > m ? m : (v)))
   int before = CPS_CLAMPM(k - 1) * m * m;                  // interior nodes in the planes below
@@ -144,47 +137,6 @@ static inline int node_shell_rank(int n, int P) {
   if (i == 0) return 2 * P * P + 2 * P * m + (k - 1) * m + (j - 1);
   return 2 * P * P + 2 * P * m + m * m + (k - 1) * m + (j - 1);   // i == P - 1 (interior nodes have no rank)
 #endif
-}
-// Shell rank for a mesh whose elements are walked in RUNS along local direction d (0: i, 1: j, 2: k), the face between two
-// consecutive elements of a run being summed inside the fused kernel: with t the node's index along d and (a, b) its indices in the
-// two other directions, the RING nodes (0 < t < P-1: the four side faces) come first, face by face, then the NEAR face
-// (t = 0: its boundary nodes, then its interior), then the FAR face (t = P-1).  An element linked to both run neighbours
-// stores ring + near boundary only: a contiguous prefix of its block.
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-static inline int merge_shell_rank(int n, int P, int d) {
-  const int m = P - 2, c0 = n % P, c1 = (n / P) % P, c2 = n / (P * P);
-  const int t = d == 0 ? c0 : (d == 1 ? c1 : c2), a = d == 0 ? c1 : c0, b = d == 2 ? c1 : c2;
-  const int ring = m * (4 * P - 4), per = 4 * P - 4;
-  if (t > 0 && t < P - 1) {
-    if (b == 0) return (t - 1) * P + a;
-    if (b == P - 1) return m * P + (t - 1) * P + a;
-    if (a == 0) return 2 * m * P + (t - 1) * m + (b - 1);
-    return 2 * m * P + m * m + (t - 1) * m + (b - 1);       // a == P - 1 (interior nodes have no rank)
-  }
-  if (t == 0) {
-    if (b == 0) return ring + a;
-    if (b == P - 1) return ring + P + a;
-    if (a == 0) return ring + 2 * P + (b - 1);
-    if (a == P - 1) return ring + 2 * P + m + (b - 1);
-    return ring + per + (b - 1) * m + (a - 1);               // interior of the near face
-  }
-  return ring + per + m * m + b * P + a;                       // far face
-}
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-static inline int abl_node_kind(int n, int P) {   // (timing-only ablation -DCPS_ABLATE_MERGE, tools/r4_merge_bound.sh) 1: stored straight to y, 2: not stored
-#ifdef CPS_ABLATE_MERGE
-  const int i = n % P, j = (n / P) % P, k = n / (P * P);
-  if (i == P - 1) return 2;
-#if CPS_ABLATE_MERGE != 2    // (2: the near face's interior goes through the E-vector like the rest of the shell)
-  if (i == 0 && j > 0 && j < P - 1 && k > 0 && k < P - 1) return 1;
-#endif
-#endif
-  (void)n; (void)P;
-  return 0;
 }
 #ifdef __HIPCC__
 __host__ __device__
