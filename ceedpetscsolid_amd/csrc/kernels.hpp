@@ -201,6 +201,9 @@ hipError_t launch_setup_geo(int Q, const BasisTables &t, const SetupGeoArgs &a, 
 hipError_t launch_diag(int P, int Q, int qf, const BasisTables &t, const DiagArgs &a, hipStream_t s,
                        const char **name);
 
+// The instantiations of one quadrature size are compiled as pencil_inst_parts(Q) objects (kernels_fused_inst.hip, -DCPS_PART=<k>): the kernels
+// with (Q - P) % parts == k -- the Q = 8 object alone took 72 s of a 90 s build.  csrc/Makefile lists the same parts.
+constexpr int pencil_inst_parts(int Q) { return Q == 8 ? 4 : (Q == 7 ? 2 : 1); }
 // elements per wave (= per group) of the pencil kernel, PencilGeom<P, Q>::E: 3 Q^2 pencils per element and pass against 64
 // lanes and the 9 Q^3-double LDS slab per element
 #ifndef CPS_PENCIL_E5

@@ -1,6 +1,7 @@
 // kernels_fused_inst.hip -- instantiations of the fused operator kernel for one
-// quadrature size.  Compiled once per -DCPS_Q=<Q> (see Makefile) so the
-// instantiations build in parallel; each object exports launch_fused_grad_q<Q>.
+// quadrature size.  Compiled once per -DCPS_Q=<Q> -DCPS_PART=<k> (see Makefile) so the
+// instantiations build in parallel; each object exports launch_fused_grad_q<Q>p<k> and holds
+// the kernels with (Q - P) % pencil_inst_parts(Q) == k.
 //
 // Node counts P per Q follow the level-degree rules of the reference
 // (cloptions.c:195-225): the fine level has P = Q (qextra = 0), coarse levels
@@ -11,6 +12,9 @@
 #ifndef CPS_Q
 #error "compile with -DCPS_Q=<points per direction>"
 #endif
+#ifndef CPS_PART
+#define CPS_PART 0
+#endif
 
 namespace cps {
 
@@ -19,10 +23,13 @@ namespace cps {
 #define CPS_STR_(x) #x
 #define CPS_STR(x) CPS_STR_(x)
 
+// (the part test depends on the template parameter, so the kernels of the other parts are not instantiated here)
 #define CPS_CASE(Pv, QFv, QFname)                                                   \
-  if (P == Pv && qf == QFv) {                                                       \
-    *name = "fused_grad<P=" #Pv ",Q=" CPS_STR(CPS_Q) "," QFname ">/pencil";         \
-    return launch_fused_pencil_t<Pv, CPS_Q, QFv>(t, a, s);                          \
+  if constexpr ((CPS_Q - (Pv)) % pencil_inst_parts(CPS_Q) == PART) {                \
+    if (P == Pv && qf == QFv) {                                                     \
+      *name = "fused_grad<P=" #Pv ",Q=" CPS_STR(CPS_Q) "," QFname ">/pencil";       \
+      return launch_fused_pencil_t<Pv, CPS_Q, QFv>(t, a, s);                        \
+    }                                                                               \
   }
 // The derived-state tangent is instantiated where it measured a gain: Q >= 6 (one element per wave; -2.6 ... -3.1 % on config 5's
 // block, same box); at Q = 5 it removes 9 % of the VALU instructions and 0 % of the time (pencil_derived_state, kernels.hpp).
@@ -37,9 +44,8 @@ namespace cps {
   CPS_CASE(Pv, QF_HYPERFS_DF, "HyperFSdF") \
   CPS_DERIVED(Pv)
 
-hipError_t CPS_CAT(launch_fused_grad_q, CPS_Q)(int P, int qf, const BasisTables &t,
-                                               const FusedGradArgs &a, hipStream_t s,
-                                               const char **name) {
+template <int PART>
+static hipError_t dispatch_part(int P, int qf, const BasisTables &t, const FusedGradArgs &a, hipStream_t s, const char **name) {
   CPS_JACOBIANS(CPS_Q)
   CPS_CASE(CPS_Q, QF_HYPERSS_F, "HyperSSF")
   CPS_CASE(CPS_Q, QF_HYPERFS_F, "HyperFSF")
@@ -62,6 +68,12 @@ hipError_t CPS_CAT(launch_fused_grad_q, CPS_Q)(int P, int qf, const BasisTables 
   CPS_JACOBIANS(7)
 #endif
   return hipErrorInvalidValue;
+}
+
+hipError_t CPS_CAT(CPS_CAT(CPS_CAT(launch_fused_grad_q, CPS_Q), p), CPS_PART)(int P, int qf, const BasisTables &t, const FusedGradArgs &a,
+                                                                              hipStream_t s, const char **name) {
+  static_assert(CPS_PART >= 0 && CPS_PART < pencil_inst_parts(CPS_Q), "part of this quadrature size");
+  return dispatch_part<CPS_PART>(P, qf, t, a, s, name);
 }
 
 }  // namespace cps

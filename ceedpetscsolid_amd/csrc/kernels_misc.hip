@@ -394,18 +394,22 @@ int device_cu_count() {
 // ===========================================================================
 // Fused-operator dispatch over the per-Q objects (kernels_fused_inst.hip).
 // ===========================================================================
-#define CPS_DECL_Q(Qv) hipError_t launch_fused_grad_q##Qv(int, int, const BasisTables &, const FusedGradArgs &, hipStream_t, const char **);
-CPS_DECL_Q(2) CPS_DECL_Q(3) CPS_DECL_Q(4) CPS_DECL_Q(5) CPS_DECL_Q(6) CPS_DECL_Q(7) CPS_DECL_Q(8)
+#define CPS_DECL_QP(Qv, Pt) hipError_t launch_fused_grad_q##Qv##p##Pt(int, int, const BasisTables &, const FusedGradArgs &, hipStream_t, const char **);
+CPS_DECL_QP(2, 0) CPS_DECL_QP(3, 0) CPS_DECL_QP(4, 0) CPS_DECL_QP(5, 0) CPS_DECL_QP(6, 0) CPS_DECL_QP(7, 0) CPS_DECL_QP(7, 1)
+CPS_DECL_QP(8, 0) CPS_DECL_QP(8, 1) CPS_DECL_QP(8, 2) CPS_DECL_QP(8, 3)
 hipError_t launch_fused_grad(int P, int Q, int qf, const BasisTables &t, const FusedGradArgs &a,
                              hipStream_t s, const char **name) {
+  static_assert(pencil_inst_parts(7) == 2 && pencil_inst_parts(8) == 4 && pencil_inst_parts(6) == 1, "the objects declared above");
+  const int part = (Q >= 2 && Q <= MAXN1D && P <= Q) ? (Q - P) % pencil_inst_parts(Q) : 0;
   switch (Q) {
-    case 2: return launch_fused_grad_q2(P, qf, t, a, s, name);
-    case 3: return launch_fused_grad_q3(P, qf, t, a, s, name);
-    case 4: return launch_fused_grad_q4(P, qf, t, a, s, name);
-    case 5: return launch_fused_grad_q5(P, qf, t, a, s, name);
-    case 6: return launch_fused_grad_q6(P, qf, t, a, s, name);
-    case 7: return launch_fused_grad_q7(P, qf, t, a, s, name);
-    case 8: return launch_fused_grad_q8(P, qf, t, a, s, name);
+    case 2: return launch_fused_grad_q2p0(P, qf, t, a, s, name);
+    case 3: return launch_fused_grad_q3p0(P, qf, t, a, s, name);
+    case 4: return launch_fused_grad_q4p0(P, qf, t, a, s, name);
+    case 5: return launch_fused_grad_q5p0(P, qf, t, a, s, name);
+    case 6: return launch_fused_grad_q6p0(P, qf, t, a, s, name);
+    case 7: return part == 0 ? launch_fused_grad_q7p0(P, qf, t, a, s, name) : launch_fused_grad_q7p1(P, qf, t, a, s, name);
+    case 8: return part == 0 ? launch_fused_grad_q8p0(P, qf, t, a, s, name) : (part == 1 ? launch_fused_grad_q8p1(P, qf, t, a, s, name) :
+                   (part == 2 ? launch_fused_grad_q8p2(P, qf, t, a, s, name) : launch_fused_grad_q8p3(P, qf, t, a, s, name)));
   }
   return hipErrorInvalidValue;
 }

@@ -13,7 +13,7 @@ workgroup barrier.  None of this is promised by the language, so the build check
     no VGPR or SGPR spills
   * at most 256 VGPRs (two waves per SIMD) for the kernels of the metric configurations
 
-usage: isa_guard.py build/fused_q5.o [build/fused_q7.o ...] [--summary out.txt]
+usage: isa_guard.py build/fused_q5p0.o [build/fused_q7p0.o ...] [--summary out.txt]
 Exit status 1 on a violation in a guarded kernel (k_fused_pencil<P,Q,...>; Q = 8 -- degree 7, one wave per SIMD by design -- is held to
 the same LDS / barrier / scratch rules with a 512-register limit).
 """

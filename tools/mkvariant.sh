@@ -9,8 +9,8 @@ T=/tmp/variants/$name; W=$T/pkg/csrc; rm -rf $T; mkdir -p $W $T/include; cp -r $
 cd $W; touch build/*.o build/isa_summary.txt
 if [ "$qs" = all ]; then rm -f build/*.o; qs="2 3 4 5 6 7 8"; fi
 if [ "$qs" = misc ]; then rm -f build/misc.o; qs=""; fi
-for q in $qs; do rm -f build/fused_q$q.o; done
+for q in $qs; do rm -f build/fused_q${q}p*.o; done
 make -s -j8 EXTRA_HIPFLAGS="$flags" libceed_mi355x.so libsolid_harness_mi355x.so
 mkdir -p $R/tools/variants/$name; cp $W/*.so $R/tools/variants/$name/
-python3 $R/tools/isa_guard.py $(for q in $qs; do echo build/fused_q$q.o; done) --summary /tmp/variants/$name.isa.txt > /dev/null 2>&1 || true
+python3 $R/tools/isa_guard.py $(for q in $qs; do ls build/fused_q${q}p*.o; done) --summary /tmp/variants/$name.isa.txt > /dev/null 2>&1 || true
 grep -E "P=5,Q=5,HyperFSdF,geo=1|P=5,Q=5,HyperSSdF,geo=1" /tmp/variants/$name.isa.txt || true
