@@ -279,15 +279,6 @@ CPS_DEV void pencil_pass(ktab_t table, const ldsp_t (&addr)[R], int lane, int nt
   } else pencil_pass_impl<NIN, NOUT, LD, TR, SB, SRC, DST, SGN, EO, R>(table, addr, lane, ntask);
 }
 
-// (tuning hooks, round 4) streaming hints: the stored state is read once per apply, the E-vector written once and read once
-#ifndef CPS_NT_STATE
-#define CPS_NT_STATE 0
-#endif
-#ifndef CPS_NT_EVEC
-#define CPS_NT_EVEC 0
-#endif
-template <bool NT> CPS_DEV double gld(const double *p) { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
-template <bool NT> CPS_DEV void gst(double *p, double v) { if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v; }
 #ifndef CPS_PENCIL_MINW
 #define CPS_PENCIL_MINW 2   // waves per SIMD the register allocation is held to (256 VGPRs)
 #endif
@@ -449,7 +440,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
       const double *sb = ka->state_in + e0 * (NST * QS);
       const uint32_t vs = (uint32_t)(el * (NST * QS) + q);
 #pragma unroll
-      for (int c = 0; c < NST; c++) stv[c] = gld<CPS_NT_STATE>(&(sb + c * QS)[vs]);
+      for (int c = 0; c < NST; c++) stv[c] = (sb + c * QS)[vs];
     }
   };
   auto load_offsets = [&](int g, uint32_t *o) {
@@ -813,7 +804,7 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
           } else {
             double *eb = ka->evec + (size_t)(ka->elem_begin + grp * E) * ka->evec_stride;
             const uint32_t ve = (r % 2) ? (ev_idx[r / 2] >> 16) : (ev_idx[r / 2] & 0xFFFFu);
-            gst<CPS_NT_EVEC>(&eb[ve], v[r][0]); gst<CPS_NT_EVEC>(&(eb + 1)[ve], v[r][1]); gst<CPS_NT_EVEC>(&(eb + 2)[ve], v[r][2]);
+            eb[ve] = v[r][0]; (eb + 1)[ve] = v[r][1]; (eb + 2)[ve] = v[r][2];
           }
         }
       }

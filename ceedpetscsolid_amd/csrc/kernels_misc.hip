@@ -494,11 +494,7 @@ __global__ void k_assemble(const uint32_t *rowptr, const uint32_t *cols, const u
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const double *p = evec + (size_t)c[j] * 3;
-#ifdef CPS_NT_ASM    // (tuning hook, round 4) the E-vector is read once: streaming loads
-        v[j][0] = __builtin_nontemporal_load(p); v[j][1] = __builtin_nontemporal_load(p + 1); v[j][2] = __builtin_nontemporal_load(p + 2);
-#else
         v[j][0] = p[0]; v[j][1] = p[1]; v[j][2] = p[2];
-#endif
       }
 #pragma unroll
       for (int j = 0; j < 4; j++)
