@@ -232,7 +232,10 @@ def checked_rccl_halo(ceed, halo: "HaloExchange", probe: np.ndarray, device, tim
     ncclCommInitRank and the first exchange -- the calls that can hang when a peer is missing -- run in a worker thread
     under a time limit, with the rank's device made current first (a new thread starts on device 0).
     * time-out: the worker is stuck inside a collective and nothing sound can be done beside it in this process -- the
-      note is printed and the process EXITS with status 3 (a fresh launch is the retry).
+      note is printed and the process EXITS with status 3 (a fresh launch is the retry).  Only the stuck rank exits by itself: the
+      others are waiting in the collective that follows the bring-up and end when the LAUNCHER ends them -- which is required of it:
+      torch.distributed.run (what bench.py --gpus N starts, and what the driver uses) tears the whole job down as soon as one rank
+      exits non-zero, as mpirun does; a launcher that does not must put its own limit around the job.
     * exception or wrong sums on any rank: with strict (the default) HaloBringUpError on every rank; without, every rank
       gets (None, note) and may use the torch exchange -- the caller must then SAY so (bench.py: "halo_path")."""
     import sys
