@@ -349,6 +349,13 @@ static int read_phys(CeedQFunction qf, double *nu, double *E) {
   return 0;
 }
 
+// a recording remembers each provenance buffer it read once (a V-cycle applies the same operators many times)
+static void capture_dep(Ceed c, const GraphDep &d) {
+  for (const GraphDep &e : c->capture_deps)
+    if (e.v == d.v && e.geo == d.geo && e.derived == d.derived) return;
+  c->capture_deps.push_back(d);
+}
+
 struct TimerScope {
   CeedOperator op; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
   TimerScope(CeedOperator o, hipStream_t st) : op(o), s(st) {
@@ -412,7 +419,7 @@ static int fused_prepare(CeedOperator op, CeedVector in, CeedVector out, bool ad
         sv->derived_nu == a.nu && sv->derived_E == a.E) {
       F.qfkind = QF_HYPERFS_DF_DS;
       a.state_in = sv->derived;
-      if (c->capturing) c->capture_deps.push_back(GraphDep{sv, nullptr, sv->derived});
+      if (c->capturing) capture_dep(c, GraphDep{sv, nullptr, sv->derived});
     }
   }
   if (op->o_state >= 0) {
@@ -444,7 +451,7 @@ static int fused_prepare(CeedOperator op, CeedVector in, CeedVector out, bool ad
       a.geo_aff = qv->geo_aff;
       a.geo_swept = qv->geo_swept; a.geo_axis = qv->geo_axis;
       for (int i = 0; i < ai.basis->Q1d; i++) { a.qref[i] = qv->geo_qref[i]; a.qwt[i] = qv->geo_qwt[i]; }
-      if (c->capturing) c->capture_deps.push_back(GraphDep{qv, qv->geo, nullptr});
+      if (c->capturing) capture_dep(c, GraphDep{qv, qv->geo, nullptr});
     }
   }
   lame_constants(a.nu, a.E, &a.lambda, &a.TwoMu);
