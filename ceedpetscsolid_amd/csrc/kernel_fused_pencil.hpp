@@ -290,8 +290,10 @@ CPS_DEV void pencil_pass(ktab_t table, const ldsp_t (&addr)[R], int lane, int nt
 #endif
 constexpr int pencil_minw(int Q) { return Q == 5 ? CPS_PENCIL_MINW5 : CPS_PENCIL_MINW; }
 #ifndef CPS_PENCIL_NSET_BIGQ
-#define CPS_PENCIL_NSET_BIGQ 1   // Q >= 6: the split-table passes keep all rounds' pencils in VGPRs; a second q-point set
-#endif                           // would push the hyperFS tangent past 256 VGPRs (26 spilled to scratch)
+#define CPS_PENCIL_NSET_BIGQ 2   // Q >= 6: two sets as well since round 4.  Rounds 1-3 had ONE (a second set pushed the hyperFS tangent past
+#endif                           // 256 VGPRs: 26 spilled); the blocked task -> lane mapping freed ~18 registers at Q = 7 and the second set
+                                 // fits (202-236 VGPRs at Q = 6, 7).  Same-box A/B (profiles/r04_ab_experiments.txt item 12): config 5's block
+                                 // -3.3 %, the whole 64^3 box -4.5 %, Q = 6 -2.3 %, hyperSS at Q = 7 -7.1 %
 // GEO = 1: the geometric factors are recomputed per point from the element's trilinear map (FusedGradArgs::geo) instead of
 // read; GEO = 2: every element of the mesh is AFFINE (a parallelepiped: the box meshes of configs 1, 2 and 5), dXdx and
 // det J are constants of the element (FusedGradArgs::geo_aff, ten doubles) and only the weight varies from point to point;
@@ -423,7 +425,8 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
   // group's block.  Lanes of a dead element (only in the last, partial group) read the group's last
   // live element instead.
   auto nlive_of = [&](int nelem, int g) { const int n = nelem - g * E; return n < E ? n : E; };  // uniform, >= 1
-  constexpr int NSET = RQ >= 2 ? (Q >= 6 ? CPS_PENCIL_NSET_BIGQ : CPS_PENCIL_NSET) : 1;
+  // (Q >= 6 with qdata READ -- ten more doubles per point and set -- keeps one set: the residual kernel at Q = 6 spilled with two)
+  constexpr int NSET = RQ >= 2 ? (Q >= 6 ? (GEO == 0 ? 1 : CPS_PENCIL_NSET_BIGQ) : CPS_PENCIL_NSET) : 1;
   double qd[NSET][10], st[NSET][NST];
   auto load_point = [&](double *qdv, double *stv, int g, int r) {
     const kargs_t ka = kargs_fresh<KA>();  // one scalar load for the fields used here

@@ -10,7 +10,7 @@ cp $R/ceedpetscsolid_amd/csrc/*.so /tmp/dflt_libs/
 args() { case $1 in
   c4) echo "";; nz12) echo "--nz 12 --steps 100";; ss) echo "--problem hyperSS";;
   box6) echo "--workload box --nr 32 --nth 32 --nz 32 --degree 6";; p2) echo "--degree 2";; p3) echo "--degree 3";; mesh) echo "--workload mesh";;
-  lin) echo "--problem linElas";; scr) echo "--scramble all";; scro) echo "--scramble order";; scrm) echo "--scramble all --reorder";; scrom) echo "--scramble order --reorder";; em) echo "--emulate-rank 3 --of 8 --steps 100 --warmup 10";; box64) echo "--workload box --nr 64 --nth 64 --nz 64 --degree 6 --steps 20";; esac; }
+  lin) echo "--problem linElas";; scr) echo "--scramble all";; scro) echo "--scramble order";; scrm) echo "--scramble all --reorder";; scrom) echo "--scramble order --reorder";; em) echo "--emulate-rank 3 --of 8 --steps 100 --warmup 10";; box64) echo "--workload box --nr 64 --nth 64 --nz 64 --degree 6 --steps 20";; box5) echo "--workload box --nr 36 --nth 36 --nz 36 --degree 5";; box6ss) echo "--workload box --nr 32 --nth 32 --nz 32 --degree 6 --problem hyperSS";; esac; }
 run() { name=$1
   for t in $W; do
     timeout -k 10 300 python3 $R/bench.py $(args $t) --no-cpu-baseline --cold-idle-s 0 > $O/v_${name}_$t.json 2> $O/v_${name}_$t.err || { echo "$name $t failed"; tail -2 $O/v_${name}_$t.err; }
