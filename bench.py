@@ -348,6 +348,10 @@ def main():
                          "apply with the waves' phase time stamps collected; mean shader cycles per phase of the fused kernel -> FILE")
     ap.add_argument("--calibrate-traffic", action="store_true",
                     help="also launch k_axpby over a 1 GiB vector (known byte count) for PMC calibration")
+    ap.add_argument("--refine-layers", type=int, default=0, metavar="NZ",
+                    help="--workload mesh: re-make the swept mesh with its cross-section refined 2 x 2 and NZ uniform layers (mesh.refine_swept_mesh); "
+                         "the reference's cylinder8_44928e with NZ = 53 is 99 216 hexes on a REAL unstructured (CUBIT-paved) cross-section -- the "
+                         "closest thing to the absent cylinder8_99Ke_4ss_us.exo")
     ap.add_argument("--scramble", default="none", choices=["none", "order", "all"],
                     help="one GPU: the SAME mesh as an unstructured generator might hand it over (mesh.scramble_mesh) -- order: elements and "
                          "vertices in random order; all: also every element's local axes relabelled by a random rotation (no common sweep "
@@ -410,6 +414,9 @@ def main():
     elif args.workload == "mesh":   # one unstructured mesh, z-slab partition of its elements over the ranks (strong scaling)
         from ceedpetscsolid_amd.mesh import load_mesh_npz, partition_slabs, submesh
         mesh = load_mesh_npz(args.mesh)
+        if args.refine_layers > 0:
+            from ceedpetscsolid_amd.mesh import refine_swept_mesh
+            mesh = refine_swept_mesh(mesh, args.refine_layers)
         if world > 1:
             mesh = submesh(mesh, partition_slabs(mesh, world)[rank])
         bc = [s for s in (998, 999) if s in mesh.side_sets and len(mesh.side_sets[s])]
@@ -614,7 +621,7 @@ def main():
             "config": {"workload": (f"config 4: {args.problem}, hollow cylinder {args.nr}x{args.nth}x{args.nz} = "
                                     f"{mesh.nelem} hex per GPU (stand-in for cylinder8_99Ke_4ss_us.exo), degree {args.degree}, "
                                     f"Q={Q}, clamped ends, Jacobian apply y=J(u)x") if args.workload == "cylinder" else
-                                   (f"unstructured reference mesh {os.path.basename(args.mesh)}: {args.problem}, {mesh.nelem} hex on this rank, "
+                                   (f"unstructured reference mesh {os.path.basename(args.mesh)}" + (f", cross-section refined 2 x 2, {args.refine_layers} layers" if args.refine_layers > 0 else "") + f": {args.problem}, {mesh.nelem} hex on this rank, "
                                     f"degree {args.degree}, Q={Q}, side sets {bc} clamped, Jacobian apply y=J(u)x") if args.workload == "mesh" else
                                    (f"config 5 shape: {args.problem}, box {args.nr}x{args.nth}x{args.nz} = {mesh.nelem} hex per GPU, "
                                     f"degree {args.degree}, Q={Q}, z faces clamped, Jacobian apply y=J(u)x"),

@@ -522,6 +522,84 @@ def reorder_elements_locality(mesh: HexMesh, bits: int = 10) -> HexMesh:
     return HexMesh(mesh.coords, mesh.cells[perm], ss, vertex_gid=mesh.vertex_gid, name=mesh.name + "[morton]")
 
 
+def refine_swept_mesh(mesh: HexMesh, nz: int, tol: float = 1e-6) -> HexMesh:
+    """A swept (extruded along z) HEX8 mesh re-made with its CROSS-SECTION refined 2 x 2 and ``nz`` uniform layers: the unstructured
+    cross-section an external generator paved (e.g. the 468 CUBIT quads of the reference's cylinder8_44928e_2ss_us.exo) at another size --
+    a stand-in for the absent cylinder8_99Ke_4ss_us.exo that keeps a REAL unstructured topology (468 x 4 quads x 53 layers = 99 216 hexes).
+    New vertices on edges whose two ends lie on one circle about the z axis are put on that circle (the annulus keeps its shape).  Elements
+    are numbered layer by layer, within a layer in the generator's order (the four children of a quad together); side sets: the original
+    ids of the two end caps (found by their z), local faces k- / k+."""
+    z = mesh.coords[:, 2]
+    z0, z1 = z.min(), z.max()
+    bottom = np.abs(z - z0) < tol * max(1.0, z1 - z0)
+    quads = []                                            # cross-section quads, tensor order [v00, v10, v01, v11], from the elements on the bottom cap
+    for cell in mesh.cells:
+        onb = bottom[cell]
+        if onb.sum() != 4:
+            continue
+        for d in range(3):                                # the local direction of the sweep: the bottom vertices are one side of it
+            side0 = [c for c in range(8) if not (c >> d) & 1]
+            side1 = [c for c in range(8) if (c >> d) & 1]
+            for side in (side0, side1):
+                if onb[side].all():
+                    quads.append(cell[side])
+    quads = np.array(quads, dtype=np.int64)
+    assert len(quads) > 0 and mesh.nelem % len(quads) == 0, "not a swept mesh with a flat bottom cap"
+    used, inv = np.unique(quads.ravel(), return_inverse=True)
+    q = inv.reshape(-1, 4)
+    xy = mesh.coords[used, :2]
+    # orientation: counter-clockwise in (x, y) so that (i, j, z) is right-handed
+    a, b, c = xy[q[:, 1]] - xy[q[:, 0]], xy[q[:, 2]] - xy[q[:, 0]], None
+    flip = (a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]) < 0
+    q[flip] = q[flip][:, [1, 0, 3, 2]]
+    nv = len(xy)
+    edges = {}
+    pts = [xy]
+    def mid(u, v):
+        key = (min(u, v), max(u, v))
+        if key not in edges:
+            m = 0.5 * (xy[u] + xy[v])
+            ru, rv = np.hypot(*xy[u]), np.hypot(*xy[v])
+            if abs(ru - rv) < 1e-9 * max(ru, 1.0) and np.hypot(*m) > 0:       # both ends on one circle: stay on it
+                m = m * (ru / np.hypot(*m))
+            edges[key] = nv + len(edges)
+            pts.append(m[None, :])
+        return edges[key]
+    child = []
+    centres = []
+    for v00, v10, v01, v11 in q:
+        e0, e1, e2, e3 = mid(v00, v10), mid(v01, v11), mid(v00, v01), mid(v10, v11)   # bottom, top, left, right
+        centres.append((v00, v10, v01, v11, e0, e1, e2, e3))
+    nmid = len(edges)
+    mids = np.concatenate(pts[1:], axis=0) if nmid else np.zeros((0, 2))
+    cpts = []
+    for n, (v00, v10, v01, v11, e0, e1, e2, e3) in enumerate(centres):
+        cc = nv + nmid + n
+        cpts.append(0.25 * (mids[e0 - nv] + mids[e1 - nv] + mids[e2 - nv] + mids[e3 - nv]))
+        child += [[v00, e0, e2, cc], [e0, v10, cc, e3], [e2, cc, v01, e1], [cc, e3, e1, v11]]
+    xy2 = np.concatenate([xy, mids, np.array(cpts)], axis=0)
+    q2 = np.array(child, dtype=np.int64)
+    n2, nq = len(xy2), len(q2)
+    zs = np.linspace(z0, z1, nz + 1)
+    coords = np.concatenate([np.column_stack([xy2, np.full(n2, zz)]) for zz in zs], axis=0)
+    cells = np.concatenate([np.concatenate([q2 + k * n2, q2 + (k + 1) * n2], axis=1) for k in range(nz)], axis=0)
+    ss = {}
+    caps = {}
+    for sid, fs in mesh.side_sets.items():                 # which original id is which end cap
+        fs = np.asarray(fs)
+        if len(fs):
+            zc = mesh.coords[mesh.cells[fs[:, 0]]].mean(axis=1)[:, 2].mean()
+            caps["lo" if zc < 0.5 * (z0 + z1) else "hi"] = sid
+    e = np.arange(nq)
+    if "lo" in caps:
+        ss[caps["lo"]] = np.stack([e, np.full(nq, 4)], axis=1)
+    if "hi" in caps:
+        ss[caps["hi"]] = np.stack([e + (nz - 1) * nq, np.full(nq, 5)], axis=1)
+    out = HexMesh(coords, cells, ss, name=mesh.name + f"[cross-section 2x2, {nz} layers]")
+    _fix_orientation(out)
+    return out
+
+
 def key_bytes(keys: np.ndarray) -> np.ndarray:
     """Topological keys as fixed-size byte strings (hashable / sortable across ranks)."""
     k = np.ascontiguousarray(keys, dtype=np.int64)

@@ -231,7 +231,7 @@ def test_full_size_properties_config4(gpu):
     assert np.abs(J(t)).max() < 1e-11 * np.abs(jv).max()
 
 
-@pytest.mark.parametrize("which", ["config 4", "config 5 per-GPU block", "unstructured cylinder8_44928e"])
+@pytest.mark.parametrize("which", ["config 4", "config 5 per-GPU block", "unstructured cylinder8_44928e", "unstructured 99 216 hexes"])
 def test_full_size_matches_oracle(oracle, oracle_lib, gpu, which):
     """BASELINE configs 4 and 5 (one GPU's 32^3 block, p=6) at FULL size against the oracle itself (threaded over
     elements: a residual and a Jacobian apply of a ~20 M-dof problem take the CPU a few seconds each): the north-star
@@ -239,6 +239,10 @@ def test_full_size_matches_oracle(oracle, oracle_lib, gpu, which):
     import ctypes as C
     if which == "config 4":
         mesh, degree, bc = hollow_cylinder_mesh(10, 110, 90), 4, [998, 999]
+    elif which == "unstructured 99 216 hexes":   # config 4's SIZE on the reference's own CUBIT-paved cross-section (468 quads, refined 2 x 2, 53 layers)
+        from ceedpetscsolid_amd.mesh import refine_swept_mesh
+        mesh, degree, bc = refine_swept_mesh(load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_44928e_2ss_us.npz")), 53), 4, [998, 999]
+        assert mesh.nelem == 99216
     elif which.startswith("unstructured"):   # the largest unstructured reference cylinder present: CUBIT element and vertex order
         mesh, degree, bc = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_44928e_2ss_us.npz")), 4, [998, 999]
         assert mesh.nelem == 44928

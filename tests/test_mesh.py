@@ -194,3 +194,36 @@ def test_scrambled_mesh_is_the_same_discrete_problem(oracle):
         assert np.allclose(X, outs[0][0], atol=1e-12)
         assert np.linalg.norm(r - outs[0][1]) < 1e-12 * np.linalg.norm(outs[0][1])
         assert np.linalg.norm(j - outs[0][2]) < 1e-12 * np.linalg.norm(outs[0][2])
+
+
+def test_refined_swept_mesh_keeps_the_unstructured_cross_section():
+    """mesh.refine_swept_mesh (bench.py --workload mesh --refine-layers 53: the reference's 44 928-hex cylinder's CUBIT-paved cross-section
+    at config 4's size, 99 216 hexes): every quad of the cross-section becomes four, new boundary vertices stay on the circles, the
+    result is a conforming right-handed HEX8 mesh with the two end caps as side sets."""
+    from ceedpetscsolid_amd.mesh import load_mesh_npz, refine_swept_mesh
+    m = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_672e_4ss_us.npz"))
+    z = np.unique(np.round(m.coords[:, 2], 6))
+    nq = m.nelem // (len(z) - 1)
+    r = refine_swept_mesh(m, 7)
+    assert r.nelem == 4 * nq * 7
+    assert sorted(len(v) for k, v in r.side_sets.items() if k in (998, 999)) == [4 * nq, 4 * nq]
+    X = r.coords[r.cells]
+    dx = (X[:, 1::2] - X[:, 0::2]).mean(axis=1); dy = (X[:, [2, 3, 6, 7]] - X[:, [0, 1, 4, 5]]).mean(axis=1); dz = (X[:, 4:] - X[:, :4]).mean(axis=1)
+    det = np.einsum("ij,ij->i", np.cross(dx, dy), dz)
+    assert det.min() > 0
+    h = m.coords[:, 2].max() - m.coords[:, 2].min()
+    assert abs(det.sum() / (np.pi * 0.75 * h) - 1.0) < 0.01          # the annulus, polygonal boundary
+    rr = np.hypot(r.coords[:, 0], r.coords[:, 1])
+    assert rr.min() > 0.5 - 1e-9 and rr.max() < 1.0 + 1e-9
+    # conforming: every face belongs to one (boundary) or two elements, and the boundary faces are the caps and the two lateral surfaces
+    faces = []
+    for f in range(6):
+        axis, side = f // 2, f % 2
+        cs = [c for c in range(8) if ((c >> axis) & 1) == side]
+        faces.append(np.sort(r.cells[:, cs], axis=1))
+    faces = np.concatenate(faces)
+    _, cnt = np.unique(faces, axis=0, return_counts=True)
+    assert set(cnt.tolist()) <= {1, 2}
+    on_bdry = int((cnt == 1).sum())
+    edges_on_circles = on_bdry - 2 * 4 * nq                            # lateral faces = boundary edges of the cross-section x layers
+    assert edges_on_circles % 7 == 0 and edges_on_circles > 0
