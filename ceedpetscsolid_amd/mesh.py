@@ -549,7 +549,7 @@ def refine_swept_mesh(mesh: HexMesh, nz: int, tol: float = 1e-6) -> HexMesh:
     q = inv.reshape(-1, 4)
     xy = mesh.coords[used, :2]
     # orientation: counter-clockwise in (x, y) so that (i, j, z) is right-handed
-    a, b, c = xy[q[:, 1]] - xy[q[:, 0]], xy[q[:, 2]] - xy[q[:, 0]], None
+    a, b = xy[q[:, 1]] - xy[q[:, 0]], xy[q[:, 2]] - xy[q[:, 0]]
     flip = (a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]) < 0
     q[flip] = q[flip][:, [1, 0, 3, 2]]
     nv = len(xy)
