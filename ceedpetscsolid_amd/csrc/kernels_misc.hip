@@ -636,10 +636,14 @@ hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const u
                            int add, hipStream_t s, int max_blocks, const HaloUnpackArgs *unpack, const HaloPackFold *pack) {
   const int nun = unpack ? unpack->n : 0;
   if (nnodes <= 0 && nun <= 0) return hipSuccess;
-  unsigned nb_rows = (unsigned)((std::max(nnodes, 0) + 255) / 256);
+#ifndef CPS_ASM_BLOCK
+#define CPS_ASM_BLOCK 256    // (tuning hook) threads per workgroup of k_assemble: 128 and 512 measured in round 4, nothing
+#endif
+  constexpr int AB = CPS_ASM_BLOCK;
+  unsigned nb_rows = (unsigned)((std::max(nnodes, 0) + AB - 1) / AB);
   if (max_blocks > 0 && nb_rows > (unsigned)max_blocks) nb_rows = (unsigned)max_blocks;     // (grid-stride loop over the rows)
-  const unsigned nb_un = (unsigned)std::min((nun + 255) / 256, 1024);
-  hipLaunchKernelGGL(k_assemble, dim3(nb_rows + nb_un), dim3(256), 0, s, rowptr, cols, node_off, flags, evec, y, nnodes, add,
+  const unsigned nb_un = (unsigned)std::min((nun + AB - 1) / AB, 1024);
+  hipLaunchKernelGGL(k_assemble, dim3(nb_rows + nb_un), dim3(AB), 0, s, rowptr, cols, node_off, flags, evec, y, nnodes, add,
                      (int)nb_rows, unpack ? *unpack : HaloUnpackArgs{nullptr, nullptr, nullptr, nullptr, 0},
                      pack ? *pack : HaloPackFold{nullptr, nullptr, nullptr});
   return hipGetLastError();
