@@ -480,9 +480,9 @@ static int fused_prepare(CeedOperator op, CeedVector in, CeedVector out, bool ad
     if (err) return err;
   }
   F.flags = (op->mask_mode & 2) ? *flagsp : nullptr;
-  CHK(ceed_need_evec(c, (size_t)r->nelem * 3 * (size_t)r->elemsize));
+  a.evec_stride = 3 * (F.direct ? evec_block_records(ai.basis->P1d) : r->elemsize);
+  CHK(ceed_need_evec(c, (size_t)r->nelem * std::max((size_t)3 * (size_t)r->elemsize, (size_t)a.evec_stride)));   // (an aligned shell block may exceed P^3 records at small P)
   a.evec = c->evec;
-  a.evec_stride = 3 * (F.direct ? element_shell_size(ai.basis->P1d) : r->elemsize);
   return 0;
 }
 // one launch of the fused kernel over elements [e0, e0 + ne)
@@ -623,7 +623,7 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
       HIPCHK(launch_fused_grad(F.b->P1d, F.b->Q1d, F.qfkind, op->tables, aq, s, &nm));
       if (waves <= 0) return ceed_error("pipelined assembly: no persistent-wave count for P=%d Q=%d", F.b->P1d, F.b->Q1d);
     }
-    const int per_elem = F.direct ? element_shell_size(F.b->P1d) : F.r->elemsize;
+    const int per_elem = F.direct ? evec_block_records(F.b->P1d) : F.r->elemsize;
     PipeMap *PM = nullptr;
     const bool fs = F.qfkind == QF_HYPERFS_DF || F.qfkind == QF_HYPERFS_DF_DS || F.qfkind == QF_HYPERFS_F;
     const int mb = c->opt.pipe_mb > 0 ? c->opt.pipe_mb : (fs ? 160 : 90);     // MB of E-vector per segment (get_pipe)

@@ -128,7 +128,7 @@ int build_csr(CeedElemRestriction r, CsrMap &M, const unsigned char *prio, int s
     if (sl == 0xFFFFFFFFu) continue;
     // E position: e * elemsize + n, or in the shell-only E-vector of the direct-store mode e * shell size + shell rank
     const size_t e = i / (size_t)r->elemsize; const int ln = (int)(i % (size_t)r->elemsize);
-    cols[cursor[sl]++] = skipP > 0 ? (uint32_t)(e * (size_t)element_shell_size(skipP) + (size_t)node_shell_rank(ln, skipP)) : (uint32_t)i;
+    cols[cursor[sl]++] = skipP > 0 ? (uint32_t)(e * (size_t)evec_block_records(skipP) + (size_t)node_shell_rank(ln, skipP)) : (uint32_t)i;
   }
   M.nnodes = nn;
   // every L-vector entry is written by the assembly (or, for the skipped nodes, by the fused kernel)

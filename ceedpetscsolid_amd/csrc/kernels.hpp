@@ -142,6 +142,15 @@ static inline int node_shell_rank(int n, int P) {
 __host__ __device__
 #endif
 static inline int element_shell_size(int P) { return P * P * P - (P > 2 ? (P - 2) * (P - 2) * (P - 2) : 0); }
+// 24-byte records between the shell E-vector blocks of consecutive elements (tuning hook, round 4: 16 makes every block a whole number
+// of 128-byte lines -- measured, nothing: profiles/r04_ab_experiments.txt item 19)
+#ifndef CPS_EVEC_ALIGN
+#define CPS_EVEC_ALIGN 1
+#endif
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline int evec_block_records(int P) { return (element_shell_size(P) + CPS_EVEC_ALIGN - 1) / CPS_EVEC_ALIGN * CPS_EVEC_ALIGN; }
 
 struct TransferArgs {
   const uint32_t *off_c;  // coarse [nelem][Pc^3]
