@@ -385,6 +385,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # one node (the contract of --gpus N): RCCL's socket bootstrap -- torch's communicator and the library's own -- over the loopback
+        # interface, which always exists and always resolves (the container's hostname may not); the data goes over xGMI either way
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")   # "gloo": single-GPU rehearsal of the N > 1 path
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
