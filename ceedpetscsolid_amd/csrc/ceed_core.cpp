@@ -206,7 +206,8 @@ extern "C" int CeedXGraphDestroy(CeedXGraph *graph) {
   return 0;
 }
 
-void vec_drop_geo(CeedVector v) {
+void vec_drop_geo(CeedVector v) {   // = "the vector is being written"
+  v->version++;
   v->derived_valid = false;
   // retired, not freed: a recorded graph may hold these pointers in its kernel arguments (it refuses to replay --
   // CeedXGraphLaunch checks its GraphDeps -- but its nodes must never point at freed memory)

@@ -107,6 +107,7 @@ struct CeedVector_private {
   int refcount = 1;
   CeedInt length = 0;
   double *h = nullptr, *d = nullptr;   // current host / device storage
+  uint64_t version = 0;                // bumped by every write access through the API (caches keyed by a vector's contents check it)
   bool h_owned = false, d_owned = false;
   bool h_valid = false, d_valid = false;
   // provenance of a qdata vector: written by the SetupGeo operator from trilinear elements whose map coefficients
@@ -227,6 +228,15 @@ struct CeedOperator_private {
   int mask_mode = 0;
   // optional fine-side scale for transfers
   CeedVector scale = nullptr;
+  // transfer operators in OWNER form (ceed_operator.cpp: transfer_owner_map, transfer_weights)
+  std::vector<unsigned char> h_mask_fine;  // the fine side's Dirichlet mask (empty: none)
+  uint32_t *d_own_f = nullptr;             // [nelem][Pf^3] offset | flags of the fine nodes each element owns
+  bool own_full_cover = false;             // every entry of the fine L-vector has an owner
+  double *d_w = nullptr;                   // scale x local multiplicity per fine dof
+  size_t w_len = 0;
+  bool w_ready = false, w_unit = false;    // w_unit: every covered weight is 1 -- the kernels read none
+  CeedVector w_scale = nullptr;            // the scale vector and its version the weights were formed from
+  uint64_t w_version = 0;
   // split-phase apply (communication overlap): the first `ovl_lead` elements are the only
   // contributors of the priority nodes, which come first in the operator's own transpose map
   int ovl_lead = 0;

@@ -128,6 +128,8 @@ static void op_free_flags(CeedOperator o) {
   o->pipe_flags.clear();
   o->d_node_flags = o->d_node_flags_ovl = o->d_node_flags_shell = nullptr;
   o->h_mask.clear();
+  o->h_mask_fine.clear();
+  ceed_retire(o->ceed, o->d_own_f); o->d_own_f = nullptr;     // (recorded graphs may still read it)
   o->mask_mode = 0;
 }
 extern "C" int CeedOperatorDestroy(CeedOperator *op) {
@@ -148,6 +150,7 @@ extern "C" int CeedOperatorDestroy(CeedOperator *op) {
   op_free_flags(o);
   for (auto &pf : o->pack_folds) { ceed_retire(o->ceed, pf.d_ptr); ceed_retire(o->ceed, pf.d_slot); }
   o->ovl_csr.release();
+  ceed_retire(o->ceed, o->d_w);
   CeedVectorDestroy(&o->scale);
   for (auto &ev : o->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   ceed_unref(o->ceed);
@@ -715,6 +718,66 @@ static int apply_fused_with_halo(CeedOperator op, CeedVector in, CeedVector out,
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// The transfer operators in OWNER form (kernels_misc.hip, k_transfer)
+// ---------------------------------------------------------------------------
+// own_f[e][n] = offset | fine-side Dirichlet flags if element e is the FIRST (in element order) to hold fine node n, else
+// 0xFFFFFFFF.  Set-up time, host; rebuilt when the operator's mask changes.
+static int transfer_owner_map(CeedOperator op, CeedElemRestriction rf) {
+  if (op->d_own_f) return 0;
+  Ceed c = op->ceed;
+  if (c->capturing) return ceed_error("first apply of a transfer operator during graph capture: apply it once before recording");
+  const size_t n = rf->h_offsets.size();
+  std::vector<uint32_t> own(n ? n : 1);
+  std::vector<unsigned char> seen((size_t)rf->lsize, 0);
+  const std::vector<unsigned char> &mk = op->h_mask_fine;
+  size_t distinct = 0;
+  for (size_t i = 0; i < n; i++) {
+    const uint32_t o = (uint32_t)rf->h_offsets[i];
+    if (seen[o]) { own[i] = 0xFFFFFFFFu; continue; }
+    seen[o] = 1; distinct++;
+    uint32_t f = 0;
+    if (!mk.empty()) for (int k = 0; k < 3; k++) if (mk[(size_t)o + k]) f |= 1u << k;
+    own[i] = o | (f << OFF_FLAG_SHIFT);
+  }
+  op->own_full_cover = distinct * 3 == (size_t)rf->lsize;
+  HIPCHK(hipMalloc((void **)&op->d_own_f, sizeof(uint32_t) * own.size()));
+  HIPCHK(hipMemcpy(op->d_own_f, own.data(), sizeof(uint32_t) * own.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+// w = (fine-side scale, CeedXOperatorSetFineScale, or 1) x (local multiplicity of the fine restriction) per fine dof; *w = null
+// when every covered entry is 1 (the scale IS 1 / local multiplicity: one rank).  Recomputed when the scale vector was written
+// since (CeedVector_private::version) -- with one host read of a counter, so never while recording.
+static int transfer_weights(CeedOperator op, CeedElemRestriction rf, const double **w) {
+  Ceed c = op->ceed;
+  CeedVector sc = op->scale;
+  const uint64_t ver = sc ? sc->version : 0;
+  if (op->w_ready && op->w_scale == sc && op->w_version == ver) { *w = op->w_unit ? nullptr : op->d_w; return 0; }
+  if (c->capturing)
+    return ceed_error("transfer operator during graph capture: its fine-side scale was written since the last apply (or this is the first); "
+                      "apply the operator once before recording");
+  double *psc = nullptr;
+  if (sc) CHK(vec_dev(sc, false, &psc));
+  const size_t n = (size_t)rf->lsize;
+  if (op->w_len < n) {
+    ceed_retire(c, op->d_w); op->d_w = nullptr; op->w_len = 0;
+    HIPCHK(hipMalloc((void **)&op->d_w, sizeof(double) * (n ? n : 1)));
+    op->w_len = n;
+  }
+  int *d_cnt = nullptr, cnt = 1;
+  HIPCHK(hipMalloc((void **)&d_cnt, sizeof(int)));
+  HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(int), c->stream));
+  CHK(dev_zero(c, op->d_w, n));
+  HIPCHK(launch_multiplicity(rf->d_offsets, rf->nelem, rf->elemsize, rf->ncomp, rf->compstride, op->d_w, c->stream));
+  HIPCHK(launch_transfer_weights(op->d_w, psc, n, d_cnt, c->stream));
+  HIPCHK(hipMemcpyAsync(&cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));      // set-up time only
+  (void)hipFree(d_cnt);
+  op->w_unit = cnt == 0; op->w_scale = sc; op->w_version = ver; op->w_ready = true;
+  *w = op->w_unit ? nullptr : op->d_w;
+  return 0;
+}
+
 static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool add) {
   CHK(op_plan(op));
   CeedQFunction qf = op->qf;
@@ -781,28 +844,36 @@ static int op_apply_single(CeedOperator op, CeedVector in, CeedVector out, bool 
     if (in == out) return ceed_error("in-place operator apply is not supported");
     if (in->length < (pro ? rc : rf)->lsize || out->length < (pro ? rf : rc)->lsize) return ceed_error("transfer vector too short");
     TransferArgs a{};
-    double *px, *py, *psc = nullptr;
+    double *px, *py;
     CHK(vec_dev(in, false, &px));
     CHK(vec_dev(out, true, &py));
-    if (op->scale) { CHK(vec_dev(op->scale, false, &psc)); if (op->scale->length < rf->lsize) return ceed_error("scale vector too short"); }
-    // flagged arrays: *_in belongs to the input side's restriction, *_out to the output side's
-    const uint32_t *fin = op->d_off_flagged_in, *fout = op->d_off_flagged_out;
-    a.off_c = pro ? (fin ? fin : rc->d_offsets) : (fout ? fout : rc->d_offsets);
-    a.off_f = pro ? (fout ? fout : rf->d_offsets) : (fin ? fin : rf->d_offsets);
-    a.x = px; a.y = py; a.scale_f = psc; a.nelem = rc->nelem;
-    a.mask_in = (op->mask_mode & 1) ? 1 : 0; a.mask_out = (op->mask_mode & 2) ? 1 : 0;
-    // deterministic scatter, as for the residual / Jacobian: element results -> E-vector -> per-node sums in
-    // element order over the OUTPUT restriction's transpose map (masked entries travel as zeros)
-    CeedElemRestriction ro = pro ? rf : rc;
-    CHK(build_csr(ro, ro->csr, nullptr));
-    CHK(ceed_need_evec(op->ceed, (size_t)ro->nelem * ro->ncomp * ro->elemsize));
-    a.evec = op->ceed->evec;
-    if (!add && !ro->csr.full_cover) CHK(dev_zero(op->ceed, py, (size_t)out->length));
+    if (op->scale && op->scale->length < rf->lsize) return ceed_error("scale vector too short");
+    // OWNER form (kernels_misc.hip): the fine nodes each element owns, and the weights (null: all 1, the one-rank case)
+    CHK(transfer_owner_map(op, rf));
+    CHK(transfer_weights(op, rf, &a.w_f));
+    // the coarse side's flagged offsets: the input side of a prolongation, the output side of a restriction
+    const uint32_t *fc = pro ? op->d_off_flagged_in : op->d_off_flagged_out;
+    a.off_c = fc ? fc : rc->d_offsets;
+    a.own_f = op->d_own_f;
+    a.x = px; a.y = py; a.nelem = rc->nelem; a.add = add ? 1 : 0;
+    const int m_in = (op->mask_mode & 1) ? 1 : 0, m_out = (op->mask_mode & 2) ? 1 : 0;
+    a.mask_c = pro ? m_in : m_out; a.mask_f = pro ? m_out : m_in;
+    if (pro) {
+      // every fine node is stored by its owner: no E-vector, no sum
+      if (!add && !op->own_full_cover) CHK(dev_zero(op->ceed, py, (size_t)out->length));
+    } else {
+      // deterministic scatter on the COARSE side (Pc^3 nodes per element): element results -> E-vector -> per-node sums in
+      // element order over the coarse restriction's transpose map (masked entries travel as zeros)
+      CHK(build_csr(rc, rc->csr, nullptr));
+      CHK(ceed_need_evec(op->ceed, (size_t)rc->nelem * rc->ncomp * rc->elemsize));
+      a.evec = op->ceed->evec;
+      if (!add && !rc->csr.full_cover) CHK(dev_zero(op->ceed, py, (size_t)out->length));
+    }
     TimerScope ts(op, s);
     hipError_t e = launch_transfer(b->P1d, b->Q1d, pro, op->tables, a, s, &kname);
     if (e == hipErrorInvalidValue && !*kname) return ceed_error("no transfer kernel for Pc=%d Pf=%d", b->P1d, b->Q1d);
     HIPCHK(e);
-    HIPCHK(launch_assemble(ro->csr.d_rowptr, ro->csr.d_cols, ro->csr.d_node_off, nullptr, a.evec, py, ro->csr.nnodes, add ? 1 : 0, s));
+    if (!pro) HIPCHK(launch_assemble(rc->csr.d_rowptr, rc->csr.d_cols, rc->csr.d_node_off, nullptr, a.evec, py, rc->csr.nnodes, add ? 1 : 0, s));
     op->launches++;
     break;
   }
@@ -945,8 +1016,15 @@ extern "C" int CeedXOperatorSetDirichletMaskMode(CeedOperator op, CeedMemType mt
     op->h_mask.assign(mask, mask + lsize);
   } else if (op->plan == PLAN_PROLONG || op->plan == PLAN_RESTRICT) {
     if (!mask || !mask_out) return ceed_error("transfer operators need the input-side and the output-side mask");
-    CHK(make_flagged(op->in[0].rstr, mask, lsize, &op->d_off_flagged_in));
-    CHK(make_flagged(op->out[0].rstr, mask_out, lsize_out, &op->d_off_flagged_out));
+    // the COARSE side's flags ride in its offsets (input of a prolongation, output of a restriction); the FINE side's in the
+    // owner map (transfer_owner_map), rebuilt at the next apply
+    const bool pro = op->plan == PLAN_PROLONG;
+    if (pro) CHK(make_flagged(op->in[0].rstr, mask, lsize, &op->d_off_flagged_in));
+    else CHK(make_flagged(op->out[0].rstr, mask_out, lsize_out, &op->d_off_flagged_out));
+    CeedElemRestriction rf = pro ? op->out[0].rstr : op->in[0].rstr;
+    if ((pro ? lsize_out : lsize) < rf->lsize) return ceed_error("Dirichlet mask shorter than the L-vector");
+    const unsigned char *mf = pro ? mask_out : mask;
+    op->h_mask_fine.assign(mf, mf + rf->lsize);
   } else return ceed_error("this operator takes no Dirichlet mask");
   op->mask_mode = mode ? mode : 3;
   return 0;
@@ -957,6 +1035,7 @@ extern "C" int CeedXOperatorSetDirichletMask(CeedOperator op, CeedMemType mtype,
 // Fine-side multiplicity scale of the transfer operators (matops.c:149,176); NULL clears.
 extern "C" int CeedXOperatorSetFineScale(CeedOperator op, CeedVector scale) {
   CeedVectorDestroy(&op->scale);
+  op->w_ready = false;
   if (scale && scale != CEED_VECTOR_NONE) { op->scale = scale; scale->refcount++; }
   return 0;
 }

@@ -152,17 +152,20 @@ __host__ __device__
 #endif
 static inline int evec_block_records(int P) { return (element_shell_size(P) + CPS_EVEC_ALIGN - 1) / CPS_EVEC_ALIGN * CPS_EVEC_ALIGN; }
 
+// p-multigrid transfer in OWNER form (kernels_misc.hip, k_transfer): every fine node belongs to the first element that holds it.
 struct TransferArgs {
-  const uint32_t *off_c;  // coarse [nelem][Pc^3]
-  const uint32_t *off_f;  // fine   [nelem][Pf^3]
+  const uint32_t *off_c;  // coarse [nelem][Pc^3], the coarse side's Dirichlet flags in the top bits
+  const uint32_t *own_f;  // fine   [nelem][Pf^3]: offset | Dirichlet flags of the nodes this element OWNS, 0xFFFFFFFF for the others
   const double *x;
-  double *y;
-  const double *scale_f;  // optional per-dof scale on the fine side (multiplicity^-1), or null
+  double *y;              // prolong: the fine L-vector, stored by the owners
+  const double *w_f;      // per fine dof: (scale, e.g. multiplicity^-1 over all ranks) x (local multiplicity); null when every entry is 1
   int nelem;
-  int mask_in, mask_out;
-  double *evec;           // element results ([elem][output nodes][3], masked entries as zeros); launch_assemble() sums
-                          // them into y in element order
+  int mask_c, mask_f;     // honour the flags of the coarse / fine side
+  int add;                // prolong: y += (restrict: launch_assemble() adds)
+  double *evec;           // restrict: element results ([elem][Pc^3][3], masked entries as zeros); launch_assemble() sums them
+                          // into y in element order
 };
+hipError_t launch_transfer_weights(double *w, const double *scale, size_t n, int *n_not_unit, hipStream_t s);
 
 // x_c(xi) = a0 + a[c][0] xi + a[c][1] eta + a[c][2] zeta + a[c][3] xi eta + a[c][4] xi zeta + a[c][5] eta zeta + a[c][6] xi eta zeta
 // on [-1,1]^3: the 7 coefficients per component that the Jacobian d x / d xi needs, [c][m] per element.

@@ -166,71 +166,176 @@ hipError_t launch_setup_geo(int Q, const BasisTables &t, const SetupGeoArgs &a, 
 }
 
 // ===========================================================================
-// p-multigrid transfer (setuplibceed.c:847-862; matops.c:115-203).
-// PROLONG : coarse gather -> interp Pc->Pf (GLL points = fine nodes) -> fine
-//           scatter-add, each contribution times scale_f (the 1/multiplicity
-//           of matops.c:149 folded into the scatter).
-// RESTRICT: fine gather times scale_f (matops.c:176) -> interp^T -> coarse
-//           scatter-add.
+// p-multigrid transfer (setuplibceed.c:847-862; matops.c:115-203), round 5: pencil passes, OWNER form.
+//
+// A prolonged H1 field is single-valued at a fine node shared by several elements (the tensor-product interpolant on a
+// face sees that face's coarse nodes only), so sum_e contribution_e / multiplicity (matops.c:149) IS any one element's
+// contribution, to rounding.  Every fine node therefore has ONE owning element (the first that holds it, in element
+// order: TransferArgs::own_f):
+//   PROLONG : coarse gather -> interp Pc -> Pf in three pencil passes -> each element STORES the fine nodes it owns.
+//             No fine E-vector, no scatter-add, no k_assemble, no multVec read on one rank.
+//   RESTRICT: each element GATHERS the fine nodes it owns (the others read as zero) -> interp^T -> coarse E-vector
+//             -> launch_assemble() (27 nodes per element at Pc = 3: small, and bit-reproducible) -- exactly the transpose.
+// The per-dof weight w = (fine-side scale) x (local multiplicity) is 1 where the scale is 1 / multiplicity (one rank); it is
+// read (w_f) only when the host found an entry that differs: the interface nodes of an element partition, whose scale holds
+// the multiplicity over ALL ranks, or the extension-free form without a scale (plain libCEED semantics: w = multiplicity).
+//
+// One wave64 = one workgroup owns XferGeom::E elements.  In a pass a lane owns one line of an element along the contraction
+// direction, one component; tables are wave-uniform (kernarg segment -> SGPR operands).  LDS arrays are laid out so that the
+// lane-fastest index of the pass that reads them is contiguous: U0 [kc][jc][ic][c], U1 [kc][jc][if][c], U2 [kc][jf][if][c].
 // ===========================================================================
-template <int PC, int PF, bool PROLONG>
-__global__ __launch_bounds__(Geom<PF>::BLOCK) void k_transfer(const BasisTables tab, const TransferArgs a) {
-  using G = Geom<PF>;
-  constexpr int F3 = G::Q3, C3 = PC * PC * PC, TPE = G::TPE, EPB = G::EPB, BLOCK = G::BLOCK;
-  __shared__ double sB[PF * PC];
-  __shared__ double slab[EPB][9 * F3];
-  const int tid = threadIdx.x, el = tid / TPE, q = tid % TPE;
-  const int e = blockIdx.x * EPB + el;
-  const bool live = e < a.nelem;
-  double *R0 = slab[el], *R1 = R0 + 3 * F3, *R2 = R0 + 6 * F3;
-  stage_table<PF * PC, BLOCK>(tab.interp, sB);
-  const bool cnode = live && q < C3, fnode = live && q < F3;
-  uint32_t offc = cnode ? a.off_c[(size_t)e * C3 + q] : 0u;
-  uint32_t offf = fnode ? a.off_f[(size_t)e * F3 + q] : 0u;
-  if constexpr (PROLONG) {
-    if (q < C3) {
-      const uint32_t base = offc & OFF_MASK, fl = a.mask_in ? (offc >> OFF_FLAG_SHIFT) : 0u;
+constexpr uint32_t XFER_SKIP = 0xFFFFFFFFu;    // own_f entry of a fine node another element owns
+#ifndef CPS_XFER_E5
+#define CPS_XFER_E5 2
+#endif
+constexpr int xfer_group_elems(int PF) { return PF <= 3 ? 4 : (PF == 4 ? 4 : (PF == 5 ? CPS_XFER_E5 : 1)); }
+template <int PC, int PF> struct XferGeom {
+  static constexpr int C3 = PC * PC * PC, F2 = PF * PF, F3 = PF * PF * PF;
+  static constexpr int E = xfer_group_elems(PF);
+  static constexpr int N0 = 3 * C3, N1 = 3 * PC * PC * PF, N2 = 3 * PC * F2;   // doubles per element of U0, U1, U2
+  static constexpr int NI = E * PC * PC * 3, NJ = E * PC * PF * 3, NK = E * F2 * 3;   // pencils of the i-, j-, k-pass
+  static constexpr int KR = (NK + 63) / 64;                                    // rounds of the k-pass
+};
+
+template <int PC, int PF, bool PROLONG, bool WEIGHTED>
+__global__ __launch_bounds__(64) void k_transfer(const BasisTables tab, const TransferArgs a) {
+  using G = XferGeom<PC, PF>;
+  constexpr int C3 = G::C3, F2 = G::F2, F3 = G::F3, E = G::E, N0 = G::N0, N1 = G::N1, N2 = G::N2, KR = G::KR;
+  __shared__ double U0[E * N0], U1[E * N1], U2[E * N2];
+  const int lane = threadIdx.x;
+  const int e0 = blockIdx.x * E;
+  const int ne = min(E, a.nelem - e0);
+  // B[f][c] = tab.interp[f * PC + c]: value of coarse basis function c at fine node f (GLL points of the fine level)
+  // the k-pass columns of this lane and the fine nodes they hold: requested first, needed last (prolong) or at once (restrict)
+  uint32_t own[KR][PF];
 #pragma unroll
-      for (int c = 0; c < 3; c++) R0[c * C3 + q] = (cnode && !((fl >> c) & 1u)) ? a.x[base + c] : 0.;
+  for (int r = 0; r < KR; r++) {
+    const int t = lane + 64 * r, el = t / (3 * F2), n2 = (t % (3 * F2)) / 3;
+#pragma unroll
+    for (int k = 0; k < PF; k++) own[r][k] = t < ne * 3 * F2 ? a.own_f[(size_t)(e0 + el) * F3 + k * F2 + n2] : XFER_SKIP;
+  }
+  if constexpr (PROLONG) {
+    for (int t = lane; t < ne * N0; t += 64) {
+      const int el = t / N0, r = t % N0, n = r / 3, c = r % 3;
+      const uint32_t off = a.off_c[(size_t)(e0 + el) * C3 + n];
+      const bool dead = a.mask_c && ((off >> (OFF_FLAG_SHIFT + c)) & 1u);
+      U0[t] = dead ? 0. : a.x[(off & OFF_MASK) + c];
     }
     __syncthreads();
-    double v[3];
-    interp_forward<PC, PF>(q, R0, R1, R2, sB, v);
-    if (fnode) {
-      const uint32_t base = offf & OFF_MASK, fl = a.mask_out ? (offf >> OFF_FLAG_SHIFT) : 0u;
+    for (int t = lane; t < G::NI; t += 64) {          // i: U0[kc][jc][ic][c] -> U1[kc][jc][if][c]
+      const int el = t / (PC * PC * 3), r = t % (PC * PC * 3), m = r / 3, c = r % 3;
+      double u[PC];
 #pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const double val = a.scale_f ? v[c] * a.scale_f[base + c] : v[c];
-        a.evec[((size_t)e * F3 + q) * 3 + c] = ((fl >> c) & 1u) ? 0. : val;   // summed by launch_assemble()
+      for (int i = 0; i < PC; i++) u[i] = U0[el * N0 + (m * PC + i) * 3 + c];
+#pragma unroll
+      for (int f = 0; f < PF; f++) {
+        double s = 0.;
+#pragma unroll
+        for (int i = 0; i < PC; i++) s += tab.interp[f * PC + i] * u[i];
+        U1[el * N1 + (m * PF + f) * 3 + c] = s;
+      }
+    }
+    __syncthreads();
+    for (int t = lane; t < G::NJ; t += 64) {          // j: U1[kc][jc][if][c] -> U2[kc][jf][if][c]
+      const int el = t / (PC * PF * 3), r = t % (PC * PF * 3), kc = r / (PF * 3), ic = r % (PF * 3);
+      double u[PC];
+#pragma unroll
+      for (int j = 0; j < PC; j++) u[j] = U1[el * N1 + (kc * PC + j) * PF * 3 + ic];
+#pragma unroll
+      for (int f = 0; f < PF; f++) {
+        double s = 0.;
+#pragma unroll
+        for (int j = 0; j < PC; j++) s += tab.interp[f * PC + j] * u[j];
+        U2[el * N2 + (kc * PF + f) * PF * 3 + ic] = s;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < KR; r++) {                    // k: U2[kc][jf][if][c] -> the owned fine nodes of the column, stored
+      const int t = lane + 64 * r, el = t / (3 * F2), rem = t % (3 * F2), c = rem % 3;
+      if (t >= ne * 3 * F2) break;
+      double u[PC];
+#pragma unroll
+      for (int k = 0; k < PC; k++) u[k] = U2[el * N2 + k * F2 * 3 + rem];
+#pragma unroll
+      for (int f = 0; f < PF; f++) {
+        const uint32_t off = own[r][f];
+        if (off == XFER_SKIP) continue;
+        double s = 0.;
+#pragma unroll
+        for (int k = 0; k < PC; k++) s += tab.interp[f * PC + k] * u[k];
+        double *dst = a.y + (off & OFF_MASK) + c;
+        if constexpr (WEIGHTED) s *= a.w_f[(off & OFF_MASK) + c];
+        if (a.mask_f && ((off >> (OFF_FLAG_SHIFT + c)) & 1u)) s = 0.;
+        *dst = a.add ? *dst + s : s;
       }
     }
   } else {
-    if (q < F3) {
-      const uint32_t base = offf & OFF_MASK, fl = a.mask_in ? (offf >> OFF_FLAG_SHIFT) : 0u;
 #pragma unroll
-      for (int c = 0; c < 3; c++) {
-        double xv = (fnode && !((fl >> c) & 1u)) ? a.x[base + c] : 0.;
-        if (fnode && a.scale_f) xv *= a.scale_f[base + c];
-        R0[c * F3 + q] = xv;
+    for (int r = 0; r < KR; r++) {                    // k^T: the owned fine nodes of the column -> U2[kc][jf][if][c]
+      const int t = lane + 64 * r, el = t / (3 * F2), rem = t % (3 * F2), c = rem % 3;
+      if (t >= E * 3 * F2) break;
+      double v[PF];
+#pragma unroll
+      for (int f = 0; f < PF; f++) {
+        const uint32_t off = own[r][f];
+        const bool dead = off == XFER_SKIP || (a.mask_f && ((off >> (OFF_FLAG_SHIFT + c)) & 1u));
+        v[f] = dead ? 0. : a.x[(off & OFF_MASK) + c];
+        if constexpr (WEIGHTED) if (!dead) v[f] *= a.w_f[(off & OFF_MASK) + c];
+      }
+#pragma unroll
+      for (int k = 0; k < PC; k++) {
+        double s = 0.;
+#pragma unroll
+        for (int f = 0; f < PF; f++) s += tab.interp[f * PC + k] * v[f];
+        U2[el * N2 + k * F2 * 3 + rem] = s;
       }
     }
     __syncthreads();
-    double v[3];
-    interp_transpose<PC, PF>(q, R0, R1, R2, sB, v);
-    if (cnode) {
-      const uint32_t fl = a.mask_out ? (offc >> OFF_FLAG_SHIFT) : 0u;
+    for (int t = lane; t < G::NJ; t += 64) {          // j^T: U2[kc][jf][if][c] -> U1[kc][jc][if][c]
+      const int el = t / (PC * PF * 3), r = t % (PC * PF * 3), kc = r / (PF * 3), ic = r % (PF * 3);
+      double v[PF];
 #pragma unroll
-      for (int c = 0; c < 3; c++) a.evec[((size_t)e * C3 + q) * 3 + c] = ((fl >> c) & 1u) ? 0. : v[c];
+      for (int f = 0; f < PF; f++) v[f] = U2[el * N2 + (kc * PF + f) * PF * 3 + ic];
+#pragma unroll
+      for (int j = 0; j < PC; j++) {
+        double s = 0.;
+#pragma unroll
+        for (int f = 0; f < PF; f++) s += tab.interp[f * PC + j] * v[f];
+        U1[el * N1 + (kc * PC + j) * PF * 3 + ic] = s;
+      }
+    }
+    __syncthreads();
+    for (int t = lane; t < G::NI; t += 64) {          // i^T: U1[kc][jc][if][c] -> U0[kc][jc][ic][c]
+      const int el = t / (PC * PC * 3), r = t % (PC * PC * 3), m = r / 3, c = r % 3;
+      double v[PF];
+#pragma unroll
+      for (int f = 0; f < PF; f++) v[f] = U1[el * N1 + (m * PF + f) * 3 + c];
+#pragma unroll
+      for (int i = 0; i < PC; i++) {
+        double s = 0.;
+#pragma unroll
+        for (int f = 0; f < PF; f++) s += tab.interp[f * PC + i] * v[f];
+        U0[el * N0 + (m * PC + i) * 3 + c] = s;
+      }
+    }
+    __syncthreads();
+    // the group's block of the coarse E-vector [elem][node][3] is contiguous: whole-line stores; masked entries travel as zeros
+    for (int t = lane; t < ne * N0; t += 64) {
+      const int el = t / N0, r = t % N0, n = r / 3, c = r % 3;
+      const bool dead = a.mask_c && ((a.off_c[(size_t)(e0 + el) * C3 + n] >> (OFF_FLAG_SHIFT + c)) & 1u);
+      a.evec[(size_t)e0 * N0 + t] = dead ? 0. : U0[t];
     }
   }
 }
 template <int PC, int PF>
 static hipError_t transfer_t(bool prolong, const BasisTables &t, const TransferArgs &a, hipStream_t s) {
-  using G = Geom<PF>;
+  using G = XferGeom<PC, PF>;
   if (a.nelem <= 0) return hipSuccess;
-  const dim3 grid((a.nelem + G::EPB - 1) / G::EPB), block(G::BLOCK);
-  if (prolong) hipLaunchKernelGGL((k_transfer<PC, PF, true>), grid, block, 0, s, t, a);
-  else hipLaunchKernelGGL((k_transfer<PC, PF, false>), grid, block, 0, s, t, a);
+  const dim3 grid((a.nelem + G::E - 1) / G::E), block(64);
+  const bool w = a.w_f != nullptr;
+  if (prolong) { if (w) hipLaunchKernelGGL((k_transfer<PC, PF, true, true>), grid, block, 0, s, t, a); else hipLaunchKernelGGL((k_transfer<PC, PF, true, false>), grid, block, 0, s, t, a); }
+  else { if (w) hipLaunchKernelGGL((k_transfer<PC, PF, false, true>), grid, block, 0, s, t, a); else hipLaunchKernelGGL((k_transfer<PC, PF, false, false>), grid, block, 0, s, t, a); }
   return hipGetLastError();
 }
 hipError_t launch_transfer(int Pc, int Pf, bool prolong, const BasisTables &t, const TransferArgs &a,
@@ -244,6 +349,23 @@ hipError_t launch_transfer(int Pc, int Pf, bool prolong, const BasisTables &t, c
   CPS_TR(2, 3) CPS_TR(3, 4) CPS_TR(3, 5) CPS_TR(4, 5) CPS_TR(5, 6) CPS_TR(5, 7) CPS_TR(6, 7) CPS_TR(5, 8)
   CPS_TR(7, 8) CPS_TR(2, 4) CPS_TR(2, 5)
   return hipErrorInvalidValue;
+}
+// w[i] = (local multiplicity, as counted into w by launch_multiplicity) * (scale ? scale[i] : 1); *n_not_unit counts the
+// covered entries whose weight is not 1 (to 4 ulp: (1 / m) m rounds to 1 for the multiplicities of a mesh, not for every integer)
+__global__ void k_xfer_weights(double *w, const double *scale, size_t n, int *n_not_unit) {
+  int bad = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double m = w[i], v = scale ? m * scale[i] : m;
+    w[i] = v;
+    if (m != 0. && fabs(v - 1.) > 1e-15) bad = 1;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicAdd(n_not_unit, 1);
+}
+hipError_t launch_transfer_weights(double *w, const double *scale, size_t n, int *n_not_unit, hipStream_t s) {
+  if (!n) return hipSuccess;
+  size_t b = (n + 255) / 256;
+  hipLaunchKernelGGL(k_xfer_weights, dim3((unsigned)(b > 2048 ? 2048 : b)), dim3(256), 0, s, w, scale, n, n_not_unit);
+  return hipGetLastError();
 }
 
 // ===========================================================================
