@@ -201,130 +201,174 @@ template <int PC, int PF, bool PROLONG, bool WEIGHTED>
 __global__ __launch_bounds__(64) void k_transfer(const BasisTables tab, const TransferArgs a) {
   using G = XferGeom<PC, PF>;
   constexpr int C3 = G::C3, F2 = G::F2, F3 = G::F3, E = G::E, N0 = G::N0, N1 = G::N1, N2 = G::N2, KR = G::KR;
+  constexpr int SR = (E * N0 + 63) / 64;           // rounds of the coarse-side staging (a lane per coarse value)
   __shared__ double U0[E * N0], U1[E * N1], U2[E * N2];
   const int lane = threadIdx.x;
-  const int e0 = blockIdx.x * E;
-  const int ne = min(E, a.nelem - e0);
-  // B[f][c] = tab.interp[f * PC + c]: value of coarse basis function c at fine node f (GLL points of the fine level)
-  // the k-pass columns of this lane and the fine nodes they hold: requested first, needed last (prolong) or at once (restrict)
-  uint32_t own[KR][PF];
+  // XCD-aware: the groups are cut into 8 contiguous chunks; block b serves chunk b % 8 (blocks b and b + 8 share an XCD under the
+  // round-robin placement), so the elements that share coarse and fine nodes meet in one L2 (prolong p2 -> p4 at 99 000 hexes:
+  // 175 -> 82 MB fetched).  One group per workgroup, NOT a persistent loop: a wave that ends never waits for its stores, a wave
+  // that goes on to a next group does (its next loads count behind them in vmcnt) -- measured 47 -> 69 us for that prolongation.
+  const int ngroups = (a.nelem + E - 1) / E, chunk = (ngroups + 7) / 8;
+  const int grp = (int)(blockIdx.x % 8) * chunk + (int)(blockIdx.x / 8);
+  if (grp >= min(ngroups, (int)(blockIdx.x % 8 + 1) * chunk)) return;
+  // B[f][c] = tab.interp[f * PC + c]: value of coarse basis function c at fine node f (GLL points of the fine level).
+  // Loads are written as straight-line rounds (no data-dependent control flow around them: all are in flight together); a lane
+  // without work reads a valid entry of its group and discards it.
+  auto load_own = [&](int g, uint32_t (&o)[KR][PF]) {      // the k-pass columns of this lane: the fine nodes they own
+    const int e0 = g * E, ne = min(E, a.nelem - e0);
 #pragma unroll
-  for (int r = 0; r < KR; r++) {
-    const int t = lane + 64 * r, el = t / (3 * F2), n2 = (t % (3 * F2)) / 3;
+    for (int r = 0; r < KR; r++) {
+      const int t = lane + 64 * r, el = t / (3 * F2), n2 = (t % (3 * F2)) / 3;
+      const bool live = t < ne * 3 * F2;
 #pragma unroll
-    for (int k = 0; k < PF; k++) own[r][k] = t < ne * 3 * F2 ? a.own_f[(size_t)(e0 + el) * F3 + k * F2 + n2] : XFER_SKIP;
-  }
-  if constexpr (PROLONG) {
-    for (int t = lane; t < ne * N0; t += 64) {
-      const int el = t / N0, r = t % N0, n = r / 3, c = r % 3;
-      const uint32_t off = a.off_c[(size_t)(e0 + el) * C3 + n];
-      const bool dead = a.mask_c && ((off >> (OFF_FLAG_SHIFT + c)) & 1u);
-      U0[t] = dead ? 0. : a.x[(off & OFF_MASK) + c];
-    }
-    __syncthreads();
-    for (int t = lane; t < G::NI; t += 64) {          // i: U0[kc][jc][ic][c] -> U1[kc][jc][if][c]
-      const int el = t / (PC * PC * 3), r = t % (PC * PC * 3), m = r / 3, c = r % 3;
-      double u[PC];
-#pragma unroll
-      for (int i = 0; i < PC; i++) u[i] = U0[el * N0 + (m * PC + i) * 3 + c];
-#pragma unroll
-      for (int f = 0; f < PF; f++) {
-        double s = 0.;
-#pragma unroll
-        for (int i = 0; i < PC; i++) s += tab.interp[f * PC + i] * u[i];
-        U1[el * N1 + (m * PF + f) * 3 + c] = s;
+      for (int k = 0; k < PF; k++) {
+        const uint32_t v = a.own_f[(size_t)e0 * F3 + (live ? el * F3 + k * F2 + n2 : 0)];
+        o[r][k] = live ? v : XFER_SKIP;
       }
     }
-    __syncthreads();
-    for (int t = lane; t < G::NJ; t += 64) {          // j: U1[kc][jc][if][c] -> U2[kc][jf][if][c]
-      const int el = t / (PC * PF * 3), r = t % (PC * PF * 3), kc = r / (PF * 3), ic = r % (PF * 3);
-      double u[PC];
+  };
+  auto load_offc = [&](int g, uint32_t (&o)[SR]) {
+    const int e0 = g * E, ne = min(E, a.nelem - e0);
 #pragma unroll
-      for (int j = 0; j < PC; j++) u[j] = U1[el * N1 + (kc * PC + j) * PF * 3 + ic];
-#pragma unroll
-      for (int f = 0; f < PF; f++) {
-        double s = 0.;
-#pragma unroll
-        for (int j = 0; j < PC; j++) s += tab.interp[f * PC + j] * u[j];
-        U2[el * N2 + (kc * PF + f) * PF * 3 + ic] = s;
-      }
+    for (int r = 0; r < SR; r++) {
+      const int t = lane + 64 * r;
+      o[r] = a.off_c[(size_t)e0 * C3 + (t < ne * N0 ? t / 3 : 0)];
     }
-    __syncthreads();
+  };
+  uint32_t own[KR][PF], offc[SR];
+  load_own(grp, own);
+  load_offc(grp, offc);
+  {
+    const int e0 = grp * E, ne = min(E, a.nelem - e0);
+    if constexpr (PROLONG) {
+      double xin[SR];
 #pragma unroll
-    for (int r = 0; r < KR; r++) {                    // k: U2[kc][jf][if][c] -> the owned fine nodes of the column, stored
-      const int t = lane + 64 * r, el = t / (3 * F2), rem = t % (3 * F2), c = rem % 3;
-      if (t >= ne * 3 * F2) break;
-      double u[PC];
+      for (int r = 0; r < SR; r++) xin[r] = a.x[(offc[r] & OFF_MASK) + (lane + 64 * r) % 3];
 #pragma unroll
-      for (int k = 0; k < PC; k++) u[k] = U2[el * N2 + k * F2 * 3 + rem];
-#pragma unroll
-      for (int f = 0; f < PF; f++) {
-        const uint32_t off = own[r][f];
-        if (off == XFER_SKIP) continue;
-        double s = 0.;
-#pragma unroll
-        for (int k = 0; k < PC; k++) s += tab.interp[f * PC + k] * u[k];
-        double *dst = a.y + (off & OFF_MASK) + c;
-        if constexpr (WEIGHTED) s *= a.w_f[(off & OFF_MASK) + c];
-        if (a.mask_f && ((off >> (OFF_FLAG_SHIFT + c)) & 1u)) s = 0.;
-        *dst = a.add ? *dst + s : s;
+      for (int r = 0; r < SR; r++) {
+        const int t = lane + 64 * r, c = t % 3;
+        const bool dead = a.mask_c && ((offc[r] >> (OFF_FLAG_SHIFT + c)) & 1u);
+        if (t < ne * N0) U0[t] = dead ? 0. : xin[r];
       }
-    }
-  } else {
+      __syncthreads();
+      for (int t = lane; t < G::NI; t += 64) {          // i: U0[kc][jc][ic][c] -> U1[kc][jc][if][c]
+        const int el = t / (PC * PC * 3), r = t % (PC * PC * 3), m = r / 3, c = r % 3;
+        double u[PC];
 #pragma unroll
-    for (int r = 0; r < KR; r++) {                    // k^T: the owned fine nodes of the column -> U2[kc][jf][if][c]
-      const int t = lane + 64 * r, el = t / (3 * F2), rem = t % (3 * F2), c = rem % 3;
-      if (t >= E * 3 * F2) break;
-      double v[PF];
+        for (int i = 0; i < PC; i++) u[i] = U0[el * N0 + (m * PC + i) * 3 + c];
 #pragma unroll
-      for (int f = 0; f < PF; f++) {
-        const uint32_t off = own[r][f];
-        const bool dead = off == XFER_SKIP || (a.mask_f && ((off >> (OFF_FLAG_SHIFT + c)) & 1u));
-        v[f] = dead ? 0. : a.x[(off & OFF_MASK) + c];
-        if constexpr (WEIGHTED) if (!dead) v[f] *= a.w_f[(off & OFF_MASK) + c];
+        for (int f = 0; f < PF; f++) {
+          double s = 0.;
+#pragma unroll
+          for (int i = 0; i < PC; i++) s += tab.interp[f * PC + i] * u[i];
+          U1[el * N1 + (m * PF + f) * 3 + c] = s;
+        }
+      }
+      __syncthreads();
+      for (int t = lane; t < G::NJ; t += 64) {          // j: U1[kc][jc][if][c] -> U2[kc][jf][if][c]
+        const int el = t / (PC * PF * 3), r = t % (PC * PF * 3), kc = r / (PF * 3), ic = r % (PF * 3);
+        double u[PC];
+#pragma unroll
+        for (int j = 0; j < PC; j++) u[j] = U1[el * N1 + (kc * PC + j) * PF * 3 + ic];
+#pragma unroll
+        for (int f = 0; f < PF; f++) {
+          double s = 0.;
+#pragma unroll
+          for (int j = 0; j < PC; j++) s += tab.interp[f * PC + j] * u[j];
+          U2[el * N2 + (kc * PF + f) * PF * 3 + ic] = s;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < KR; r++) {                    // k: U2[kc][jf][if][c] -> the owned fine nodes of the column, stored
+        const int t = lane + 64 * r, el = t / (3 * F2), rem = t % (3 * F2), c = rem % 3;
+        if (t >= ne * 3 * F2) break;
+        double u[PC];
+#pragma unroll
+        for (int k = 0; k < PC; k++) u[k] = U2[el * N2 + k * F2 * 3 + rem];
+#pragma unroll
+        for (int f = 0; f < PF; f++) {
+          const uint32_t off = own[r][f];
+          if (off == XFER_SKIP) continue;
+          double s = 0.;
+#pragma unroll
+          for (int k = 0; k < PC; k++) s += tab.interp[f * PC + k] * u[k];
+          double *dst = a.y + (off & OFF_MASK) + c;
+          if constexpr (WEIGHTED) s *= a.w_f[(off & OFF_MASK) + c];
+          if (a.mask_f && ((off >> (OFF_FLAG_SHIFT + c)) & 1u)) s = 0.;
+          *dst = a.add ? *dst + s : s;
+        }
+      }
+    } else {
+      // all gathers of the wave's columns are issued together (lanes without an owned node read entry 0 and discard it)
+      double xv[KR][PF];
+#pragma unroll
+      for (int r = 0; r < KR; r++) {
+        const int c = ((lane + 64 * r) % (3 * F2)) % 3;
+#pragma unroll
+        for (int f = 0; f < PF; f++) {
+          const uint32_t off = own[r][f];
+          const uint32_t idx = off == XFER_SKIP ? 0u : (off & OFF_MASK) + c;
+          xv[r][f] = a.x[idx];
+          if constexpr (WEIGHTED) xv[r][f] *= a.w_f[idx];
+        }
       }
 #pragma unroll
-      for (int k = 0; k < PC; k++) {
-        double s = 0.;
+      for (int r = 0; r < KR; r++) {                    // k^T: the owned fine nodes of the column -> U2[kc][jf][if][c]
+        const int t = lane + 64 * r, el = t / (3 * F2), rem = t % (3 * F2), c = rem % 3;
+        double v[PF];
 #pragma unroll
-        for (int f = 0; f < PF; f++) s += tab.interp[f * PC + k] * v[f];
-        U2[el * N2 + k * F2 * 3 + rem] = s;
+        for (int f = 0; f < PF; f++) {
+          const uint32_t off = own[r][f];
+          const bool dead = off == XFER_SKIP || (a.mask_f && ((off >> (OFF_FLAG_SHIFT + c)) & 1u));
+          v[f] = dead ? 0. : xv[r][f];
+        }
+        if (t < E * 3 * F2) {
+#pragma unroll
+          for (int k = 0; k < PC; k++) {
+            double s = 0.;
+#pragma unroll
+            for (int f = 0; f < PF; f++) s += tab.interp[f * PC + k] * v[f];
+            U2[el * N2 + k * F2 * 3 + rem] = s;
+          }
+        }
       }
-    }
-    __syncthreads();
-    for (int t = lane; t < G::NJ; t += 64) {          // j^T: U2[kc][jf][if][c] -> U1[kc][jc][if][c]
-      const int el = t / (PC * PF * 3), r = t % (PC * PF * 3), kc = r / (PF * 3), ic = r % (PF * 3);
-      double v[PF];
+      __syncthreads();
+      for (int t = lane; t < G::NJ; t += 64) {          // j^T: U2[kc][jf][if][c] -> U1[kc][jc][if][c]
+        const int el = t / (PC * PF * 3), r = t % (PC * PF * 3), kc = r / (PF * 3), ic = r % (PF * 3);
+        double v[PF];
 #pragma unroll
-      for (int f = 0; f < PF; f++) v[f] = U2[el * N2 + (kc * PF + f) * PF * 3 + ic];
+        for (int f = 0; f < PF; f++) v[f] = U2[el * N2 + (kc * PF + f) * PF * 3 + ic];
 #pragma unroll
-      for (int j = 0; j < PC; j++) {
-        double s = 0.;
+        for (int j = 0; j < PC; j++) {
+          double s = 0.;
 #pragma unroll
-        for (int f = 0; f < PF; f++) s += tab.interp[f * PC + j] * v[f];
-        U1[el * N1 + (kc * PC + j) * PF * 3 + ic] = s;
+          for (int f = 0; f < PF; f++) s += tab.interp[f * PC + j] * v[f];
+          U1[el * N1 + (kc * PC + j) * PF * 3 + ic] = s;
+        }
       }
-    }
-    __syncthreads();
-    for (int t = lane; t < G::NI; t += 64) {          // i^T: U1[kc][jc][if][c] -> U0[kc][jc][ic][c]
-      const int el = t / (PC * PC * 3), r = t % (PC * PC * 3), m = r / 3, c = r % 3;
-      double v[PF];
+      __syncthreads();
+      for (int t = lane; t < G::NI; t += 64) {          // i^T: U1[kc][jc][if][c] -> U0[kc][jc][ic][c]
+        const int el = t / (PC * PC * 3), r = t % (PC * PC * 3), m = r / 3, c = r % 3;
+        double v[PF];
 #pragma unroll
-      for (int f = 0; f < PF; f++) v[f] = U1[el * N1 + (m * PF + f) * 3 + c];
+        for (int f = 0; f < PF; f++) v[f] = U1[el * N1 + (m * PF + f) * 3 + c];
 #pragma unroll
-      for (int i = 0; i < PC; i++) {
-        double s = 0.;
+        for (int i = 0; i < PC; i++) {
+          double s = 0.;
 #pragma unroll
-        for (int f = 0; f < PF; f++) s += tab.interp[f * PC + i] * v[f];
-        U0[el * N0 + (m * PC + i) * 3 + c] = s;
+          for (int f = 0; f < PF; f++) s += tab.interp[f * PC + i] * v[f];
+          U0[el * N0 + (m * PC + i) * 3 + c] = s;
+        }
       }
-    }
-    __syncthreads();
-    // the group's block of the coarse E-vector [elem][node][3] is contiguous: whole-line stores; masked entries travel as zeros
-    for (int t = lane; t < ne * N0; t += 64) {
-      const int el = t / N0, r = t % N0, n = r / 3, c = r % 3;
-      const bool dead = a.mask_c && ((a.off_c[(size_t)(e0 + el) * C3 + n] >> (OFF_FLAG_SHIFT + c)) & 1u);
-      a.evec[(size_t)e0 * N0 + t] = dead ? 0. : U0[t];
+      __syncthreads();
+      // the group's block of the coarse E-vector [elem][node][3] is contiguous: whole-line stores; masked entries travel as zeros
+#pragma unroll
+      for (int r = 0; r < SR; r++) {
+        const int t = lane + 64 * r, c = t % 3;
+        const bool dead = a.mask_c && ((offc[r] >> (OFF_FLAG_SHIFT + c)) & 1u);
+        if (t < ne * N0) a.evec[(size_t)e0 * N0 + t] = dead ? 0. : U0[t];
+      }
     }
   }
 }
@@ -332,7 +376,8 @@ template <int PC, int PF>
 static hipError_t transfer_t(bool prolong, const BasisTables &t, const TransferArgs &a, hipStream_t s) {
   using G = XferGeom<PC, PF>;
   if (a.nelem <= 0) return hipSuccess;
-  const dim3 grid((a.nelem + G::E - 1) / G::E), block(64);
+  const int ngroups = (a.nelem + G::E - 1) / G::E;
+  const dim3 grid(8 * ((ngroups + 7) / 8)), block(64);
   const bool w = a.w_f != nullptr;
   if (prolong) { if (w) hipLaunchKernelGGL((k_transfer<PC, PF, true, true>), grid, block, 0, s, t, a); else hipLaunchKernelGGL((k_transfer<PC, PF, true, false>), grid, block, 0, s, t, a); }
   else { if (w) hipLaunchKernelGGL((k_transfer<PC, PF, false, true>), grid, block, 0, s, t, a); else hipLaunchKernelGGL((k_transfer<PC, PF, false, false>), grid, block, 0, s, t, a); }
