@@ -68,6 +68,7 @@ class CeedLib:
         "CeedXOperatorSetFineScale", "CeedXOperatorSetOverlapSplit", "CeedXOperatorApplyPhase",
         "CeedXVectorPointwiseMult", "CeedXVectorAXPBY", "CeedXVectorDot", "CeedXVectorChebyshevUpdate",
         "CeedXGraphBeginCapture", "CeedXGraphEndCapture", "CeedXGraphLaunch", "CeedXGraphDestroy",
+        "CeedXOperatorApplyChebyshev", "CeedXOperatorApplyResidual",
         "CeedXVectorChebyshevStart", "CeedXVectorWAXPBY", "CeedXVectorDotTo", "CeedXScalarDivide", "CeedXVectorAXPBYScalars",
         "CeedXCsrCreate", "CeedXCsrAssemble", "CeedXCsrApply", "CeedXCsrGetDiagonal", "CeedXCsrDestroy",
         "CeedXCsrCreateRect", "CeedXCsrCreateProduct", "CeedXCsrGetPattern", "CeedXCsrUpdate", "CeedXCsrGetValues", "CeedXCsrInvertDenseSPD",

@@ -171,6 +171,8 @@ struct CeedElemRestriction_private {
   // recorded graphs and alternating operators (different Q on one restriction) keep valid pointers
   std::vector<PipeMap *> pipes;
   int interior_private = 0;  // 0: not checked yet; 1: every element-interior node has one contributor; -1: not so
+  uint32_t *d_int_off = nullptr;   // node offsets of the element-interior nodes, elements in order, int_per_elem each (direct-store mode:
+  int int_per_elem = 0;            // the epilogue kernels read those nodes' values from y -- build_interior_list)
 };
 
 struct CeedBasis_private {
@@ -268,6 +270,7 @@ void vec_drop_geo(CeedVector v);
 // restriction maps (ceed_restriction.cpp)
 int build_csr(CeedElemRestriction r, CsrMap &M, const unsigned char *prio, int skipP = 0);
 bool rstr_interior_private(CeedElemRestriction r, int P);
+int build_interior_list(CeedElemRestriction r, int P);
 int get_pipe(CeedElemRestriction r, const CsrMap &M, int E, int per_elem, int req_seg, int waves, int mb_per_segment, PipeMap **out);
 
 // halo internals the operator apply needs (ceed_halo.cpp)

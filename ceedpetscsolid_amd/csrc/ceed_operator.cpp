@@ -472,6 +472,7 @@ static int fused_prepare(CeedOperator op, CeedVector in, CeedVector out, bool ad
     if ((F.M->nskipped > 0) != F.direct) return ceed_error("split-phase map and direct-store mode disagree");
   } else if (F.direct) {
     CHK(build_csr(r, r->csr_shell, nullptr, ai.basis->P1d));
+    CHK(build_interior_list(r, ai.basis->P1d));
     F.M = &r->csr_shell; flagsp = &op->d_node_flags_shell;
   } else {
     CHK(build_csr(r, r->csr, nullptr));
@@ -552,7 +553,7 @@ static int get_pack_fold(CeedOperator op, CeedElemRestriction r, const CsrMap *M
 // segment k + 1 sits in the other queue and fills the chip as the waves of segment k retire (no kernel boundary between
 // fused kernels), every k_assemble but the last runs beside a fused kernel.  Every row is summed in contributor order by
 // one thread, whatever the segment: bitwise the serial result.
-static int apply_pipelined(CeedOperator op, const FusedApply &F, PipeMap *PM, const char **kname) {
+static int apply_pipelined(CeedOperator op, const FusedApply &F, PipeMap *PM, const char **kname, const EpilogueArgs *ep = nullptr) {
   Ceed c = op->ceed;
   hipStream_t s = c->stream;
   CHK(ceed_need_side_stream(c));
@@ -582,6 +583,14 @@ static int apply_pipelined(CeedOperator op, const FusedApply &F, PipeMap *PM, co
     HIPCHK(hipEventRecord(c->ev_seg[k], sk));
     if (k >= 1) HIPCHK(hipStreamWaitEvent(sk, c->ev_seg[k - 1], 0));
     const int r0 = PM->row_bound[k], nr = PM->row_bound[k + 1] - r0;
+    if (ep) {   // the consumer of the output in place of its store; the segment's own element-interior nodes ride along
+      EpilogueArgs ek = *ep;
+      const int nint = F.direct ? F.r->int_per_elem : 0;
+      ek.int_off = nint ? F.r->d_int_off + (size_t)PM->elem_bound[k] * nint : nullptr;
+      ek.n_int = (PM->elem_bound[k + 1] - PM->elem_bound[k]) * nint;
+      HIPCHK(launch_assemble_epi(PM->d_rowptr + r0, PM->d_cols, PM->d_node_off + r0, fl ? fl + r0 : nullptr, F.a.evec, nr, ek, sk,
+                                 k + 1 < nseg ? c->opt.pipe_blocks : 0));
+    } else
     HIPCHK(launch_assemble(PM->d_rowptr + r0, PM->d_cols, PM->d_node_off + r0, fl ? fl + r0 : nullptr, F.a.evec, F.py, nr, 0,
                            sk, k + 1 < nseg ? c->opt.pipe_blocks : 0));
   }
@@ -653,6 +662,53 @@ static int apply_fused_grad(CeedOperator op, CeedVector in, CeedVector out, bool
     CHK(halo_wait_arrivals(H, s));
     HIPCHK(launch_halo_unpack_add(halo_unpack_args(H), F.py, s));
   }
+  op->launches++;
+  return 0;
+}
+
+// The apply with its consumer fused behind it (CeedXOperatorApplyChebyshev / ApplyResidual): the launches of a whole apply in
+// overwrite mode, with k_assemble_epi in place of k_assemble -- the shell rows' sums and the element-interior values the fused kernel
+// stored into `t` go straight into the Chebyshev step (or the residual), y = t is never written or re-read as a whole.
+// *fused = false (nothing launched): the apply is not of that shape (nodes without an element: full_cover) -- the caller runs the two
+// steps one after the other.
+static int apply_fused_epilogue(CeedOperator op, CeedVector in, CeedVector t, EpilogueArgs ep, const char **kname, bool *fused) {
+  Ceed c = op->ceed;
+  hipStream_t s = c->stream;
+  FusedApply F;
+  *fused = false;
+  CHK(fused_prepare(op, in, t, false, false, F));
+  const CsrMap *M = F.M;
+  if (!M->full_cover) return 0;
+  const int nint = F.direct ? F.r->int_per_elem : 0;
+  if (F.direct && !F.r->d_int_off) return ceed_error("interior-node list of the restriction missing");
+  *fused = true;
+  ep.t = F.py;
+  TimerScope ts(op, s);
+  if (c->opt.pipe_segments != 0) {
+    int waves = 0;
+    {
+      FusedGradArgs aq = F.a;
+      aq.query_waves = &waves;
+      const char *nm = "";
+      HIPCHK(launch_fused_grad(F.b->P1d, F.b->Q1d, F.qfkind, op->tables, aq, s, &nm));
+      if (waves <= 0) return ceed_error("pipelined assembly: no persistent-wave count for P=%d Q=%d", F.b->P1d, F.b->Q1d);
+    }
+    const int per_elem = F.direct ? evec_block_records(F.b->P1d) : F.r->elemsize;
+    PipeMap *PM = nullptr;
+    const bool fs = F.qfkind == QF_HYPERFS_DF || F.qfkind == QF_HYPERFS_DF_DS || F.qfkind == QF_HYPERFS_F;
+    const int mb = c->opt.pipe_mb > 0 ? c->opt.pipe_mb : (fs ? 160 : 90);
+    CHK(get_pipe(F.r, *M, pencil_group_elems(F.b->Q1d), per_elem, std::max(c->opt.pipe_segments, 0), waves, mb, &PM));
+    if (PM && PM->nseg >= 2) {
+      CHK(apply_pipelined(op, F, PM, kname, &ep));
+      op->launches++;
+      return 0;
+    }
+  }
+  op->launch_info[0] = 1; op->launch_info[1] = 1; op->launch_info[2] = 1; op->launch_info[3] = F.r->nelem;
+  CHK(fused_launch(op, F, 0, F.r->nelem, 0, s, kname));
+  ep.int_off = nint ? F.r->d_int_off : nullptr;
+  ep.n_int = F.r->nelem * nint;
+  HIPCHK(launch_assemble_epi(M->d_rowptr, M->d_cols, M->d_node_off, F.flags, F.a.evec, M->nnodes, ep, s));
   op->launches++;
   return 0;
 }
@@ -1124,6 +1180,68 @@ extern "C" int CeedXOperatorApplyWithHalo(CeedOperator op, CeedVector in, CeedVe
   }
   const char *kname = "";
   CHK(apply_fused_with_halo(op, in, out, halo, &kname));
+  op->kernel_name = kname;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// The apply fused with its consumer (include/ceed.h; elasticity.c:539-552, 588-590)
+// ---------------------------------------------------------------------------
+static int epi_check(CeedOperator op, CeedVector in, CeedVector t, const char *who) {
+  if (op->composite) return ceed_error("%s: not provided for composite operators", who);
+  CHK(op_plan(op));
+  if (op->plan != PLAN_FUSED_GRAD || op->o_state >= 0) return ceed_error("%s is provided for the Jacobian operators", who);
+  if (!in || !t || in == t) return ceed_error("%s: the scratch vector t must be a vector of its own", who);
+  return 0;
+}
+extern "C" int CeedXOperatorApplyChebyshev(CeedOperator op, CeedVector in, CeedVector t, CeedVector x, CeedVector d, CeedVector r,
+                                           CeedVector b, CeedVector dinv, double c1, double c2, int assign_x) {
+  CHK(epi_check(op, in, t, "CeedXOperatorApplyChebyshev"));
+  const bool first = b && b != CEED_VECTOR_NONE;
+  const CeedInt n = x->length;
+  if (d->length != n || r->length != n || dinv->length != n || t->length != n || in->length != n || (first && b->length != n))
+    return ceed_error("CeedXOperatorApplyChebyshev: vector lengths differ");
+  if (first && (b == r || b == x || b == d || c2 != 0.)) return ceed_error("CeedXOperatorApplyChebyshev: a first step takes a right-hand side of its own and c2 = 0");
+  if (t == x || t == d || t == r || t == dinv || (first && t == b)) return ceed_error("CeedXOperatorApplyChebyshev: the scratch vector t aliases an operand");
+  EpilogueArgs ep{};
+  ep.kind = EPI_CHEB;
+  double *pb = nullptr, *pi;
+  CHK(vec_dev(dinv, false, &pi));
+  if (first) CHK(vec_dev(b, false, &pb));
+  CHK(vec_dev(r, true, &ep.r)); CHK(vec_dev(d, true, &ep.d)); CHK(vec_dev(x, true, &ep.x));
+  ep.r0 = pb; ep.dinv = pi; ep.c1 = c1; ep.c2 = c2; ep.assign_x = assign_x;
+  const char *kname = "";
+  bool fused = false;
+  CHK(apply_fused_epilogue(op, in, t, ep, &kname, &fused));
+  if (!fused) {     // a restriction that leaves L-vector entries without an element: the two steps, one after the other
+    CHK(apply_fused_grad(op, in, t, false, -1, &kname));
+    double *pt;
+    CHK(vec_dev(t, false, &pt));
+    HIPCHK(launch_cheb_update(ep.x, ep.d, ep.r, ep.r0, pt, ep.dinv, c1, c2, assign_x, (size_t)n, op->ceed->stream));
+  }
+  op->kernel_name = kname;
+  return 0;
+}
+extern "C" int CeedXOperatorApplyResidual(CeedOperator op, CeedVector in, CeedVector t, CeedVector b, CeedVector w) {
+  CHK(epi_check(op, in, t, "CeedXOperatorApplyResidual"));
+  const CeedInt n = w->length;
+  if (b->length != n || t->length != n || in->length != n) return ceed_error("CeedXOperatorApplyResidual: vector lengths differ");
+  if (t == b || t == w) return ceed_error("CeedXOperatorApplyResidual: the scratch vector t aliases an operand");
+  EpilogueArgs ep{};
+  ep.kind = EPI_RESID;
+  double *pb;
+  CHK(vec_dev(b, false, &pb));
+  CHK(vec_dev(w, true, &ep.w));
+  ep.b = pb;
+  const char *kname = "";
+  bool fused = false;
+  CHK(apply_fused_epilogue(op, in, t, ep, &kname, &fused));
+  if (!fused) {
+    CHK(apply_fused_grad(op, in, t, false, -1, &kname));
+    double *pt;
+    CHK(vec_dev(t, false, &pt));
+    HIPCHK(launch_waxpby(ep.w, 1.0, pb, -1.0, pt, (size_t)n, op->ceed->stream));
+  }
   op->kernel_name = kname;
   return 0;
 }

@@ -78,6 +78,7 @@ extern "C" int CeedElemRestrictionDestroy(CeedElemRestriction *rstr) {
   if (r == CEED_ELEMRESTRICTION_NONE) return 0;
   if (--r->refcount > 0) return 0;
   if (r->d_offsets) (void)hipFree(r->d_offsets);
+  if (r->d_int_off) (void)hipFree(r->d_int_off);
   r->csr.release();
   r->csr_shell.release();
   for (PipeMap *p : r->pipes) {
@@ -157,6 +158,22 @@ bool rstr_interior_private(CeedElemRestriction r, int P) {
     if (node_is_element_interior((int)(i % (size_t)r->elemsize), P) && cnt[(size_t)r->h_offsets[i]] != 1) return false;
   r->interior_private = 1;
   return true;
+}
+
+// Node offsets of the element-interior nodes (the ones the fused kernel stores itself), [elem][(P-2)^3] in element-local order.
+int build_interior_list(CeedElemRestriction r, int P) {
+  if (r->d_int_off || P < 3) return 0;
+  if (r->ceed->capturing) return ceed_error("first apply of an operator during graph capture: apply it once before recording");
+  const int m = (P - 2) * (P - 2) * (P - 2);
+  std::vector<uint32_t> lst((size_t)r->nelem * m);
+  size_t k = 0;
+  for (CeedInt e = 0; e < r->nelem; e++)
+    for (int n = 0; n < r->elemsize; n++)
+      if (node_is_element_interior(n, P)) lst[k++] = (uint32_t)r->h_offsets[(size_t)e * r->elemsize + n];
+  HIPCHK(hipMalloc((void **)&r->d_int_off, sizeof(uint32_t) * (lst.size() ? lst.size() : 1)));
+  HIPCHK(hipMemcpy(r->d_int_off, lst.data(), sizeof(uint32_t) * lst.size(), hipMemcpyHostToDevice));
+  r->int_per_elem = m;
+  return 0;
 }
 
 // Segments of the pipelined assembly: element ranges whose group counts are whole rounds of the fused kernel's persistent

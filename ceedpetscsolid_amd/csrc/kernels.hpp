@@ -236,6 +236,26 @@ hipError_t launch_assemble(const uint32_t *rowptr, const uint32_t *cols, const u
                            int add, hipStream_t s, int max_blocks = 0, const HaloUnpackArgs *unpack = nullptr,
                            const HaloPackFold *pack = nullptr);   // max_blocks: cap on the grid (pipelined assembly)
 
+// The same sum with an epilogue in place of the store of y (kernels_misc.hip, k_assemble_epi): the output of a fused apply consumed
+// where it is formed -- a Chebyshev step or the residual b - A v.
+enum EpilogueKind : int { EPI_NONE = 0, EPI_CHEB = 1, EPI_RESID = 2 };
+struct EpilogueArgs {
+  int kind;
+  const double *t;          // the apply's output vector: holds the ELEMENT-INTERIOR nodes' values (stored by the fused kernel) only
+  const uint32_t *int_off;  // node offsets of the element-interior nodes handled by this launch, n_int of them (0: none)
+  int n_int;
+  // EPI_CHEB: r = (r0 ? r0 : r) - t;  d = c1 dinv r + c2 d;  x = assign_x ? d : x + d
+  double *x, *d, *r;
+  const double *r0, *dinv;
+  double c1, c2;
+  int assign_x;
+  // EPI_RESID: w = b - t
+  double *w;
+  const double *b;
+};
+hipError_t launch_assemble_epi(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off, const unsigned char *flags,
+                               const double *evec, int nnodes, const EpilogueArgs &ep, hipStream_t s, int max_blocks = 0);
+
 // Coordinate-driven set-up operators (kernels_coord.hip): opSetupForce and opTrue of setuplibceed.c:555-623.
 struct CoordOpArgs {
   const uint32_t *off_x;   // [nelem][8] coordinate restriction

@@ -602,16 +602,24 @@ __global__ void k_axpby(double *y, double a, const double *x, double b, size_t n
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     y[i] = a * x[i] + (b == 0. ? 0. : b * y[i]);
 }
+// One dof of a Chebyshev step: r = rbase - t (has_t), d = c1 dinv r + c2 d, x = d or x + d.  ONE definition for the stand-alone
+// update (k_cheb_update) and the epilogue of the fused apply (k_assemble_epi): explicit operation order, no contraction left to
+// the compiler, so that both forms give the same bits.
+CPS_DEV void cheb_dof(double rbase, bool has_t, double ti, bool store_r, size_t i, double *x, double *d, double *r, const double *dinv,
+                      double c1, double c2, int assign_x) {
+#pragma clang fp contract(off)
+  const double ri = has_t ? rbase - ti : rbase;
+  if (store_r) r[i] = ri;
+  double di = (c1 * dinv[i]) * ri;
+  if (c2 != 0.) di = __builtin_fma(c2, d[i], di);
+  d[i] = di;
+  x[i] = assign_x ? di : x[i] + di;
+}
 __global__ void k_cheb_update(double *x, double *d, double *r, const double *r0, const double *t, const double *dinv, double c1,
                               double c2, int assign_x, size_t n) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    double ri = r0 ? r0[i] : r[i];          // r0: the right-hand side of a first step (r = b - t without a copy of b)
-    if (t) ri -= t[i];
-    if (t || r0) r[i] = ri;
-    const double di = c1 * dinv[i] * ri + (c2 == 0. ? 0. : c2 * d[i]);
-    d[i] = di;
-    x[i] = assign_x ? di : x[i] + di;
-  }
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    // r0: the right-hand side of a first step (r = b - t without a copy of b)
+    cheb_dof(r0 ? r0[i] : r[i], t != nullptr, t ? t[i] : 0., t || r0, i, x, d, r, dinv, c1, c2, assign_x);
 }
 __global__ void k_masked_copy(double *dst, const double *src, const unsigned char *mask, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -680,6 +688,65 @@ __global__ void k_assemble(const uint32_t *rowptr, const uint32_t *cols, const u
         pk.send[e & 0x3FFFFFFFu] = cmp == 0 ? a0 : (cmp == 1 ? a1 : a2);
       }
   }
+}
+
+// k_assemble with an EPILOGUE instead of the store of y (round 5): the operator's output t = A v is consumed where it is formed.
+//   EPI_CHEB : one step of the Chebyshev smoother (elasticity.c:539-552) -- r = (r0 or r) - t, d = c1 dinv r + c2 d, x = d or x + d
+//   EPI_RESID: w = b - t (the residual between the smoother and the restriction of a V-cycle)
+// Rows [0, nnodes): the shell nodes of the transpose map, summed in contributor order exactly as k_assemble does.  Workgroups
+// [nb_rows, gridDim.x): the dofs of the ELEMENT-INTERIOR nodes (int_off: their node offsets, elements in order), whose t the fused
+// kernel stored into `t` itself.  t at the shell nodes is never written.  The apply's input may be d (or x) itself: a row is
+// summed only after the last element that holds its node has finished (pipelined form: rows belong to the segment of their LAST
+// contributor), and no later element gathers it.
+__global__ void k_assemble_epi(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off, const unsigned char *flags,
+                               const double *evec, int nnodes, int nb_rows, const EpilogueArgs ep) {
+  if ((int)blockIdx.x >= nb_rows) {
+    const size_t n = (size_t)ep.n_int * 3;
+    for (size_t u = ((size_t)blockIdx.x - nb_rows) * blockDim.x + threadIdx.x; u < n; u += ((size_t)gridDim.x - nb_rows) * blockDim.x) {
+      const size_t i = (size_t)(ep.int_off[u / 3] & OFF_MASK) + u % 3;
+      const double ti = ep.t[i];
+      if (ep.kind == EPI_CHEB) cheb_dof(ep.r0 ? ep.r0[i] : ep.r[i], true, ti, true, i, ep.x, ep.d, ep.r, ep.dinv, ep.c1, ep.c2, ep.assign_x);
+      else ep.w[i] = ep.b[i] - ti;
+    }
+    return;
+  }
+  // One lane per DOF (three lanes per row): every stream of the epilogue -- r, dinv, d, x, b, w -- is then read and written 8 bytes
+  // per lane, contiguously over the wave (rows in ascending node order), instead of three 24-byte-strided accesses per lane; the
+  // three lanes of a row read its rowptr / cols entries together (one request) and each sums ITS component in contributor order
+  // (the same additions in the same order as k_assemble: same bits).
+  const size_t ndof = (size_t)nnodes * 3;
+  for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < ndof; u += (size_t)nb_rows * blockDim.x) {
+    const int r = (int)(u / 3), c = (int)(u % 3);
+    const uint32_t k0 = rowptr[r], k1 = rowptr[r + 1];
+    double a = 0.;
+    for (uint32_t k = k0; k < k1; k += 4) {
+      uint32_t cc[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) cc[j] = cols[k + j < k1 ? k + j : k1 - 1];
+      double v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = evec[(size_t)cc[j] * 3 + c];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (k + j < k1) a += v[j];
+    }
+    const unsigned fl = flags ? flags[r] : 0u;
+    const double ti = ((fl >> c) & 1u) ? 0. : a;
+    const size_t i = (size_t)(node_off[r] & OFF_MASK) + c;
+    if (ep.kind == EPI_CHEB) cheb_dof(ep.r0 ? ep.r0[i] : ep.r[i], true, ti, true, i, ep.x, ep.d, ep.r, ep.dinv, ep.c1, ep.c2, ep.assign_x);
+    else ep.w[i] = ep.b[i] - ti;
+  }
+}
+hipError_t launch_assemble_epi(const uint32_t *rowptr, const uint32_t *cols, const uint32_t *node_off, const unsigned char *flags,
+                               const double *evec, int nnodes, const EpilogueArgs &ep, hipStream_t s, int max_blocks) {
+  if (nnodes <= 0 && ep.n_int <= 0) return hipSuccess;
+  constexpr int AB = 256;
+  unsigned nb_rows = (unsigned)(((size_t)std::max(nnodes, 0) * 3 + AB - 1) / AB);     // a lane per dof
+  if (max_blocks > 0 && nb_rows > (unsigned)max_blocks) nb_rows = (unsigned)max_blocks;
+  unsigned nb_int = (unsigned)std::min<size_t>(((size_t)std::max(ep.n_int, 0) * 3 + AB - 1) / AB, 4096);
+  if (max_blocks > 0 && nb_int > (unsigned)max_blocks) nb_int = (unsigned)max_blocks;
+  hipLaunchKernelGGL(k_assemble_epi, dim3(nb_rows + nb_int), dim3(AB), 0, s, rowptr, cols, node_off, flags, evec, nnodes, (int)nb_rows, ep);
+  return hipGetLastError();
 }
 
 __global__ void k_halo_pack(const uint32_t *idx, int n, const double *y, double *buf) {

@@ -80,7 +80,7 @@ class NewtonPMG:
                  coarse: str = "cg", coarse_cheb_its: int = 40, coarse_cheb_ratio: float = 100.0, graph: bool = False,
                  amg_smooth_its: int = 3, amg_smooth_ratio: float = 10.0, amg_max_coarse_dofs: int = 1500, amg_coarse_cycles: int = 1,
                  ksp_rtol: float = 1e-10, snes_rtol: float = 1e-8, snes_maxit: int = 50, verbose: bool = False,
-                 line_search: str = "cp"):
+                 line_search: str = "cp", fuse_epilogue: bool = True):
         """``clamp``: {side_set_id: dict(translate=(..), axis=(..), angle_over_pi=..)} as
         -bc_clamp_<id>_translate / _rotate (cloptions.c:86-131); ids present in the problem's Dirichlet
         set but absent here are held at zero."""
@@ -92,6 +92,9 @@ class NewtonPMG:
         if line_search not in ("cp", "cp-petsc", "full"):
             raise ValueError(f"line_search {line_search!r}")
         self.line_search = line_search
+        # fuse_epilogue: the smoother's Chebyshev step and the V-cycle's residual formed in the epilogue of the Jacobian apply
+        # (CeedXOperatorApplyChebyshev / ApplyResidual: same bits as apply + update); one rank only (no interface sum in between)
+        self.fuse_epilogue = bool(fuse_epilogue)
         self.smooth_its, self.coarse_rtol, self.coarse_maxit = smooth_its, coarse_rtol, coarse_maxit
         # coarse solver: "cg" (Jacobi-PCG to coarse_rtol: accurate, but two host-synchronised dots per
         # iteration) or "chebyshev" (fixed polynomial over [emax/ratio, 1.1 emax]: no reductions, no host
@@ -315,6 +318,22 @@ class NewtonPMG:
             self.stats.jacobian_applies += 1
         self._halo_sum(lv, y)
 
+    def _fused_op(self, lv):
+        """The level's Jacobian operator if its consumers may be fused behind it: matrix-free level, no interface sum."""
+        if not self.fuse_epilogue or self.halos or self.rhalos or (lv == 0 and self.asm is not None):
+            return None
+        return self.p.levels[lv].opJacob
+
+    def level_residual(self, lv, b, x, z):
+        """z = b - A x on level lv (t: the level's scratch)."""
+        w, op = self.w[lv], self._fused_op(lv)
+        if op is not None:
+            self.L.chk(self.L.lib.CeedXOperatorApplyResidual(op.h, x.h, w["t"].h, b.h, z.h))
+            self.stats.jacobian_applies += 1
+        else:
+            self.A(lv, x, w["t"])
+            self.waxpby(z, 1.0, b, -1.0, w["t"])
+
     def _collect_bc_nodes(self):
         from .mesh import side_set_nodes
         lv = self.p.levels[self.p.fine]
@@ -464,16 +483,25 @@ class NewtonPMG:
         upd = self.L.lib.CeedXVectorChebyshevUpdate
         # first step: r = b - A x;  d = dinv r / theta;  x (+)= d      (fused: one pass over the vectors, b read in place)
         start = self.L.lib.CeedXVectorChebyshevStart
+        op = self._fused_op(lv)
+        fused = self.L.lib.CeedXOperatorApplyChebyshev
         if zero_guess:
             self.L.chk(start(x.h, d.h, r.h, b.h, None, w["dinv"].h, C.c_double(1.0 / theta), 1))
+        elif op is not None:      # the apply and the step in one: A x is consumed where it is formed
+            self.L.chk(fused(op.h, x.h, t.h, x.h, d.h, r.h, b.h, w["dinv"].h, C.c_double(1.0 / theta), C.c_double(0.0), 0))
+            self.stats.jacobian_applies += 1
         else:
             self.A(lv, x, t)
             self.L.chk(start(x.h, d.h, r.h, b.h, t.h, w["dinv"].h, C.c_double(1.0 / theta), 0))
         for k in range(1, its):
-            self.A(lv, d, t)
             rho_new = 1.0 / (2.0 * sigma - rho)
             # r -= A d;  d = (2 rho'/delta) dinv r + (rho' rho) d;  x += d
-            self.L.chk(upd(x.h, d.h, r.h, t.h, w["dinv"].h, C.c_double(2.0 * rho_new / delta), C.c_double(rho_new * rho), 0))
+            if op is not None:
+                self.L.chk(fused(op.h, d.h, t.h, x.h, d.h, r.h, None, w["dinv"].h, C.c_double(2.0 * rho_new / delta), C.c_double(rho_new * rho), 0))
+                self.stats.jacobian_applies += 1
+            else:
+                self.A(lv, d, t)
+                self.L.chk(upd(x.h, d.h, r.h, t.h, w["dinv"].h, C.c_double(2.0 * rho_new / delta), C.c_double(rho_new * rho), 0))
             rho = rho_new
 
     def coarse_solve(self, b, x):
@@ -528,8 +556,7 @@ class NewtonPMG:
             return
         w, wc = self.w[lv], self.w[lv - 1]
         self.chebyshev(lv, b, x, self.smooth_its, True)
-        self.A(lv, x, w["t"])
-        self.waxpby(w["z"], 1.0, b, -1.0, w["t"])                          # residual
+        self.level_residual(lv, b, x, w["z"])
         if lv == 1 and self.replicated:     # the coarse level lives in the global numbering, replicated: one all-gather in, a gather out
             self.p.restrict(lv, w["z"], self.wl0["b"])
             self._halo_sum(0, self.wl0["b"])

@@ -39,6 +39,7 @@ ap.add_argument("--amg-coarse-cycles", type=int, default=1, help="cycles of an i
 ap.add_argument("--amg-max-coarse", type=int, default=1500, help="rows up to which a level of the aggregation hierarchy is stored dense and inverted")
 ap.add_argument("--coarse-maxit", type=int, default=200)
 ap.add_argument("--coarse-rtol", type=float, default=1e-3)
+ap.add_argument("--no-fuse", action="store_true", help="A/B: the smoother's Chebyshev step and the V-cycle's residual as passes of their own")
 args = ap.parse_args()
 
 # several GPUs: `python -m torch.distributed.run --nproc-per-node N examples/solve_config3.py ...` -- one element
@@ -76,13 +77,14 @@ tr = tuple(float(t) for t in args.translate.split(","))
 solver = NewtonPMG(prob, clamp={s: (dict(translate=tr) if s == 998 else dict()) for s in bc_sides}, halo=halos, verbose=args.verbose and rank == 0,
                    coarse_maxit=args.coarse_maxit, coarse_rtol=args.coarse_rtol, coarse=args.coarse, graph=args.graph,
                    coarse_cheb_its=args.coarse_cheb_its, coarse_cheb_ratio=args.coarse_cheb_ratio,
-                   amg_smooth_its=args.amg_smooth_its, amg_smooth_ratio=args.amg_smooth_ratio, amg_max_coarse_dofs=args.amg_max_coarse, amg_coarse_cycles=args.amg_coarse_cycles)
+                   amg_smooth_its=args.amg_smooth_its, amg_smooth_ratio=args.amg_smooth_ratio, amg_max_coarse_dofs=args.amg_max_coarse, amg_coarse_cycles=args.amg_coarse_cycles,
+                   fuse_epilogue=not args.no_fuse)
 t_setup = time.perf_counter() - t0
 st = solver.solve(args.increments)
 u = solver.U.to_numpy().reshape(-1, 3)
 out = {"resource": ceed.resource, "problem": args.problem, "mesh": os.path.basename(args.mesh), "elements": mesh.nelem,
        "level_degrees": prob.degrees, "global_dofs_per_level": [prob.n_free(l) for l in range(len(prob.levels))],
-       "translate_998": list(tr), "coarse_solver": args.coarse, "vcycle_graph": args.graph, "load_increments": st.increments, "converged": st.converged, "snes_its": st.newton_its, "ksp_its": st.ksp_its,
+       "translate_998": list(tr), "coarse_solver": args.coarse, "vcycle_graph": args.graph, "fused_epilogue": not args.no_fuse, "load_increments": st.increments, "converged": st.converged, "snes_its": st.newton_its, "ksp_its": st.ksp_its,
        "coarse_cg_its": st.coarse_its, "jacobian_applies": st.jacobian_applies, "residual_evals": st.residual_evals, "coarse_spmv": st.coarse_spmv,
        "setup_s": t_setup, "snes_solve_s": st.seconds,
        "amg": ({k: solver.amg.info.get(k) for k in ("levels", "rows", "build_seconds", "per_level")} if getattr(solver, "amg", None) is not None else None),

@@ -304,6 +304,20 @@ CEED_EXTERN int CeedXVectorChebyshevStart(CeedVector x, CeedVector d, CeedVector
                                           CeedVector t /* or NULL */, CeedVector dinv,
                                           double c1, int assign_x);
 CEED_EXTERN int CeedXVectorWAXPBY(CeedVector w, double a, CeedVector x, double b, CeedVector y);
+/* The operator apply with its CONSUMER fused behind it (round 5): t = A in is  */
+/* used where it is formed and never stored as a whole (t: scratch L-vector;  */
+/* its contents afterwards are unspecified).  What the smoother and the       */
+/* V-cycle of elasticity.c:539-552, 588-590 do with a Jacobian apply:         */
+/*   ApplyChebyshev: r = (b or r) - A in;  d = c1 * dinv .* r + c2 * d;       */
+/*     x = d if assign_x else x + d.  `in` may be d or x themselves (the      */
+/*     Chebyshev recurrence applies the operator to its own direction).       */
+/*     Same bits as CeedOperatorApply + CeedXVectorChebyshevUpdate / Start.   */
+/*   ApplyResidual: w = b - A in.                                             */
+/* Single-rank L-vectors (no interface sum between the apply and its consumer).*/
+CEED_EXTERN int CeedXOperatorApplyChebyshev(CeedOperator op, CeedVector in, CeedVector t, CeedVector x, CeedVector d,
+                                            CeedVector r, CeedVector b /* or NULL */, CeedVector dinv,
+                                            double c1, double c2, int assign_x);
+CEED_EXTERN int CeedXOperatorApplyResidual(CeedOperator op, CeedVector in, CeedVector t, CeedVector b, CeedVector w);
 /* Assembled sparse operator on L-vectors: the coarse level of the multigrid. */
 /* The reference builds it by finite-difference colouring of the p=1 operator */
 /* (misc.c:151-183, elasticity.c:457-483) and hands it to GAMG; here the      */

@@ -1135,6 +1135,22 @@ int CeedXVectorChebyshevUpdate(CeedVector x, CeedVector d, CeedVector r, CeedVec
   }
   return 0;
 }
+/* The fused forms of the product (include/ceed.h), restated as what they fuse: the apply, then its consumer. */
+int CeedXOperatorApplyChebyshev(CeedOperator op, CeedVector in, CeedVector t, CeedVector x, CeedVector d, CeedVector r, CeedVector b,
+                                CeedVector dinv, double c1, double c2, int assign_x) {
+  int ierr = CeedOperatorApply(op, in, t, CEED_REQUEST_IMMEDIATE);
+  if (ierr) return ierr;
+  if (b && b != CEED_VECTOR_NONE) {
+    if (c2 != 0.) return oracle_error("CeedXOperatorApplyChebyshev: a first step (b given) has c2 = 0");
+    return CeedXVectorChebyshevStart(x, d, r, b, t, dinv, c1, assign_x);
+  }
+  return CeedXVectorChebyshevUpdate(x, d, r, t, dinv, c1, c2, assign_x);
+}
+int CeedXOperatorApplyResidual(CeedOperator op, CeedVector in, CeedVector t, CeedVector b, CeedVector w) {
+  int ierr = CeedOperatorApply(op, in, t, CEED_REQUEST_IMMEDIATE);
+  if (ierr) return ierr;
+  return CeedXVectorWAXPBY(w, 1.0, b, -1.0, t);
+}
 int CeedXVectorDot(CeedVector x, CeedVector y, CeedVector weight, double *result) {
   vec_ensure(x); vec_ensure(y);
   double s = 0.;

@@ -1,0 +1,1 @@
+#include "petsc_types_stub.h"
