@@ -94,7 +94,12 @@ class NewtonPMG:
         self.line_search = line_search
         # fuse_epilogue: the smoother's Chebyshev step and the V-cycle's residual formed in the epilogue of the Jacobian apply
         # (CeedXOperatorApplyChebyshev / ApplyResidual: same bits as apply + update); one rank only (no interface sum in between)
-        self.fuse_epilogue = bool(fuse_epilogue)
+        # "auto" (either switch): the forms give the same bits, so the first call of record_preconditioner TIMES the V-cycle in each
+        # combination on the problem at hand and keeps the fastest (measured, 99 000 hexes at p = 4: eager + fused 6.1 ms, graph +
+        # two passes 6.4-6.6, graph + fused 6.8-7.0, eager + two passes 6.5-6.7; 5 580 hexes: the replayed graph wins by 2x)
+        self._auto_fuse = fuse_epilogue == "auto"
+        self.fuse_epilogue = True if self._auto_fuse else bool(fuse_epilogue)
+        self.tuning = None
         self.smooth_its, self.coarse_rtol, self.coarse_maxit = smooth_its, coarse_rtol, coarse_maxit
         # coarse solver: "cg" (Jacobi-PCG to coarse_rtol: accurate, but two host-synchronised dots per
         # iteration) or "chebyshev" (fixed polynomial over [emax/ratio, 1.1 emax]: no reductions, no host
@@ -103,7 +108,10 @@ class NewtonPMG:
         # graph=True: record the V-cycle (a fixed sequence of ~150 small launches once the eigenvalue
         # estimates are known) into a hipGraph per Newton step and replay it per Krylov iteration;
         # needs the reduction-free Chebyshev coarse solver
-        self.graph = bool(graph)
+        self._auto_graph = graph == "auto"
+        self.graph = False if self._auto_graph else bool(graph)
+        if self._auto_graph and coarse not in ("chebyshev", "assembled", "amg"):
+            self._auto_graph = False               # (the CG coarse solve cannot be recorded: eager)
         if self.graph and coarse not in ("chebyshev", "assembled", "amg"):
             raise ValueError("graph=True needs coarse='chebyshev', 'assembled' or 'amg' (the CG coarse solve reads dot products on the host)")
         # coarse="assembled": the same Chebyshev polynomial, but on the ASSEMBLED p=1 matrix (assembly.py): a
@@ -123,6 +131,8 @@ class NewtonPMG:
             self.replicated = bool(many and coarse == "amg")
             if self.replicated and self.graph:
                 raise ValueError("graph=True: the replicated coarse level moves vectors with torch.distributed, which cannot be recorded")
+            if self.replicated:
+                self._auto_graph = False
             self.asm = AssembledLevel(prob, 0, replicate=halo[0] if self.replicated else None)
             if coarse == "amg":
                 from .amg import AggregationAMG
@@ -161,6 +171,8 @@ class NewtonPMG:
                 raise ValueError("one RcclHalo per multigrid level expected")
             if self.graph and self.rhalos is None:
                 raise ValueError("graph=True on several ranks needs the library's exchange (torch.distributed calls cannot be recorded)")
+            if self.rhalos is None:
+                self._auto_graph = False
             if self.rhalos is not None and lead_elements > 0:      # split-phase Jacobians: exchange under the interior elements
                 for lv, level in enumerate(prob.levels):
                     level.opJacob.set_overlap_split(int(lead_elements), self.halos[lv].interface_dof_mask())
@@ -576,11 +588,46 @@ class NewtonPMG:
         self.axpby(x, 1.0, w["z"], 1.0)
         self.chebyshev(lv, b, x, self.smooth_its, False)
 
+    def _autotune_vcycle(self, r, z, reps=2):
+        """Pick (fused consumers?, replayed graph?) by timing the V-cycle in every combination left open ("auto")."""
+        import time
+        top = self.nlev - 1
+        keep = (self.stats.jacobian_applies, self.stats.coarse_its, self.stats.coarse_spmv)
+        fuses = (True, False) if (self._auto_fuse and self._fused_op(top) is not None) else (self.fuse_epilogue,)
+        graphs = (True, False) if self._auto_graph else (self.graph,)
+        times = {}
+        for f in fuses:
+            self.fuse_epilogue = f
+            self.vcycle(top, r, z)                 # first-use set-up of this form is neither recorded nor timed
+            for g in graphs:
+                run, gr = (lambda: self.vcycle(top, r, z)), None
+                if g:
+                    gr = self.ceed.capture(run)
+                    run = gr.launch
+                run(); self.ceed.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    run()
+                self.ceed.synchronize()
+                times[(f, g)] = (time.perf_counter() - t0) / reps
+                if gr is not None:
+                    gr.destroy()
+        (self.fuse_epilogue, self.graph), _ = min(times.items(), key=lambda kv: kv[1])
+        self._auto_fuse = self._auto_graph = False
+        self._pc_warm = True
+        self.stats.jacobian_applies, self.stats.coarse_its, self.stats.coarse_spmv = keep
+        self.tuning = {"fused_epilogue": self.fuse_epilogue, "vcycle_graph": self.graph,
+                       "vcycle_ms": {f"{'fused' if f else 'two_pass'}+{'graph' if g else 'eager'}": 1e3 * t for (f, g), t in times.items()}}
+        if self.verbose:
+            print("V-cycle forms (ms):", self.tuning["vcycle_ms"], "->", "fused" if self.fuse_epilogue else "two passes", "+", "graph" if self.graph else "eager")
+
     def record_preconditioner(self, r, z):
         """Capture vcycle(r -> z) for the current diagonals / eigenvalue bounds (call after setup_preconditioner)."""
         if self._pc_graph is not None:
             self._pc_graph.destroy()
             self._pc_graph = None
+        if (self._auto_fuse or self._auto_graph) and self.nlev > 1:
+            self._autotune_vcycle(r, z)
         if not self.graph or self.nlev == 1:
             return
         top = self.nlev - 1

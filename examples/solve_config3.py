@@ -31,6 +31,7 @@ ap.add_argument("--oracle", action="store_true", help="TESTS ONLY: run the same 
 ap.add_argument("--verbose", action="store_true")
 ap.add_argument("--coarse", default="cg", choices=["cg", "chebyshev", "assembled", "amg"])
 ap.add_argument("--graph", action="store_true", help="replay the V-cycle as a hipGraph")
+ap.add_argument("--auto", action="store_true", help="time the V-cycle eager / replayed, fused / two-pass at the first Newton step and keep the fastest")
 ap.add_argument("--coarse-cheb-its", type=int, default=40)
 ap.add_argument("--coarse-cheb-ratio", type=float, default=100.0)
 ap.add_argument("--amg-smooth-its", type=int, default=3)
@@ -75,16 +76,16 @@ if world > 1:
              for lv in prob.levels]
 tr = tuple(float(t) for t in args.translate.split(","))
 solver = NewtonPMG(prob, clamp={s: (dict(translate=tr) if s == 998 else dict()) for s in bc_sides}, halo=halos, verbose=args.verbose and rank == 0,
-                   coarse_maxit=args.coarse_maxit, coarse_rtol=args.coarse_rtol, coarse=args.coarse, graph=args.graph,
+                   coarse_maxit=args.coarse_maxit, coarse_rtol=args.coarse_rtol, coarse=args.coarse, graph="auto" if args.auto else args.graph,
                    coarse_cheb_its=args.coarse_cheb_its, coarse_cheb_ratio=args.coarse_cheb_ratio,
                    amg_smooth_its=args.amg_smooth_its, amg_smooth_ratio=args.amg_smooth_ratio, amg_max_coarse_dofs=args.amg_max_coarse, amg_coarse_cycles=args.amg_coarse_cycles,
-                   fuse_epilogue=not args.no_fuse)
+                   fuse_epilogue="auto" if args.auto else not args.no_fuse)
 t_setup = time.perf_counter() - t0
 st = solver.solve(args.increments)
 u = solver.U.to_numpy().reshape(-1, 3)
 out = {"resource": ceed.resource, "problem": args.problem, "mesh": os.path.basename(args.mesh), "elements": mesh.nelem,
        "level_degrees": prob.degrees, "global_dofs_per_level": [prob.n_free(l) for l in range(len(prob.levels))],
-       "translate_998": list(tr), "coarse_solver": args.coarse, "vcycle_graph": args.graph, "fused_epilogue": not args.no_fuse, "load_increments": st.increments, "converged": st.converged, "snes_its": st.newton_its, "ksp_its": st.ksp_its,
+       "translate_998": list(tr), "coarse_solver": args.coarse, "vcycle_graph": solver.graph, "fused_epilogue": solver.fuse_epilogue, "vcycle_tuning": solver.tuning, "load_increments": st.increments, "converged": st.converged, "snes_its": st.newton_its, "ksp_its": st.ksp_its,
        "coarse_cg_its": st.coarse_its, "jacobian_applies": st.jacobian_applies, "residual_evals": st.residual_evals, "coarse_spmv": st.coarse_spmv,
        "setup_s": t_setup, "snes_solve_s": st.seconds,
        "amg": ({k: solver.amg.info.get(k) for k in ("levels", "rows", "build_seconds", "per_level")} if getattr(solver, "amg", None) is not None else None),

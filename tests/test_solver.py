@@ -99,6 +99,60 @@ def test_config3_full_solve_on_the_device(gpu):
     assert 0.09 < umax[2] <= 0.1 + 1e-9 and 0.045 < umax[1] < 0.06 and umax[0] < 0.01, umax
 
 
+def test_fused_apply_entries_on_the_oracle_are_their_two_steps(oracle):
+    """CeedXOperatorApplyChebyshev / ApplyResidual as the oracle restates them: CeedOperatorApply, then the vector update."""
+    import ctypes as C
+    from ceedpetscsolid_amd.mesh import box_mesh
+    p = SolidProblem(oracle, box_mesh(2, 2, 2), 2, "linElas", nu=0.3, E=1.0, bc_sides=[1])
+    L, op, n = oracle.L, p.levels[p.fine].opJacob, p.lsize()
+    rng = np.random.default_rng(0)
+    free = (p.levels[p.fine].mask == 0).astype(np.float64)
+    a = {k: rng.uniform(-1, 1, n) * free for k in ("x", "d", "r", "b", "dinv")}
+    for first in (False, True):
+        res = []
+        for fused in (False, True):
+            v = {k: oracle.vector(n).set_array(a[k]) for k in a}
+            t = oracle.vector(n)
+            src = v["x"] if first else v["d"]
+            c1, c2 = C.c_double(0.4), C.c_double(0.0 if first else 0.3)
+            if fused:
+                L.chk(L.lib.CeedXOperatorApplyChebyshev(op.h, src.h, t.h, v["x"].h, v["d"].h, v["r"].h, v["b"].h if first else None, v["dinv"].h, c1, c2, 0))
+            else:
+                op.apply(src, t)
+                if first:
+                    L.chk(L.lib.CeedXVectorChebyshevStart(v["x"].h, v["d"].h, v["r"].h, v["b"].h, t.h, v["dinv"].h, c1, 0))
+                else:
+                    L.chk(L.lib.CeedXVectorChebyshevUpdate(v["x"].h, v["d"].h, v["r"].h, t.h, v["dinv"].h, c1, c2, 0))
+            res.append([v[k].to_numpy() for k in ("x", "d", "r")])
+        for u, w in zip(*res):
+            assert np.array_equal(u, w)
+    X, B, T, W = oracle.vector(n).set_array(a["x"]), oracle.vector(n).set_array(a["b"]), oracle.vector(n), oracle.vector(n)
+    L.chk(L.lib.CeedXOperatorApplyResidual(op.h, X.h, T.h, B.h, W.h))
+    Y = oracle.vector(n); op.apply(X, Y)
+    assert np.array_equal(W.to_numpy(), a["b"] - Y.to_numpy())
+    p.destroy()
+
+
+@pytest.mark.gpu
+def test_vcycle_form_is_chosen_by_measurement_and_does_not_change_the_solve(gpu):
+    """graph="auto", fuse_epilogue="auto": the first Newton step times the V-cycle eager / replayed and with the smoother's
+    Chebyshev step fused into the apply's epilogue / as a pass of its own, and keeps the fastest.  The four forms give the same
+    bits, so the Newton and Krylov counts and the solution equal those of the explicit eager two-pass solve."""
+    mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_5580e_4ss_us.npz"))     # config 3 at its pinned load
+    out = []
+    for kw in (dict(graph=False, fuse_epilogue=False), dict(graph="auto", fuse_epilogue="auto"), dict(graph=True, fuse_epilogue=True)):
+        p = SolidProblem(gpu, mesh, 4, "hyperSS", nu=0.3, E=1e3, bc_sides=[998, 999])
+        s = NewtonPMG(p, clamp=CLAMP, coarse="amg", **kw)
+        st = s.solve(10)
+        assert st.converged
+        out.append((st.newton_its, st.ksp_its, s.U.to_numpy(), s.tuning))
+        p.destroy()
+    assert out[1][3] is not None and len(out[1][3]["vcycle_ms"]) == 4 and out[0][3] is None
+    for o in out[1:]:
+        assert (o[0], o[1]) == (out[0][0], out[0][1])
+        assert np.array_equal(o[2], out[0][2])
+
+
 @pytest.mark.gpu
 def test_config3_readme_load_on_the_device(gpu):
     """BASELINE config 3 at the load SURVEY 8(d) states -- -bc_clamp 998,999 -bc_clamp_998_translate 0,-0.5,1 (README.rst:63) -- with
