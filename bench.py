@@ -98,15 +98,30 @@ def isa_line(kernel_name: str, path: str):
 BUILD_ISA = os.path.join(ROOT, "ceedpetscsolid_amd", "csrc", "build", "isa_summary.txt")
 
 
-def traffic_from_profile(kernel_name: str, nelem: int):
+def isa_row_named(name: str, path: str):
+    """A row of an ISA summary by its first column (tools/isa_guard.py lists k_assemble beside the pencil kernels), or None."""
+    if not os.path.exists(path):
+        return None
+    for line in open(path):
+        f = line.rstrip("\n").split("\t")
+        if f[0] == name:
+            return f
+    return None
+
+
+def traffic_from_profile(kernel_name: str, nelem: int, launch_info=None):
     """HBM bytes per operator apply from the newest committed PMC reduction (tools/collect_traffic.py ->
-    profiles/rNN_traffic.json), if it was taken on this workload AND on this kernel; (bytes, provenance) or (None, reason).
-    The value is a constant of that profile, NOT a measurement of this run (PMC counters cannot be read from inside
-    bench.py), so it is only reported while the profile still describes the library that runs: the kernel's row of the ISA
-    summary (registers, LDS, instruction counts) stored with the profile -- "kernel_isa" in the file, else the round's
-    profiles/rNN_isa_summary.txt -- must equal the row of THIS build (csrc/build/isa_summary.txt).  Otherwise: null,
-    "stale: ..." (VERDICT r3 item 8)."""
+    profiles/rNN_traffic.json), if it was taken on this workload, this kernel AND this launch sequence; (bytes, provenance) or
+    (None, reason).  The value is a constant of that profile, NOT a measurement of this run (PMC counters cannot be read from
+    inside bench.py), so it is only reported while the profile still describes what runs:
+      * the fused kernel's row of the ISA summary (registers, LDS, instruction counts) stored with the profile -- "kernel_isa" in
+        the file, else the round's profiles/rNN_isa_summary.txt -- equals the row of THIS build (csrc/build/isa_summary.txt);
+      * the same for k_assemble's row ("assemble_isa"; half of the measured bytes are its own), where the profile holds one;
+      * the fused launches per apply of this run (CeedXOperatorGetLaunchInfo: segments of the pipelined form) equal the profile's
+        per_kernel launches_per_apply -- a run under CEED_MI355X_PIPE_MB / _PIPE_SEGMENTS / _ASSEMBLE=serial moves other bytes.
+    Otherwise: null, "stale: ...".  A profile of the right size but another kernel is skipped, not final."""
     import glob
+    reasons = []
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
             d = json.load(open(path))
@@ -116,7 +131,8 @@ def traffic_from_profile(kernel_name: str, nelem: int):
             continue
         base = os.path.basename(path)
         if d.get("kernel") != kernel_name:
-            return None, f"stale: profiles/{base} was taken on kernel '{d.get('kernel')}', this run's is '{kernel_name}'"
+            reasons.append(f"profiles/{base} was taken on kernel '{d.get('kernel')}', this run's is '{kernel_name}'")
+            continue
         now = isa_line(kernel_name, BUILD_ISA)
         then = d.get("kernel_isa") or isa_line(kernel_name, os.path.join(ROOT, "profiles", base.split("_")[0] + "_isa_summary.txt"))
         if now is None or then is None:
@@ -124,7 +140,18 @@ def traffic_from_profile(kernel_name: str, nelem: int):
         if list(now) != list(then):
             return None, (f"stale: profiles/{base} @{d.get('commit')} was taken on another build of this kernel (VGPR/SGPR/LDS/VALU/ds_read/ds_write "
                           f"then {then[1]}/{then[2]}/{then[3]}/{then[11]}/{then[12]}/{then[13]}, now {now[1]}/{now[2]}/{now[3]}/{now[11]}/{now[12]}/{now[13]}): re-run tools/refresh_profiles.sh")
-        return d.get("hbm_bytes_per_apply"), f"profiles/{base} @{d.get('commit', 'round 1')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated on a known axpby; same ISA row as this build)"
+        a_then, a_now = d.get("assemble_isa"), isa_row_named("k_assemble", BUILD_ISA)
+        if a_then is not None and (a_now is None or list(a_now) != list(a_then)):
+            return None, f"stale: profiles/{base} @{d.get('commit')} was taken on another build of k_assemble (its ISA row changed): re-run tools/refresh_profiles.sh"
+        if launch_info is not None:
+            seg_then = [v.get("launches_per_apply") for v in (d.get("per_kernel") or {}).values()]
+            if seg_then and any(sg != launch_info["segments"] for sg in seg_then if sg is not None):
+                return None, (f"stale: other assembly form -- profiles/{base} @{d.get('commit')} was taken with {seg_then[0]} fused launch(es) per apply, "
+                              f"this run makes {launch_info['segments']}")
+        guard = "same ISA rows (fused kernel" + (", k_assemble" if a_then is not None else "") + ") and launch sequence as this run"
+        return d.get("hbm_bytes_per_apply"), f"profiles/{base} @{d.get('commit', 'round 1')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated on a known axpby; {guard})"
+    if reasons:
+        return None, "stale: " + "; ".join(reasons)
     return None, "no committed PMC profile of this workload"
 
 
@@ -359,6 +386,9 @@ def main():
     ap.add_argument("--reorder", action="store_true",
                     help="sort the elements along a Morton curve through their centroids before numbering the nodes (mesh.reorder_elements_locality): "
                          "what the mesh layer can do for a badly ordered mesh (use with --scramble or --workload mesh)")
+    ap.add_argument("--blocks", type=int, default=5,
+                    help="timed blocks of --steps applies each (every block between a barrier + synchronize on both sides, one hipEvent pair "
+                         "each): ms_per_step and value are the MEDIAN block's, the spread over the blocks is reported beside them")
     ap.add_argument("--dry-run", action="store_true",
                     help="no device, no operator: the N ranks rendezvous on gloo, partition the mesh as the real run does and time the "
                          "interface sums of a test vector over torch.distributed; the line says \"dry_run\": true and \"value\": null")
@@ -387,7 +417,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # one node (the contract of --gpus N): RCCL's socket bootstrap -- torch's communicator and the library's own -- over the loopback
         # interface, which always exists and always resolves (the container's hostname may not); the data goes over xGMI either way
-        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        if os.environ.get("LOCAL_WORLD_SIZE", str(world)) == str(world):   # (a launcher that spans nodes keeps RCCL's own choice)
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")   # "gloo": single-GPU rehearsal of the N > 1 path
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -454,6 +485,19 @@ def main():
                                                  strict=not args.no_strict_halo)
         except HaloBringUpError as e:
             print(f"[bench] rank {rank}: {e}; not timing a fallback (--no-strict-halo would)", file=sys.stderr, flush=True)
+            if rank == 0:   # the record says WHY: a line with no value, the reason, and the communicator as far as it got
+                try:
+                    ranks = ceed.comm_size()[0] or None
+                except Exception:   # noqa: BLE001
+                    ranks = None
+                sys.stdout.flush()
+                os.dup2(stdout_fd, 1)
+                print(json.dumps({"metric": "MDoF/s for matrix-free Jacobian apply, p=4 hyperFS hex, 1/2/4/8 GPU", "value": None, "unit": "MDoF/s",
+                                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "rccl_ranks": ranks,
+                                  "halo_path": f"failed: {e}", "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling,
+                                  "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                                  "config": {"workload": f"{args.workload} {args.nr}x{args.nth}x{args.nz}, degree {args.degree}: not run (the library's RCCL "
+                                                         "exchange could not be brought up; --no-strict-halo times the torch exchange instead)"}}), flush=True)
             dist.destroy_process_group()
             sys.exit(4)
         use_rccl = chalo is not None
@@ -532,24 +576,49 @@ def main():
     # regime ~10 % -- profiles/r03_ab_experiments.txt item 16).
     if args.per_apply_events:
         op.set_timing(True)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
+    # --blocks timed blocks of EXACTLY --steps applies, each between a barrier + synchronize on both sides and inside one hipEvent
+    # pair; the line's ms_per_step / value are the MEDIAN block's (max over the ranks per block), the spread says how noisy the box is
+    nblk = max(1, args.blocks)
+    blk_wall, blk_dev = [], []
+    for _b in range(nblk):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(args.steps):
+            step()
+        ev1.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        blk_wall.append(time.perf_counter() - t0)
+        blk_dev.append(ev0.elapsed_time(ev1))
     if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+        t = torch.tensor(blk_wall, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        blk_wall = [float(v) for v in t.tolist()]
+    order = sorted(range(nblk), key=lambda i: blk_wall[i])
+    imed = order[(nblk - 1) // 2]
+    elapsed = blk_wall[imed]
     if args.per_apply_events:
         kernel_ms, launches = op.get_timing()
+        kernel_ms, launches = kernel_ms / nblk, launches // nblk
         op.set_timing(False)
     else:
-        kernel_ms, launches = ev0.elapsed_time(ev1), args.steps
+        kernel_ms, launches = blk_dev[imed], args.steps
+    # the shader clock WHILE the applies run: one more (untimed) block is queued and a one-wave probe on a stream of its own counts
+    # shader cycles against the 100 MHz counter for part of it -- a slow box (clock) is then distinguishable from a slow build
+    clock_ghz = None
+    try:
+        for _ in range(args.steps):
+            step()
+        clock_ghz = ceed.clock_probe(int(max(200, min(2000, 0.5e3 * blk_dev[imed]))))
+        torch.cuda.synchronize()
+    except Exception as e:   # noqa: BLE001  (informational)
+        clock_ghz = None
+        print(f"[bench] clock probe failed: {e}", file=sys.stderr)
     if args.phase_timing:
         pbuf = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
         os.environ["CEED_MI355X_PHASE_BUF"] = hex(pbuf.data_ptr())
@@ -575,11 +644,6 @@ def main():
             if (tb[:, 25] > tb[:, 24]).all():   # the same interval on the constant 100 MHz counter: the shader clock during it
                 f.write("shader clock     %8.3f GHz (cycles of the group / its time on the 100 MHz wall clock, mean over the waves)\n"
                         % float((d / ((tb[:, 25] - tb[:, 24]) * 10.0)).mean()))
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     # the exchange alone (outside the timed region): mean of 20 back-to-back interface sums
     halo_us = None
     if world > 1 or emu:
@@ -607,7 +671,7 @@ def main():
         assembly_form = ("pipelined: %d segments on %d streams, last segment %d elements" % (li["segments"], li["streams"], li["last_segment_elements"])
                          if li["segments"] > 1 else os.environ.get("CEED_MI355X_ASSEMBLE", "serial (launch too small to pipeline, split-phase apply, or switched off)"))
         achieved = abytes / avg_s / 1e9
-        traffic, traffic_src = traffic_from_profile(op.kernel_name, mesh.nelem)
+        traffic, traffic_src = traffic_from_profile(op.kernel_name, mesh.nelem, li)
         out = {
             "metric": "MDoF/s for matrix-free Jacobian apply, p=4 hyperFS hex, 1/2/4/8 GPU",
             "value": 1e-6 * n_global * args.steps / elapsed,
@@ -617,7 +681,13 @@ def main():
             "halo_path": halo_path,   # N > 1: "rccl" = the library's CeedXHalo* (pack kernel, RCCL group, unpack-add); "torch" on request / on gloo; "torch-fallback" only with --no-strict-halo
             "prewarm_ms": args.prewarm_ms, "prewarm_steps": prewarm_steps,
             "launch": "hipGraph replay of one recorded step" if args.graph else "direct",
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * elapsed / args.steps,     # the MEDIAN of the timed blocks (below)
+            "timed_blocks": {"blocks": nblk, "steps_per_block": args.steps, "ms_per_step": [1e3 * w / args.steps for w in blk_wall],
+                             "device_ms_per_step": [d / args.steps for d in blk_dev],
+                             "min": 1e3 * min(blk_wall) / args.steps, "median": 1e3 * elapsed / args.steps, "max": 1e3 * max(blk_wall) / args.steps,
+                             "spread_pct": 100.0 * (max(blk_wall) - min(blk_wall)) / elapsed,
+                             "note": "each block: barrier + synchronize, --steps applies inside one hipEvent pair, synchronize + barrier; wall time, max over the ranks"},
+            "shader_clock_GHz_under_load": clock_ghz,   # CeedXClockProbe during one more untimed block (2.4 GHz spec; ~2.0 under this kernel's f64 load)
             "ms_per_step_cold": ms_cold,   # the same loop right after a 1 s idle, before the pre-warm (rank 0's clock; not max-reduced)
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",

@@ -68,7 +68,7 @@ class CeedLib:
         "CeedXOperatorSetFineScale", "CeedXOperatorSetOverlapSplit", "CeedXOperatorApplyPhase",
         "CeedXVectorPointwiseMult", "CeedXVectorAXPBY", "CeedXVectorDot", "CeedXVectorChebyshevUpdate",
         "CeedXGraphBeginCapture", "CeedXGraphEndCapture", "CeedXGraphLaunch", "CeedXGraphDestroy",
-        "CeedXOperatorApplyChebyshev", "CeedXOperatorApplyResidual",
+        "CeedXOperatorApplyChebyshev", "CeedXOperatorApplyResidual", "CeedXClockProbe",
         "CeedXVectorChebyshevStart", "CeedXVectorWAXPBY", "CeedXVectorDotTo", "CeedXScalarDivide", "CeedXVectorAXPBYScalars",
         "CeedXCsrCreate", "CeedXCsrAssemble", "CeedXCsrApply", "CeedXCsrGetDiagonal", "CeedXCsrDestroy",
         "CeedXCsrCreateRect", "CeedXCsrCreateProduct", "CeedXCsrGetPattern", "CeedXCsrUpdate", "CeedXCsrGetValues", "CeedXCsrInvertDenseSPD",
@@ -237,6 +237,12 @@ class Ceed:
 
     def synchronize(self):
         self.L.chk(self.L.lib.CeedXSynchronize(self.h))
+
+    def clock_probe(self, spin_us: int = 2000) -> float:
+        """Shader clock (GHz) while the work queued on this Ceed's stream runs (CeedXClockProbe)."""
+        g = C.c_double()
+        self.L.chk(self.L.lib.CeedXClockProbe(self.h, C.c_int(spin_us), C.byref(g)))
+        return g.value
 
     def comm_size(self):
         """(ranks, this rank) of the Ceed's RCCL communicator as RCCL reports them (CeedXCommGetSize); (0, -1) without one."""

@@ -144,6 +144,22 @@ extern "C" int CeedXSynchronize(Ceed ceed) {
   HIPCHK(hipStreamSynchronize(ceed->stream));
   return 0;
 }
+// Shader clock (GHz) while the work already queued on the Ceed's stream runs: a one-wave probe on a stream of its own counts shader
+// cycles against the constant 100 MHz counter for `spin_us` microseconds.  Blocks the host until the probe (not the queue) is done.
+extern "C" int CeedXClockProbe(Ceed ceed, int spin_us, double *ghz) {
+  if (ceed->capturing) return ceed_error("CeedXClockProbe during graph capture");
+  if (spin_us < 1 || spin_us > 1000000) return ceed_error("CeedXClockProbe: 1 us ... 1 s");
+  hipStream_t ps = nullptr;
+  long long *d = nullptr, h[2] = {0, 0};
+  HIPCHK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+  HIPCHK(hipMalloc((void **)&d, 2 * sizeof(long long)));
+  HIPCHK(launch_clock_probe(d, spin_us, ps));
+  HIPCHK(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ps));
+  HIPCHK(hipStreamSynchronize(ps));
+  (void)hipFree(d); (void)hipStreamDestroy(ps);
+  *ghz = h[1] > 0 ? (double)h[0] / ((double)h[1] * 10.0) : 0.;     // cycles / (ticks x 10 ns) = GHz
+  return 0;
+}
 extern "C" int CeedXGraphBeginCapture(Ceed ceed) {
   if (ceed->capturing) return ceed_error("graph capture already in progress");
   HIPCHK(hipStreamSynchronize(ceed->stream));

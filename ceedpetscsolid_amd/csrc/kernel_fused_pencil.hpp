@@ -38,7 +38,11 @@ template <int P, int Q> struct PencilGeom {
   static constexpr int SJ = Q, SK = Q * Q, SC = Q3;                         // strides in doubles
   static constexpr int ARR = 3 * SC;                                        // one 3-component array
   static constexpr int PAD = Q == 5 ? 5 : 1;                                // tools/pencil_layout_search.py
+#ifdef CPS_TIMING_ALIAS_BZ   // TIMING-ONLY build (WRONG results): BZ aliased onto BX, a 6 Q^3 slab -- the upper bound of what holding the
+  static constexpr int SE = 2 * ARR + PAD;   // k-direction in registers could buy in occupancy at Q = 7 (profiles/r05_ab_experiments.txt item 1)
+#else
   static constexpr int SE = 3 * ARR + PAD;                                  // element slab: A, BX, BZ
+#endif
   static constexpr int RQ = (E * Q3 + 63) / 64;                             // point rounds per group
   static constexpr int RN = (E * P3 + 63) / 64;                             // node rounds per group
   static constexpr int GEO = E * GEO_NCOEF + 2 * Q;                           // element map coefficients + 1-D points / weights
@@ -320,7 +324,11 @@ __global__ __launch_bounds__(64, pencil_minw(Q)) void k_fused_pencil(const Basis
   constexpr int Q3 = G::Q3, P3 = G::P3, E = G::E, RQ = G::RQ, RN = G::RN;
   constexpr int SJ = G::SJ, SK = G::SK, SC = G::SC, SE = G::SE;
   constexpr int BI = 8, BJ = 8 * SJ, BK = 8 * SK, BC = 8 * SC;        // byte strides
+#ifdef CPS_TIMING_ALIAS_BZ
+  constexpr int oA = 0, oBX = 8 * G::ARR, oBZ = 8 * G::ARR;
+#else
   constexpr int oA = 0, oBX = 8 * G::ARR, oBZ = 16 * G::ARR;         // byte offsets of the arrays
+#endif
   constexpr bool ST_IN = QFTraits<QF>::state_in, ST_OUT = QFTraits<QF>::state_out;
   constexpr int NST = QFTraits<QF>::nstate;
   constexpr int QS = Q3;

@@ -99,6 +99,7 @@ struct FusedGradArgs {
   int waves_per_cu;           // > 0: persistent waves per CU (tuning hook CEED_MI355X_PENCIL_WAVES)
   int *query_waves;           // if set, the launcher stores the number of persistent waves a full launch has and launches nothing
 };
+hipError_t launch_clock_probe(long long *out /* device: shader cycles, 100 MHz ticks */, int spin_us, hipStream_t s);
 // compute units of the current device (one device per process: cached)
 int device_cu_count();
 // element-interior test shared by the kernel and the host-side map builder

@@ -547,6 +547,20 @@ hipError_t launch_diag(int P, int Q, int qf, const BasisTables &t, const DiagArg
   return hipErrorInvalidValue;
 }
 
+// One wave that idles for `ticks` of the constant 100 MHz counter and reports how many SHADER clock cycles went by: the clock the
+// chip runs at under whatever load the other streams put on it (a slow box and a slow build are then told apart: bench.py).
+__global__ void k_clock_probe(long long *out, long long ticks) {
+  if (threadIdx.x != 0) return;
+  const long long t0 = wall_clock64(), c0 = clock64();
+  long long t1 = t0;
+  while (t1 - t0 < ticks) { __builtin_amdgcn_s_sleep(32); t1 = wall_clock64(); }
+  out[0] = clock64() - c0; out[1] = t1 - t0;
+}
+hipError_t launch_clock_probe(long long *out, int spin_us, hipStream_t s) {
+  hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, out, (long long)spin_us * 100);
+  return hipGetLastError();
+}
+
 int device_cu_count() {
   static int ncu = 0;
   if (!ncu) {

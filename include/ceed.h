@@ -317,6 +317,10 @@ CEED_EXTERN int CeedXVectorWAXPBY(CeedVector w, double a, CeedVector x, double b
 CEED_EXTERN int CeedXOperatorApplyChebyshev(CeedOperator op, CeedVector in, CeedVector t, CeedVector x, CeedVector d,
                                             CeedVector r, CeedVector b /* or NULL */, CeedVector dinv,
                                             double c1, double c2, int assign_x);
+/* Measurement aid: the shader clock (GHz) the device runs at WHILE the work   */
+/* already queued on the Ceed's stream executes (a one-wave probe on a stream */
+/* of its own, `spin_us` long).  bench.py reports it beside the timed blocks. */
+CEED_EXTERN int CeedXClockProbe(Ceed ceed, int spin_us, double *ghz);
 CEED_EXTERN int CeedXOperatorApplyResidual(CeedOperator op, CeedVector in, CeedVector t, CeedVector b, CeedVector w);
 /* Assembled sparse operator on L-vectors: the coarse level of the multigrid. */
 /* The reference builds it by finite-difference colouring of the p=1 operator */

@@ -1135,6 +1135,7 @@ int CeedXVectorChebyshevUpdate(CeedVector x, CeedVector d, CeedVector r, CeedVec
   }
   return 0;
 }
+int CeedXClockProbe(Ceed ceed, int spin_us, double *ghz) { (void)ceed; (void)spin_us; *ghz = 0.; return 0; }   /* (no device clock on the CPU) */
 /* The fused forms of the product (include/ceed.h), restated as what they fuse: the apply, then its consumer. */
 int CeedXOperatorApplyChebyshev(CeedOperator op, CeedVector in, CeedVector t, CeedVector x, CeedVector d, CeedVector r, CeedVector b,
                                 CeedVector dinv, double c1, double c2, int assign_x) {

@@ -55,6 +55,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 try:
     import bench as _b
     out["kernel_isa"] = _b.isa_line(out["kernel"], _b.BUILD_ISA)
+    out["assemble_isa"] = _b.isa_row_named("k_assemble", _b.BUILD_ISA)      # half of the bytes are k_assemble's own
 except Exception as e:   # noqa: BLE001
     out["kernel_isa"] = None
     out["kernel_isa_error"] = repr(e)

@@ -63,9 +63,25 @@ def kernel_meta(co):
 QF_NAMES = {2: "LinElas", 3: "HyperSSF", 4: "HyperSSdF", 5: "HyperFSF", 6: "HyperFSdF", 17: "HyperFSdF+derived"}
 
 
+def other_name(mangled):
+    """Kernels of kernels_misc.hip that ride along in the summary WITHOUT being guarded: the restriction transpose (half of the apply's
+    measured traffic: bench.py reports a PMC profile only while this row is unchanged too), its epilogue form, the transfer kernels."""
+    if re.search(r"\d+k_assembleE", mangled):
+        return "k_assemble"
+    if re.search(r"\d+k_assemble_epiE", mangled):
+        return "k_assemble_epi"
+    m = re.search(r"\d+k_transferILi(\d+)ELi(\d+)ELb(\d)ELb(\d)EE", mangled)
+    if m:
+        return "k_transfer<Pc=%s,Pf=%s,%s%s>" % (m.group(1), m.group(2), "prolong" if m.group(3) == "1" else "restrict", ",weighted" if m.group(4) == "1" else "")
+    return None
+
+
 def short_name(mangled):
     m = re.search(r"k_fused_pencilILi(\d+)ELi(\d+)ELi(\d+)ELi(\d)E", mangled)
     if not m:
+        o = other_name(mangled)
+        if o:
+            return o, 99, 0          # q = 99: listed, not guarded
         return None, 0, 0
     P, Q, qf, geo = (int(x) for x in m.groups())
     eo = 1 if 4 <= Q <= 7 else 0     # kernels.hpp, pencil_even_odd
