@@ -67,7 +67,7 @@ class CeedLib:
         "CeedXCommGetUniqueId", "CeedXCommInit", "CeedXCommDestroy", "CeedXCommGetSize", "CeedXHaloCreate", "CeedXHaloStart", "CeedXHaloFinish", "CeedXHaloDestroy",
         "CeedXOperatorSetFineScale", "CeedXOperatorSetOverlapSplit", "CeedXOperatorApplyPhase",
         "CeedXVectorPointwiseMult", "CeedXVectorAXPBY", "CeedXVectorDot", "CeedXVectorChebyshevUpdate",
-        "CeedXGraphBeginCapture", "CeedXGraphEndCapture", "CeedXGraphLaunch", "CeedXGraphDestroy",
+        "CeedXGraphBeginCapture", "CeedXGraphEndCapture", "CeedXGraphLaunch", "CeedXGraphDestroy", "CeedXGraphIsStale",
         "CeedXOperatorApplyChebyshev", "CeedXOperatorApplyResidual", "CeedXClockProbe",
         "CeedXVectorChebyshevStart", "CeedXVectorWAXPBY", "CeedXVectorDotTo", "CeedXScalarDivide", "CeedXVectorAXPBYScalars",
         "CeedXCsrCreate", "CeedXCsrAssemble", "CeedXCsrApply", "CeedXCsrGetDiagonal", "CeedXCsrDestroy",
@@ -207,6 +207,12 @@ class Graph:
 
     def launch(self):
         self.L.chk(self.L.lib.CeedXGraphLaunch(self.h))
+
+    def stale(self) -> int:
+        """What CeedXGraphLaunch would refuse for (0: nothing) -- local to this rank."""
+        st = c_int()
+        self.L.chk(self.L.lib.CeedXGraphIsStale(self.h, C.byref(st)))
+        return st.value
 
     def destroy(self):
         if self.h:

@@ -160,6 +160,12 @@ extern "C" int CeedXClockProbe(Ceed ceed, int spin_us, double *ghz) {
   *ghz = h[1] > 0 ? (double)h[0] / ((double)h[1] * 10.0) : 0.;     // cycles / (ticks x 10 ns) = GHz
   return 0;
 }
+// the references capture_dep() took on the vectors a recording depends on, given back when the recording is dropped
+static void release_capture_deps(Ceed ceed) {
+  std::vector<GraphDep> deps;
+  deps.swap(ceed->capture_deps);
+  for (GraphDep &d : deps) { CeedVector v = d.v; (void)CeedVectorDestroy(&v); }
+}
 extern "C" int CeedXGraphBeginCapture(Ceed ceed) {
   if (ceed->capturing) return ceed_error("graph capture already in progress");
   HIPCHK(hipStreamSynchronize(ceed->stream));
@@ -168,7 +174,7 @@ extern "C" int CeedXGraphBeginCapture(Ceed ceed) {
   ceed->stream = ceed->capture_stream;
   HIPCHK(hipStreamBeginCapture(ceed->stream, hipStreamCaptureModeRelaxed));
   ceed->capturing = true;
-  ceed->capture_deps.clear();
+  release_capture_deps(ceed);
   return 0;
 }
 extern "C" int CeedXGraphEndCapture(Ceed ceed, CeedXGraph *graph) {
@@ -177,10 +183,9 @@ extern "C" int CeedXGraphEndCapture(Ceed ceed, CeedXGraph *graph) {
   hipError_t e = hipStreamEndCapture(ceed->stream, &g);
   ceed->stream = ceed->saved_stream;
   ceed->capturing = false;
-  if (e != hipSuccess || !g) { ceed->capture_deps.clear(); return ceed_error("graph capture failed: %s", hipGetErrorString(e)); }
+  if (e != hipSuccess || !g) { release_capture_deps(ceed); return ceed_error("graph capture failed: %s", hipGetErrorString(e)); }
   CeedXGraph G = new CeedXGraph_private;
-  G->deps.swap(ceed->capture_deps);
-  for (GraphDep &d : G->deps) d.v->refcount++;     // the vectors outlive the graph that checks them
+  G->deps.swap(ceed->capture_deps);                // (the references were taken when the dependencies were recorded: the vectors outlive the graph that checks them)
   G->ceed = ceed; G->graph = g;
   (void)hipGraphGetNodes(g, nullptr, &G->nodes);
   e = hipGraphInstantiate(&G->exec, g, nullptr, nullptr, 0);
@@ -195,16 +200,27 @@ extern "C" int CeedXGraphEndCapture(Ceed ceed, CeedXGraph *graph) {
   *graph = G;
   return 0;
 }
+// 0: the recording still describes its vectors; 1: a qdata vector's geometry provenance was dropped; 2: a stored state's derived state
+static int graph_stale(CeedXGraph G) {
+  for (const GraphDep &d : G->deps) {
+    if (d.geo && d.v->geo != d.geo) return 1;
+    if (d.derived && !(d.v->derived_valid && d.v->derived == d.derived)) return 2;
+  }
+  return 0;
+}
+// The check CeedXGraphLaunch makes, without launching: on SEVERAL ranks a caller agrees on the outcome (e.g. a MAX all-reduce of
+// *stale) BEFORE any rank replays a graph that holds RCCL sends / receives -- one rank refusing while its peers launch would hang
+// the job.  The check itself is local to this rank.
+extern "C" int CeedXGraphIsStale(CeedXGraph G, int *stale) { *stale = graph_stale(G); return 0; }
 extern "C" int CeedXGraphLaunch(CeedXGraph G) {
   if (G->ceed->capturing) return ceed_error("CeedXGraphLaunch during graph capture");
-  for (const GraphDep &d : G->deps) {
-    if (d.geo && d.v->geo != d.geo)
-      return ceed_error("CeedXGraphLaunch: a qdata vector this graph's operators recompute the geometry of was overwritten after the recording "
-                        "(its recorded kernels would still use the old element maps): record the graph again");
-    if (d.derived && !(d.v->derived_valid && d.v->derived == d.derived))
-      return ceed_error("CeedXGraphLaunch: the stored state a recorded HyperFSdF apply reads was overwritten outside the residual operator after "
-                        "the recording (its derived state is no longer valid): record the graph again");
-  }
+  const int st = graph_stale(G);
+  if (st == 1)
+    return ceed_error("CeedXGraphLaunch: a qdata vector this graph's operators recompute the geometry of was overwritten after the recording "
+                      "(its recorded kernels would still use the old element maps): record the graph again");
+  if (st == 2)
+    return ceed_error("CeedXGraphLaunch: the stored state a recorded HyperFSdF apply reads was overwritten outside the residual operator after "
+                      "the recording (its derived state is no longer valid): record the graph again");
   HIPCHK(hipGraphLaunch(G->exec, G->ceed->stream));
   return 0;
 }

@@ -356,6 +356,7 @@ static int read_phys(CeedQFunction qf, double *nu, double *E) {
 static void capture_dep(Ceed c, const GraphDep &d) {
   for (const GraphDep &e : c->capture_deps)
     if (e.v == d.v && e.geo == d.geo && e.derived == d.derived) return;
+  d.v->refcount++;      // held from here: the vector may be destroyed by its creator before the recording ends
   c->capture_deps.push_back(d);
 }
 

@@ -528,7 +528,7 @@ def refine_swept_mesh(mesh: HexMesh, nz: int, tol: float = 1e-6) -> HexMesh:
     a stand-in for the absent cylinder8_99Ke_4ss_us.exo that keeps a REAL unstructured topology (468 x 4 quads x 53 layers = 99 216 hexes).
     New vertices on edges whose two ends lie on one circle about the z axis are put on that circle (the annulus keeps its shape).  Elements
     are numbered layer by layer, within a layer in the generator's order (the four children of a quad together); side sets: the original
-    ids of the two end caps (found by their z), local faces k- / k+."""
+    ids of the two end caps (a set ALL of whose face vertices lie at z0 / z1), local faces k- / k+; lateral side sets are dropped with a warning."""
     z = mesh.coords[:, 2]
     z0, z1 = z.min(), z.max()
     bottom = np.abs(z - z0) < tol * max(1.0, z1 - z0)
@@ -584,12 +584,23 @@ def refine_swept_mesh(mesh: HexMesh, nz: int, tol: float = 1e-6) -> HexMesh:
     coords = np.concatenate([np.column_stack([xy2, np.full(n2, zz)]) for zz in zs], axis=0)
     cells = np.concatenate([np.concatenate([q2 + k * n2, q2 + (k + 1) * n2], axis=1) for k in range(nz)], axis=0)
     ss = {}
-    caps = {}
-    for sid, fs in mesh.side_sets.items():                 # which original id is which end cap
+    caps, dropped = {}, []
+    ztol = tol * max(1.0, z1 - z0)
+    for sid, fs in mesh.side_sets.items():                 # which original id is which end cap: EVERY vertex of EVERY face of the set at z0 (z1)
         fs = np.asarray(fs)
-        if len(fs):
-            zc = mesh.coords[mesh.cells[fs[:, 0]]].mean(axis=1)[:, 2].mean()
-            caps["lo" if zc < 0.5 * (z0 + z1) else "hi"] = sid
+        if not len(fs):
+            continue
+        zf = np.concatenate([z[mesh.cells[fs[fs[:, 1] == f, 0]][:, [c for c in range(8) if ((c >> (f // 2)) & 1) == f % 2]]].ravel()
+                             for f in range(6) if (fs[:, 1] == f).any()])
+        if np.all(np.abs(zf - z0) < ztol) and "lo" not in caps:
+            caps["lo"] = sid
+        elif np.all(np.abs(zf - z1) < ztol) and "hi" not in caps:
+            caps["hi"] = sid
+        else:
+            dropped.append(sid)                           # a lateral surface (or a second set on a cap): not carried over
+    if dropped:
+        import warnings
+        warnings.warn(f"refine_swept_mesh: side sets {sorted(dropped)} are not end caps of the sweep and are not carried over to the refined mesh")
     e = np.arange(nq)
     if "lo" in caps:
         ss[caps["lo"]] = np.stack([e, np.full(nq, 4)], axis=1)

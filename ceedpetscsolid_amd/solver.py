@@ -87,8 +87,9 @@ class NewtonPMG:
         self.p, self.ceed, self.L = prob, prob.ceed, prob.ceed.L
         self.clamp, self.mms, self.halo = clamp or {}, mms, halo
         # "cp": critical-point secant search, up to three secant steps, a step outside (0, 10] ends the search (this build's default);
-        # "cp-petsc": SNESLINESEARCHCP as PETSc runs it by default (elasticity.c:596-601 sets the type and nothing else): ONE secant
-        # step from (0, 1), the result CLAMPED to [1e-12, 1e8], never a rejection; "full": lambda = 1 (SNESLINESEARCHBASIC)
+        # "cp-petsc": SNESLINESEARCHCP with PETSc's defaults (elasticity.c:596-601 sets the type and nothing else) as recalled from its
+        # source, which is NOT in this image (unverified): ONE secant step from (0, 1), downhill slope enforced, direction switched below
+        # steptol, lambda kept above maxstep, never a rejection; "full": lambda = 1 (SNESLINESEARCHBASIC)
         if line_search not in ("cp", "cp-petsc", "full"):
             raise ValueError(f"line_search {line_search!r}")
         self.line_search = line_search
@@ -641,6 +642,12 @@ class NewtonPMG:
         self._pc_graph_io = (r, z)
 
     def precondition(self, r, z):
+        if self._pc_graph is not None and self._pc_graph_io[0] is r and self._pc_graph_io[1] is z and self._pc_graph.stale():
+            # a vector the recording depends on was overwritten behind it (CeedXGraphIsStale; the check is LOCAL to this rank): the
+            # recording is dropped and this rank runs the V-cycle eagerly -- the same launches and, on several ranks, the same RCCL
+            # exchanges in the same order as its peers' replays, so nobody waits for a message that never comes
+            self._pc_graph.destroy()
+            self._pc_graph = None
         if self._pc_graph is not None and self._pc_graph_io[0] is r and self._pc_graph_io[1] is z:
             self._pc_graph.launch()
             self.stats.jacobian_applies += self._pc_graph_counts[0]
@@ -713,11 +720,25 @@ class NewtonPMG:
                     phi = self.dot(self.dU, self.Rtry, True)
                     if abs(phi) <= 1e-8 * abs(phi_old) or abs(phi - phi_old) < 1e-300:
                         break
-                    lam_new = lam - phi * (lam - lam_old) / (phi - phi_old)
                     if self.line_search == "cp-petsc":
-                        if np.isfinite(lam_new):
-                            lam = min(max(lam_new, 1e-12), 1e8)
+                        # ONE secant step in the form of PETSc's SNESLineSearchApply_CP (max_its 1, linear order) AS RECALLED -- PETSc's
+                        # source is not in this image, so this is unverified against it: with fty = Y . F(X - lambda Y)
+                        # (Y = -dU, so fty = -phi) the slope s = d fty / d lambda is made negative ("always go downhill"), the update is
+                        # lambda - fty / s, a result below steptol (1e-12) switches direction (lambda + fty / s), one above maxstep (1e8)
+                        # or a NaN leaves lambda as it was; the step is never rejected.  (Round 4 clamped the plain secant result to
+                        # [1e-12, 1e8] instead: a negative secant step then took lambda = 1e-12, i.e. no step.)
+                        fty, fty_old = -phi, -phi_old
+                        sl = (fty - fty_old) / (lam - lam_old)
+                        if sl > 0.0:
+                            sl = -sl
+                        if sl != 0.0:
+                            lam_up = lam - fty / sl
+                            if lam_up < 1e-12:
+                                lam_up = lam + fty / sl
+                            if np.isfinite(lam_up) and lam_up <= 1e8:
+                                lam = lam_up
                         break
+                    lam_new = lam - phi * (lam - lam_old) / (phi - phi_old)
                     if not np.isfinite(lam_new) or abs(lam_new - lam) < 1e-8 or lam_new <= 0.0 or lam_new > 10.0:
                         break
                     lam_old, phi_old, lam = lam, phi, lam_new

@@ -238,6 +238,10 @@ typedef struct CeedXGraph_private *CeedXGraph;
 CEED_EXTERN int CeedXGraphBeginCapture(Ceed ceed);
 CEED_EXTERN int CeedXGraphEndCapture(Ceed ceed, CeedXGraph *graph);
 CEED_EXTERN int CeedXGraphLaunch(CeedXGraph graph);
+/* The staleness check of CeedXGraphLaunch without the launch (0: replayable). */
+/* Local to the calling rank: several ranks agree on it before replaying a     */
+/* graph that holds RCCL sends / receives.                                     */
+CEED_EXTERN int CeedXGraphIsStale(CeedXGraph graph, int *stale);
 CEED_EXTERN int CeedXGraphDestroy(CeedXGraph *graph);
 /* Name of the kernel family an operator was lowered to, e.g.                 */
 /* "fused_grad<P=5,Q=5,HyperFSdF>" (empty before the first apply).            */

@@ -189,6 +189,7 @@ int CeedXSynchronize(Ceed ceed) { (void)ceed; return 0; }
 typedef struct CeedXGraph_private *CeedXGraph;
 int CeedXGraphBeginCapture(Ceed ceed) { (void)ceed; return 1; }
 int CeedXGraphEndCapture(Ceed ceed, CeedXGraph *g) { (void)ceed; (void)g; return 1; }
+int CeedXGraphIsStale(CeedXGraph graph, int *stale) { (void)graph; *stale = 0; return 0; }
 int CeedXGraphLaunch(CeedXGraph g) { (void)g; return 1; }
 int CeedXGraphDestroy(CeedXGraph *g) { if (g) *g = 0; return 0; }
 
