@@ -6,7 +6,7 @@
 // Node counts P per Q follow the level-degree rules of the reference
 // (cloptions.c:195-225): the fine level has P = Q (qextra = 0), coarse levels
 // use degrees 1, 2, 4 (logarithmic) or every degree below the fine one (uniform) with the FINE quadrature (setuplibceed.c:757).
-// Residual kernels (which write the stored state) only exist on the fine level.
+// Residual kernels (which write the stored state) only exist on the fine level (P = Q, and P = Q - 1, Q - 2 for -qextra 1, 2).
 #include "kernel_fused_pencil.hpp"
 
 #ifndef CPS_Q
@@ -44,28 +44,50 @@ namespace cps {
   CPS_CASE(Pv, QF_HYPERFS_DF, "HyperFSdF") \
   CPS_DERIVED(Pv)
 
+// Residual kernels (they write the stored state) run on the FINE level only: P = Q, and P = Q - 1, Q - 2 for -qextra 1, 2
+// (src/cloptions.c:53-55: Q = degree + 1 + qextra, setuplibceed.c:252).  A larger qextra is a loud "no fused kernel instantiated".
+#define CPS_RESIDUALS(Pv) CPS_CASE(Pv, QF_HYPERSS_F, "HyperSSF") CPS_CASE(Pv, QF_HYPERFS_F, "HyperFSF")
+#define CPS_FINE_WITH_QEXTRA(Pv) ((CPS_Q) > (Pv) && (CPS_Q) - (Pv) <= 2)
+
 template <int PART>
 static hipError_t dispatch_part(int P, int qf, const BasisTables &t, const FusedGradArgs &a, hipStream_t s, const char **name) {
   CPS_JACOBIANS(CPS_Q)
-  CPS_CASE(CPS_Q, QF_HYPERSS_F, "HyperSSF")
-  CPS_CASE(CPS_Q, QF_HYPERFS_F, "HyperFSF")
+  CPS_RESIDUALS(CPS_Q)
 #if CPS_Q > 2
   CPS_JACOBIANS(2)
+#if CPS_FINE_WITH_QEXTRA(2)
+  CPS_RESIDUALS(2)
+#endif
 #endif
 #if CPS_Q > 3
   CPS_JACOBIANS(3)
+#if CPS_FINE_WITH_QEXTRA(3)
+  CPS_RESIDUALS(3)
+#endif
 #endif
 #if CPS_Q > 4
   CPS_JACOBIANS(4)
+#if CPS_FINE_WITH_QEXTRA(4)
+  CPS_RESIDUALS(4)
+#endif
 #endif
 #if CPS_Q > 5
   CPS_JACOBIANS(5)
+#if CPS_FINE_WITH_QEXTRA(5)
+  CPS_RESIDUALS(5)
+#endif
 #endif
 #if CPS_Q > 6      // (uniform ladders of degrees 6 and 7, cloptions.c:195-225: every degree below the fine one is a level)
   CPS_JACOBIANS(6)
+#if CPS_FINE_WITH_QEXTRA(6)
+  CPS_RESIDUALS(6)
+#endif
 #endif
 #if CPS_Q > 7
   CPS_JACOBIANS(7)
+#if CPS_FINE_WITH_QEXTRA(7)
+  CPS_RESIDUALS(7)
+#endif
 #endif
   return hipErrorInvalidValue;
 }

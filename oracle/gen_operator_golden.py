@@ -53,6 +53,9 @@ CASES = [
     ("cyl_p4_hyperSS_swept", lambda: hollow_cylinder_mesh(2, 8, 2), 4, "hyperSS", dict(bc_sides=[998])),
     ("cyl_p2_hyperFS_general", sheared_cylinder, 2, "hyperFS", dict(bc_sides=[998])),
     ("cyl_p4_linElas_swept", lambda: hollow_cylinder_mesh(1, 8, 2), 4, "linElas", dict(bc_sides=[999])),
+    # -qextra > 0 (src/cloptions.c:53-55; Q = degree + 1 + qextra, setuplibceed.c:252,757): the fine level itself runs a P < Q kernel
+    ("box_p2_hyperFS_qextra1", lambda: distorted_box(2, 2, 2, 21), 2, "hyperFS", dict(bc_sides=[1], qextra=1)),
+    ("cyl_p3_hyperSS_qextra2", lambda: hollow_cylinder_mesh(1, 8, 2), 3, "hyperSS", dict(bc_sides=[998], qextra=2)),
 ]
 
 
@@ -85,7 +88,7 @@ def main():
         out[pre + "side_ids"] = np.array(sorted(mesh.side_sets), dtype=np.int64)
         for sid in mesh.side_sets:
             out[pre + f"side_{sid}"] = np.asarray(mesh.side_sets[sid])
-        out[pre + "meta"] = np.array([degree, nu, E])
+        out[pre + "meta"] = np.array([degree, nu, E, kw.get("qextra", 0)])
         out[pre + "problem"] = np.array(problem)
         out[pre + "bc_sides"] = np.array(kw.get("bc_sides", []), dtype=np.int64)
         out[pre + "offsets"] = p.levels[p.fine].dofmap.offsets()

@@ -77,8 +77,10 @@ def operator_golden_problem(ceed, name):
     pre = name + "."
     ss = {int(s): g[pre + f"side_{int(s)}"] for s in g[pre + "side_ids"]}
     mesh = HexMesh(g[pre + "coords"], g[pre + "cells"], ss, name=name)
-    deg, nu, E = g[pre + "meta"]
-    p = SolidProblem(ceed, mesh, int(deg), str(g[pre + "problem"]), nu=float(nu), E=float(E), bc_sides=[int(s) for s in g[pre + "bc_sides"]])
+    meta = g[pre + "meta"]
+    deg, nu, E = meta[:3]
+    qextra = int(meta[3]) if len(meta) > 3 else 0
+    p = SolidProblem(ceed, mesh, int(deg), str(g[pre + "problem"]), nu=float(nu), E=float(E), bc_sides=[int(s) for s in g[pre + "bc_sides"]], qextra=qextra)
     return p, {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
 
 

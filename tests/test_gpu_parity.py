@@ -55,6 +55,14 @@ CASES = [  # (mesh factory, degree, problem, bc)
     ("p5 uniform", lambda: distorted_box(2, 1, 1), 5, "linElas", dict(bc_sides=[1], multigrid="uniform")),  # P = 2..6 at Q = 6
     ("p6 uniform", lambda: distorted_box(1, 1, 2), 6, "hyperFS", dict(bc_sides=[1], multigrid="uniform")),  # P = 2..7 at Q = 7
     ("p7 uniform", lambda: distorted_box(1, 1, 1), 7, "hyperSS", dict(bc_sides=[1], multigrid="uniform")),  # P = 2..8 at Q = 8
+    # -qextra 1, 2 (src/cloptions.c:53-55): Q = degree + 1 + qextra on EVERY level -- the residual kernel with its stored state, the
+    # Jacobian and the diagonal of the FINE level at P < Q
+    ("p2 qextra1 le", lambda: distorted_box(3, 2, 2), 2, "linElas", dict(bc_sides=[1], qextra=1)),      # P = 2, 3 at Q = 4
+    ("p2 qextra1 ss", lambda: distorted_box(2, 3, 2), 2, "hyperSS", dict(bc_sides=[6], qextra=1)),
+    ("p2 qextra2 fs", lambda: distorted_box(3, 2, 2), 2, "hyperFS", dict(bc_sides=[1, 2], qextra=2)),   # P = 2, 3 at Q = 5
+    ("p3 qextra1 fs", lambda: hollow_cylinder_mesh(2, 8, 2), 3, "hyperFS", dict(bc_sides=[998], qextra=1)),   # P = 2, 3, 4 at Q = 5 (swept)
+    ("p3 qextra2 ss", lambda: distorted_box(2, 2, 2), 3, "hyperSS", dict(bc_sides=[1], qextra=2)),      # P = 2, 3, 4 at Q = 6
+    ("p3 qextra2 le", lambda: box_mesh(2, 2, 3), 3, "linElas", dict(bc_sides=[1], qextra=2)),           # affine elements at Q = 6
 ]
 
 

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r4; mkdir -p $O; cd $R
 part=$1; commit=${2:-unknown}
 if [ "$part" = a ]; then
-  ./tools/microbench/capture_fork_repro > $O/capture_fork_repro.txt 2>&1; cat $O/capture_fork_repro.txt
+  # (the capture_fork_repro reproducer deliberately crashes a GPU child: cause recorded in profiles/r04_rccl_capture_probe.txt; run by hand only when the HIP runtime changes -- ADVICE r4)
   python3 tools/rccl_capture_probe.py > $O/rccl_capture_probe_final.txt 2>&1; head -3 $O/rccl_capture_probe_final.txt | cut -c1-300
   bash tools/refresh_profiles.sh r04 $commit "k_fused_pencil<5, 5, 6" 2>&1 | tail -12
 fi
