@@ -114,6 +114,7 @@ class _Level:
     """One transfer of the hierarchy: A (n x n, values change per Newton step) -> A_next = P^T A P (nc x nc)."""
     def __init__(self):
         self.A = self.P = self.Pt = self.T = self.Anext = None
+        self.dd = None              # several ranks, first transfer: the rank's Galerkin contribution and its place in the summed matrix
         self.n = self.nc = 0
         self.dense_next = False
         self.info = {}
@@ -127,7 +128,11 @@ class AggregationAMG:
     """Smoothed-aggregation hierarchy under an `AssembledLevel` (see the module docstring)."""
 
     def __init__(self, asm, prolongator_damping: float = 0.66, verbose: bool = False, max_coarse_dofs: int = 1500,
-                 max_levels: int = 6, smooth_its: int = 3, smooth_ratio: float = 10.0, coarse_cycles: int = 1):
+                 max_levels: int = 6, smooth_its: int = 3, smooth_ratio: float = 10.0, coarse_cycles: int = 1, dist_halo=None):
+        """``dist_halo`` (several ranks): the HaloExchange of the assembled level.  The level's matrix then is the rank's OWN
+        (its elements' sum, interface rows partial -- the additive piece A_r of A = sum_r R_r^T A_r R_r), the first transfer of
+        the hierarchy is DISTRIBUTED (`_first_transfer_distributed`) and everything below it is small and replicated."""
+        self.dist = dist_halo if (dist_halo is not None and dist_halo.world > 1) else None
         self.asm, self.ceed, self.L = asm, asm.ceed, asm.ceed.L
         self.damping, self.verbose, self.max_coarse_dofs, self.max_levels = prolongator_damping, verbose, max_coarse_dofs, max_levels
         self.smooth_its, self.smooth_ratio, self.coarse_cycles = smooth_its, smooth_ratio, coarse_cycles
@@ -199,8 +204,240 @@ class AggregationAMG:
                        prolongation_entries_per_row=float(P.nnz) / n, galerkin_entries=int(lv.T.nnz), lambda_max=lam,
                        next_is_dense=bool(lv.dense_next),
                        seconds=dict(aggregate=t_ag, tentative=t_p0, smooth_and_upload=t_sm, product_patterns=t_pr),
-                       device_bytes=int(12 * (P.nnz + Pt.nnz) + 12 * lv.T.nnz + 12 * lv.Anext.nnz))
+                       device_bytes=int(12 * (P.nnz + Pt.nnz) + 12 * lv.T.nnz + 12 * lv.Anext.nnz),
+                       distributed_bytes=int(12 * (P.nnz + Pt.nnz) + 12 * lv.T.nnz), replicated_bytes=int(12 * lv.Anext.nnz))
         return lv, Bn, col_ptr
+
+    # ---- several ranks: the first transfer, distributed -------------------------------------------------------------------
+    def _update_level(self, lv):
+        """The Galerkin matrix of transfer lv for the current Jacobian: T = A P, A_next = P^T T on the device; on several ranks the
+        first transfer's product is this rank's CONTRIBUTION P_r^T A_r P_r, summed over the ranks into the replicated matrix."""
+        lv.T.update()
+        if getattr(lv, "dd", None) is None:
+            lv.Anext.update()
+            return
+        d = lv.dd
+        d["local"].update()
+        u = np.zeros(d["nnz_union"])
+        u[d["slot"]] = d["local"].values(self.ceed)
+        u = self._allreduce_np(u)
+        d["coo"].set_array(u)
+        lv.Anext.assemble(d["coo"])
+
+    def _allreduce_np(self, a: np.ndarray) -> np.ndarray:
+        import torch
+        import torch.distributed as dist
+        h = self.dist
+        on_dev = dist.get_backend(h.group) == "nccl"
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+        if on_dev:
+            t = t.to(h.device)
+        dist.all_reduce(t, group=h.group)
+        return t.cpu().numpy()
+
+    def _allreduce(self, v: cd.Vector):
+        """Sum of a (small, coarse) vector over the ranks, in place: RCCL on the Ceed's stream where the library has a communicator
+        (recordable), else torch.distributed on the tensor behind the vector."""
+        if self.ceed.comm_size()[0] > 1:
+            n = C.c_int()
+            self.L.chk(self.L.lib.CeedVectorGetLength(v.h, C.byref(n)))
+            self.L.chk(self.L.lib.CeedXCommAllReduce(self.ceed.h, v.h, 0, n.value))
+            return
+        import torch.distributed as dist
+        h = self.dist
+        if v.t.device.type == "cuda":
+            self.ceed.synchronize()
+        if h.stage_host and v.t.device.type == "cuda":
+            t = v.t.cpu()
+            dist.all_reduce(t, group=h.group)
+            v.t.copy_(t)
+        else:
+            dist.all_reduce(v.t, group=h.group)
+        if v.t.device.type == "cuda":
+            v.set_device_pointer(v.t.data_ptr())
+
+    def _dist_vector(self, n: int) -> cd.Vector:
+        """A Ceed vector over a torch tensor (several ranks: torch.distributed sums it where the library has no communicator)."""
+        import torch
+        v = self.ceed.vector(n)
+        v.t = torch.zeros(max(n, 1), dtype=torch.float64, device=self.dist.device)[:n]
+        if v.t.device.type == "cuda":
+            v.set_device_pointer(v.t.data_ptr())
+        else:
+            v.set_array(v.t.numpy(), copy=False)
+        return v
+
+    def _first_transfer_distributed(self, A_host, B, free_node, dense_limit):
+        """The first transfer of the hierarchy on an ELEMENT-PARTITIONED level (the reference's PCGAMG is parallel, elasticity.c:568-585).
+        The level's operator is A = sum_r R_r^T A_r R_r (A_r: rank r's own assembled matrix on its local nodes, `A_host` here); vectors
+        are consistent L-vectors.  Per rank, on the host, once per solve:
+          * aggregates of the free nodes this rank OWNS (lowest sharing rank), rigid-body tentative prolongation P0 on them, coarse
+            dofs numbered globally by rank;
+          * P0's rows at the interface nodes the rank holds but does not own are fetched from their owners; T0 = A_r P0 is formed
+            locally, its interface rows (and the diagonal's) are summed over the sharing ranks in rank order, identically on each;
+          * P = (I - w D^-1 A) P0 on the rank's local nodes (consistent on the interface), lambda_max(D^-1 A) by a distributed power
+            iteration;
+        on the device: P, P^T, T = A_r P, and the rank's Galerkin CONTRIBUTION P^T T (fixed patterns).  The coarse matrix is the sum of
+        the contributions over the ranks on the union of their patterns: ONE all-reduce of its values per Newton step (`_update_level`).
+        Everything below is replicated and small.  Per V-cycle: one all-reduce of the restricted residual (`restrict`); the
+        prolongation is local.  Per-rank memory of the level: the rank's share of A, P, T -- proportional to 1 / ranks."""
+        import scipy.sparse as sp
+        import torch.distributed as dist
+        from .mesh import key_bytes
+        c, h, asm = self.ceed, self.dist, self.asm
+        dm = asm.p.levels[asm.level].dofmap
+        n = A_host.shape[0]
+        nn = n // 3
+        kb = key_bytes(dm.node_keys)
+        own_node = np.asarray(h.owner_weight).reshape(nn, 3)[:, 0] > 0
+        shared = np.zeros(nn, dtype=bool)
+        for nb in h.neigh:
+            shared[nb.dof_idx.cpu().numpy()[::3] // 3] = True
+        dof_ptr = 3 * np.arange(nn + 1, dtype=np.int64)
+
+        def gather(obj):
+            out = [None] * h.world
+            dist.all_gather_object(out, obj, group=h.group)
+            return out
+        # --- aggregates and tentative prolongation on the owned free nodes -----------------------------------------------------
+        node_of = np.arange(n) // 3
+        a_row = np.repeat(np.arange(n, dtype=np.int64), np.diff(A_host.indptr))
+        G = sp.csr_matrix((np.ones(a_row.size), (node_of[a_row], node_of[A_host.indices])), shape=(nn, nn)).tocsr()
+        fn = np.nonzero(free_node & own_node)[0]
+        t_ag = time.perf_counter()
+        if fn.size:
+            Gf = G[fn][:, fn].tocsr()
+            agg_f, na = aggregate_nodes(Gf.indptr, Gf.indices)
+        else:
+            agg_f, na = np.zeros(0, dtype=np.int64), 0
+        t_ag = time.perf_counter() - t_ag
+        agg = np.full(nn, na, dtype=np.int64)
+        agg[fn] = agg_f
+        if na:
+            P0, Bn, col_ptr = tentative_prolongation(agg, na, dof_ptr, B)
+        else:
+            P0, Bn, col_ptr = sp.csr_matrix((n, 0)), np.zeros((0, B.shape[1])), np.zeros(1, dtype=np.int64)
+        ncr = P0.shape[1]
+        info = gather({"nc": ncr, "B": Bn, "col_ptr": col_ptr})
+        off = np.concatenate([[0], np.cumsum([g["nc"] for g in info])]).astype(np.int64)
+        nc = int(off[-1])
+        if nc == 0:
+            raise ValueError("the aggregation left no coarse degree of freedom on any rank")
+        Bnext = np.concatenate([g["B"] for g in info], axis=0)
+        col_ptr_g = np.concatenate([[0]] + [g["col_ptr"][1:] + off[r] for r, g in enumerate(info)]).astype(np.int64)
+        P0 = sp.csr_matrix((P0.data, P0.indices + off[h.rank], P0.indptr), shape=(n, nc))          # global coarse columns
+
+        def rows_of(M, nodes):
+            """(key bytes, CSR rows of the 3 dofs of every node) of a sparse matrix, for publishing."""
+            d = (nodes[:, None] * 3 + np.arange(3)[None, :]).ravel()
+            S = M[d].tocsr()
+            return {"keys": kb[nodes].tobytes(), "n": int(nodes.size), "indptr": S.indptr, "indices": S.indices, "data": S.data}
+
+        def place(pub, ncols):
+            """The published rows that belong to nodes THIS rank holds, as an n x ncols matrix on its local dofs."""
+            if pub["n"] == 0:
+                return sp.csr_matrix((n, ncols))
+            keys = np.frombuffer(pub["keys"], dtype=kb.dtype)
+            order = np.argsort(kb, kind="stable")
+            pos = np.searchsorted(kb[order], keys)
+            pos = np.minimum(pos, nn - 1)
+            hit = kb[order][pos] == keys
+            loc = order[pos]                                     # local node of every published node (where hit)
+            S = sp.csr_matrix((pub["data"], pub["indices"], pub["indptr"]), shape=(3 * pub["n"], ncols)).tocoo()
+            pn, comp = S.row // 3, S.row % 3
+            keep = hit[pn]
+            return sp.csr_matrix((S.data[keep], (loc[pn[keep]] * 3 + comp[keep], S.col[keep])), shape=(n, ncols))
+        # --- P0 on every local node: the rows of interface nodes owned elsewhere come from their owners ------------------------------
+        pubs = gather(rows_of(P0, np.nonzero(shared & own_node)[0]))
+        P0 = P0.tolil() if False else P0
+        for r, pub in enumerate(pubs):
+            if r != h.rank:
+                M = place(pub, nc)
+                # (only nodes this rank does NOT own can match a row published by another owner)
+                P0 = P0 + M
+        P0 = P0.tocsr()
+        # --- T0 = A P0 and the diagonal: local products, interface rows summed over the sharing ranks in rank order ----------------
+        T0 = (A_host @ P0).tocsr()
+        diag = A_host.diagonal()
+        sh_nodes = np.nonzero(shared)[0]
+        sh_dofs = (sh_nodes[:, None] * 3 + np.arange(3)[None, :]).ravel()
+        Dm = sp.csr_matrix((diag[sh_dofs], (sh_dofs, np.zeros(sh_dofs.size, dtype=np.int64))), shape=(n, 1))
+        pubs = gather({"T": rows_of(T0, sh_nodes), "D": rows_of(Dm, sh_nodes)})
+        keep_rows = np.ones(n); keep_rows[sh_dofs] = 0.0
+        Tsum = sp.diags(keep_rows) @ T0                          # interior rows as they are; interface rows rebuilt below
+        Dsum = sp.csr_matrix((n, 1))
+        mine_T, mine_D = T0[sh_dofs], diag[sh_dofs]
+        for r, pub in enumerate(pubs):                           # rank order: the same sums, in the same order, on every sharing rank
+            if r == h.rank:
+                Tsum = Tsum + sp.csr_matrix((mine_T.tocoo().data, (sh_dofs[mine_T.tocoo().row], mine_T.tocoo().col)), shape=(n, nc))
+                Dsum = Dsum + sp.csr_matrix((mine_D, (sh_dofs, np.zeros(sh_dofs.size, dtype=np.int64))), shape=(n, 1))
+            else:
+                Tsum = Tsum + place(pub["T"], nc)
+                Dsum = Dsum + place(pub["D"], 1)
+        diag_g = diag.copy()
+        diag_g[sh_dofs] = np.asarray(Dsum.todense()).ravel()[sh_dofs]
+        dinv = np.where(diag_g != 0.0, 1.0 / np.where(diag_g != 0.0, diag_g, 1.0), 0.0)
+        # --- lambda_max(D^-1 A): power iteration, the products halo-summed, norms over the owned dofs ----------------------------
+        import torch
+        w_own = np.asarray(h.owner_weight, dtype=np.float64)
+
+        def halo_sum(y):
+            t = torch.from_numpy(np.ascontiguousarray(y)).to(h.device)
+            h.add(t)
+            return t.cpu().numpy()
+        xk = np.sin(dm.node_coords @ np.array([[12.9898, 78.233, 37.719], [93.989, 67.345, 24.113], [45.164, 11.135, 83.951]]).T * 437.5453).reshape(-1)
+        xk = xk * (np.abs(B).sum(axis=1) > 0.0)                  # (a function of the coordinates: consistent on shared nodes)
+        lam = 1.0
+        for _ in range(30):
+            y = dinv * halo_sum(A_host @ xk)
+            ny, nx = self._allreduce_np(np.array([np.sum(w_own * y * y), np.sum(w_own * xk * xk)]))
+            lam = float(np.sqrt(ny / nx))
+            xk = y / np.sqrt(ny)
+        lam *= 1.05
+        P = (P0 - (self.damping * 4.0 / 3.0 / lam) * (sp.diags(dinv) @ Tsum)).tocsr()
+        P.sort_indices()
+        Pt = P.T.tocsr()
+        Pt.sort_indices()
+        # --- device objects: the rank's share ---------------------------------------------------------------------------------------
+        lv = _Level()
+        lv.A, lv.n, lv.nc = asm.csr, n, nc
+        lv.P = cd.Csr.rect(c, n, nc, P.indptr, P.indices, P.data)
+        lv.Pt = cd.Csr.rect(c, nc, n, Pt.indptr, Pt.indices, Pt.data)
+        lv.dense_next = nc <= dense_limit
+        lv.T = cd.Csr.product(asm.csr, lv.P, variable=0)
+        local = cd.Csr.product(lv.Pt, lv.T, variable=1, dense=lv.dense_next)
+        # --- the coarse matrix: the contributions summed on the union of their patterns (replicated) -------------------------------
+        nr, ncol, nz, rp, cl = local.pattern()
+        if lv.dense_next:
+            rp_u = np.arange(nc + 1, dtype=np.int64) * nc
+            cl_u = np.tile(np.arange(nc, dtype=np.int64), nc)
+            slot = np.arange(nc * nc, dtype=np.int64)
+        else:
+            pats = gather({"rp": rp, "cl": cl})
+            U = None
+            for g in pats:
+                M = sp.csr_matrix((np.ones(g["cl"].size), g["cl"], g["rp"]), shape=(nc, nc))
+                U = M if U is None else U + M
+            U = U.tocsr(); U.sort_indices()
+            rp_u, cl_u = U.indptr.astype(np.int64), U.indices.astype(np.int64)
+            key_u = np.repeat(np.arange(nc, dtype=np.int64), np.diff(rp_u)) * nc + cl_u
+            key_l = np.repeat(np.arange(nc, dtype=np.int64), np.diff(rp)) * nc + cl
+            slot = np.searchsorted(key_u, key_l)
+            assert np.array_equal(key_u[slot], key_l)
+        nnz_u = int(rp_u[-1])
+        lv.Anext = cd.Csr(c, rp_u, cl_u, np.arange(nnz_u, dtype=np.int64), ())
+        wv = self._dist_vector(n)
+        wv.t.copy_(torch.from_numpy(w_own * (np.asarray(asm.mask) == 0)).to(wv.t.device))
+        if wv.t.device.type == "cuda":
+            wv.set_device_pointer(wv.t.data_ptr())
+        lv.dd = {"local": local, "slot": slot, "nnz_union": nnz_u, "coo": c.vector(max(nnz_u, 1)), "w": wv, "rw": c.vector(n).set_value(0.0)}
+        lv.info = dict(rows=int(n), aggregates=int(na), coarse_dofs=int(nc), coarse_dofs_of_this_rank=int(ncr), distributed_over=int(h.world),
+                       nodes_per_aggregate=float(fn.size) / max(na, 1), prolongation_entries_per_row=float(P.nnz) / max(n, 1),
+                       galerkin_entries=int(lv.T.nnz), lambda_max=lam, next_is_dense=bool(lv.dense_next), seconds=dict(aggregate=t_ag),
+                       device_bytes=int(12 * (P.nnz + Pt.nnz) + 12 * lv.T.nnz + 12 * local.nnz + 12 * nnz_u),
+                       # the rank's share of the level (P, P^T, T = A_r P: proportional to 1 / ranks) and what is replicated under it
+                       distributed_bytes=int(12 * (P.nnz + Pt.nnz) + 12 * lv.T.nnz), replicated_bytes=int(12 * local.nnz + 12 * nnz_u))
+        return lv, Bnext, col_ptr_g
 
     def build(self):
         import scipy.sparse as sp
@@ -217,26 +454,31 @@ class AggregationAMG:
         self.levels = []
         while True:
             last_allowed = len(self.levels) + 2 >= self.max_levels
-            lv, B, dof_ptr = self._transfer(A_csr, A_host, dof_ptr, B, free_node,
-                                            dense_limit=self.max_coarse_dofs if not last_allowed else 2 ** 30)
+            if self.dist is not None and not self.levels:
+                lv, B, dof_ptr = self._first_transfer_distributed(A_host, B, free_node, dense_limit=self.max_coarse_dofs)
+            else:
+                lv, B, dof_ptr = self._transfer(A_csr, A_host, dof_ptr, B, free_node,
+                                                dense_limit=self.max_coarse_dofs if not last_allowed else 2 ** 30)
             self.levels.append(lv)
             if lv.dense_next:
                 break
             if lv.nc > 0.7 * lv.n:
                 raise ValueError(f"aggregation stalls ({lv.n} -> {lv.nc} rows): no hierarchy for this matrix")
             # the next level's matrix on the host (for its aggregates and its prolongator smoothing), from the device product
-            lv.T.update(); lv.Anext.update()
+            self._update_level(lv)
             nr, ncol, nz, rp, cl = lv.Anext.pattern()
             A_host = sp.csr_matrix((lv.Anext.values(c), cl, rp), shape=(nr, ncol))
             A_csr = lv.Anext
             free_node = np.ones(dof_ptr.size - 1, dtype=bool)
             # work vectors and the start vector of the eigenvalue estimate of the new level
             for k in ("x", "b", "r", "d", "t", "z", "dinv"):
-                lv.v[k] = c.vector(lv.nc).set_value(0.0)
+                lv.v[k] = self._dist_vector(lv.nc) if (self.dist is not None and k == "b" and len(self.levels) == 1) else c.vector(lv.nc).set_value(0.0)
             x0 = np.random.default_rng(4321 + len(self.levels)).uniform(-1.0, 1.0, lv.nc)
             lv.x0 = c.vector(lv.nc).set_array(x0 / np.sqrt(np.square(x0).sum()))
         last = self.levels[-1]
         self.rc, self.xc = c.vector(last.nc).set_value(0.0), c.vector(last.nc).set_value(0.0)
+        if self.dist is not None and len(self.levels) == 1:      # the restricted residual is summed over the ranks: behind a tensor
+            self.rc = self._dist_vector(last.nc)
         self.nc = self.levels[0].nc
         self.info = dict(levels=len(self.levels) + 1, rows=[self.levels[0].n] + [l.nc for l in self.levels],
                          aggregates=self.levels[0].info["aggregates"], coarse_dofs=self.levels[0].nc,
@@ -250,8 +492,7 @@ class AggregationAMG:
         if not self.levels:
             self.build()
         for i, lv in enumerate(self.levels):
-            lv.T.update()
-            lv.Anext.update()
+            self._update_level(lv)
             if lv.dense_next:
                 lv.Anext.invert_dense_spd()
             else:
@@ -343,7 +584,16 @@ class AggregationAMG:
     # ---- the coarse correction of level 0 (called by the solver between its own smoothing sweeps): x += P (...) P^T r
     def restrict(self, r: cd.Vector):
         l0 = self.levels[0]
-        l0.Pt.apply(r, self.rc if l0.dense_next else l0.v["b"])
+        dst = self.rc if l0.dense_next else l0.v["b"]
+        if self.dist is None:
+            l0.Pt.apply(r, dst)
+            return
+        # several ranks: r is a consistent L-vector -- every dof counts ONCE (owner weights), each rank restricts its share onto the
+        # (global) coarse dofs and the shares are summed over the ranks: the coarse level below is replicated
+        d = l0.dd
+        self.L.chk(self.L.lib.CeedXVectorPointwiseMult(d["rw"].h, r.h, d["w"].h))
+        l0.Pt.apply(d["rw"], dst)
+        self._allreduce(dst)
 
     def solve_coarsest(self):
         l0 = self.levels[0]
@@ -358,7 +608,8 @@ class AggregationAMG:
 
     def destroy(self):
         for lv in reversed(self.levels):
-            for o in [lv.Anext, lv.T, lv.Pt, lv.P, lv.x0] + list(lv.v.values()):
+            dd = getattr(lv, "dd", None) or {}
+            for o in [lv.Anext, dd.get("local"), lv.T, lv.Pt, lv.P, lv.x0, dd.get("coo"), dd.get("w"), dd.get("rw")] + list(lv.v.values()):
                 if o is not None:
                     o.destroy()
         for o in (self.rc, self.xc, self._scal):

@@ -60,6 +60,12 @@ extern "C" int CeedXCsrCreate(Ceed ceed, CeedInt nrows, const CeedInt *rowptr, c
   CeedXCsr A = new CeedXCsr_private;
   A->ceed = ceed; ceed_ref(ceed);
   A->nrows = nrows; A->ncols = nrows; A->nnz = nnz; A->ncoo = ncoo; A->n_unit = n_unit;
+  {  // a full pattern with ascending columns may be inverted in place (CeedXCsrInvertDenseSPD): the summed coarsest level of a distributed hierarchy
+    bool dense = (long long)nnz == (long long)nrows * nrows && nrows > 0;
+    for (int r = 0; dense && r < nrows; r++)
+      for (int k = rowptr[r]; k < rowptr[r + 1]; k++) if (cols[k] != k - rowptr[r]) { dense = false; break; }
+    A->dense = dense;
+  }
   A->h_rowptr.assign(rowptr, rowptr + nrows + 1); A->h_cols.assign(cols, cols + nnz);
   CHK(csr_upload(&A->d_rowptr, rp)); CHK(csr_upload(&A->d_cols, cl)); CHK(csr_upload(&A->d_slotptr, slotptr));
   CHK(csr_upload(&A->d_perm, perm)); CHK(csr_upload(&A->d_unit_slot, unit)); CHK(csr_upload(&A->d_diag_slot, diag));

@@ -123,22 +123,19 @@ class NewtonPMG:
         # Galerkin matrix, Chebyshev again.  8 matrix products per cycle instead of 40, and 2.3x fewer outer iterations.
         self.asm = self.amg = None
         self.amg_smooth_its, self.amg_smooth_ratio = amg_smooth_its, amg_smooth_ratio
-        self.replicated = False
         if coarse in ("assembled", "amg") and len(prob.levels) > 1:
             from .assembly import AssembledLevel
-            # several ranks + "amg": the p = 1 matrix is REPLICATED (every rank assembles the global one from the all-gathered element
-            # matrices) and the aggregation hierarchy under it runs on every rank alike -- the single-rank coarse solve, whatever the partition
+            # several ranks: every rank assembles ITS OWN p = 1 matrix (its elements' sum; the operator is A = sum_r R_r^T A_r R_r, applied as
+            # "local product, then the interface sum" like the matrix-free levels); with "amg" the first transfer of the aggregation
+            # hierarchy is distributed over the ranks and everything under it is small and replicated (amg.py, round 5; rounds 3-4
+            # all-gathered all element matrices and replicated the whole level)
             many = halo is not None and isinstance(halo, (list, tuple)) and halo[-1].world > 1
-            self.replicated = bool(many and coarse == "amg")
-            if self.replicated and self.graph:
-                raise ValueError("graph=True: the replicated coarse level moves vectors with torch.distributed, which cannot be recorded")
-            if self.replicated:
-                self._auto_graph = False
-            self.asm = AssembledLevel(prob, 0, replicate=halo[0] if self.replicated else None)
+            self.asm = AssembledLevel(prob, 0)
             if coarse == "amg":
                 from .amg import AggregationAMG
                 self.amg = AggregationAMG(self.asm, verbose=verbose, max_coarse_dofs=amg_max_coarse_dofs,
-                                          smooth_its=amg_smooth_its, smooth_ratio=amg_smooth_ratio, coarse_cycles=amg_coarse_cycles)
+                                          smooth_its=amg_smooth_its, smooth_ratio=amg_smooth_ratio, coarse_cycles=amg_coarse_cycles,
+                                          dist_halo=halo[0] if many else None)
         self._pc_graph, self._pc_graph_io, self._pc_graph_counts, self._pc_warm = None, None, (0, 0), False
         self.ksp_rtol, self.snes_rtol, self.snes_maxit, self.verbose = ksp_rtol, snes_rtol, snes_maxit, verbose
         self.nlev = len(prob.levels)
@@ -178,11 +175,7 @@ class NewtonPMG:
                 for lv, level in enumerate(prob.levels):
                     level.opJacob.set_overlap_split(int(lead_elements), self.halos[lv].interface_dof_mask())
         self._split = bool(self.rhalos) and lead_elements > 0
-        # replicated coarse level: the level-0 work vectors have the GLOBAL length (the matrix is the global one on every rank);
-        # `wl0` are the local L-vectors the transfers read and write, moved to / from the global numbering around the coarse solve
-        mk = lambda lv: self._vec(self.asm.nrows, lv, glob=True) if (lv == 0 and self.replicated) else self._vec(prob.lsize(lv), lv)
-        self.w = [{k: mk(lv) for k in ("x", "b", "r", "d", "t", "dinv", "z")} for lv in range(self.nlev)]
-        self.wl0 = {k: self._vec(prob.lsize(0), 0) for k in ("x", "b")} if self.replicated else None
+        self.w = [{k: self._vec(prob.lsize(lv), lv) for k in ("x", "b", "r", "d", "t", "dinv", "z")} for lv in range(self.nlev)]
         self.emax = [1.0] * self.nlev
         self._x0 = {}
         self._scal = None
@@ -195,10 +188,9 @@ class NewtonPMG:
         self.weights = [None] * self.nlev
         if self.halos:
             for lv in range(self.nlev):
-                if not (lv == 0 and self.replicated):      # (every entry of the replicated level counts once, on every rank alike)
-                    wv = self._vec(prob.lsize(lv), lv)
-                    self._set(wv, self.halos[lv].owner_weight * (prob.levels[lv].mask == 0))
-                    self.weights[lv] = wv
+                wv = self._vec(prob.lsize(lv), lv)
+                self._set(wv, self.halos[lv].owner_weight * (prob.levels[lv].mask == 0))
+                self.weights[lv] = wv
                 self._refresh_multiplicity(lv)
         # body force vector (opSetupForce output, setuplibceed.c:555-583): SNESSolve(snes, F, U) solves
         # residual(U) = load * F on the unconstrained dofs (elasticity.c:645-654)
@@ -235,9 +227,6 @@ class NewtonPMG:
         r = C.c_double()
         lv = self.nlev - 1 if lv is None else lv
         wv = self.weights[lv].h if self.weights[lv] is not None else None
-        if lv == 0 and self.replicated:      # the replicated level: every rank holds the whole vector
-            self.L.chk(self.L.lib.CeedXVectorDot(x.h, y.h, None, C.byref(r)))
-            return r.value
         if self.rhalos:      # the sum over the ranks on the device (ncclAllReduce on the Ceed's stream), ONE read at the end
             if self._scal is None:
                 self._scal = self.ceed.vector(8 + 2 * 16)
@@ -255,14 +244,13 @@ class NewtonPMG:
         return v
 
     # ---- vectors that alias torch tensors (several ranks only) ----------------------------------------
-    def _vec(self, n, lv, glob=False):
+    def _vec(self, n, lv):
         c = self.ceed
         if not self.halos:
             return c.vector(n).set_value(0.0)
         import torch
         dev = self.halos[lv].device
         v = c.vector(n)
-        v.n_global = glob                 # a vector of the replicated coarse level (global numbering, complete on every rank)
         v.t = torch.zeros(n, dtype=torch.float64, device=dev)
         if dev.type == "cuda":
             v.set_device_pointer(v.t.data_ptr())
@@ -286,8 +274,6 @@ class NewtonPMG:
 
     def _halo_sum(self, lv, vec):
         """Interface sum of an operator output at level lv (the DMLocalToGlobal(ADD_VALUES) of matops.c:57)."""
-        if getattr(vec, "n_global", False):
-            return                    # a vector of the replicated (global) level: already complete on every rank
         if self.rhalos:               # the library's exchange, on the Ceed's stream: nothing to synchronise, nothing to re-wrap
             self.rhalos[lv].add(vec)
         elif self.halos:
@@ -295,19 +281,6 @@ class NewtonPMG:
                 self.ceed.synchronize()
             self.halos[lv].add(vec.t)
             self._touched(vec)
-
-    def _to_global(self, v_local, v_global):
-        """Coarse L-vector -> the replicated level's global vector (assembly.AssembledLevel.globalise)."""
-        if v_local.t.device.type == "cuda":
-            self.ceed.synchronize()
-        self.asm.globalise(v_local.t, v_global.t)
-        self._touched(v_global)
-
-    def _to_local(self, v_global, v_local):
-        if v_global.t.device.type == "cuda":
-            self.ceed.synchronize()
-        self.asm.localise(v_global.t, v_local.t)
-        self._touched(v_local)
 
     def _refresh_multiplicity(self, lv):
         """multVec of misc.c:115-143 counted over ALL ranks: 1 / (halo-summed element multiplicity)."""
@@ -387,29 +360,25 @@ class NewtonPMG:
                 self.amg.setup()                # Galerkin matrix of THIS Jacobian and its inverse
         for lv in range(self.nlev):
             w = self.w[lv]
-            rep0 = lv == 0 and self.replicated
-            if rep0:
-                self.asm.diagonal(w["dinv"])            # of the replicated global matrix
-            else:
-                self.p.get_diag(lv, w["dinv"])
-                self._halo_sum(lv, w["dinv"])
+            self.p.get_diag(lv, w["dinv"])
+            self._halo_sum(lv, w["dinv"])
             # 1 / diagonal; constrained rows come out of the masked operator as zeros and stay zero (CeedVectorReciprocal
             # leaves zeros alone): residuals and corrections are zero there anyway.  No trip through the host.
             w["dinv"].reciprocal()
             if hasattr(w["dinv"], "t"):
                 self._touched(w["dinv"])
-            mask = (np.asarray(self.asm.mask) if rep0 else self.p.levels[lv].mask) != 0
+            mask = self.p.levels[lv].mask != 0
             # The start vector of the eigenvalue estimate is drawn once per level; no BLAS on the host (a threaded BLAS
             # call leaves its worker pool spinning, which starves a CPU-quota'd process for ~0.1 s a call).
             if lv not in self._x0:
-                if self.halos and not rep0:   # shared nodes must get the same value on every rank: a hash of the coordinates
+                if self.halos:   # shared nodes must get the same value on every rank: a hash of the coordinates
                     X = self.p.levels[lv].dofmap.node_coords
                     k = np.array([[12.9898, 78.233, 37.719], [93.989, 67.345, 24.113], [45.164, 11.135, 83.951]])
                     v = np.sin(X @ k.T) * 437.5453
                     x = (2.0 * (v - np.floor(v)) - 1.0).reshape(-1) * (~mask)
                 else:
                     x = np.random.default_rng(1234 + lv).uniform(-1, 1, mask.size) * (~mask)
-                x0 = self._vec(mask.size, lv, glob=rep0)
+                x0 = self._vec(mask.size, lv)
                 self._set(x0, x / np.sqrt(np.square(x).sum()))     # (any positive scale: the iteration renormalises)
                 self._x0[lv] = x0
             # largest eigenvalue of D^-1 A: 10 steps of Jacobi-preconditioned CG on the noisy right-hand side and
@@ -460,7 +429,7 @@ class NewtonPMG:
         self.pmult(z, r, w["dinv"]); self.copy(pv, z)
         one, neg = C.c_double(1.0), C.c_double(-1.0)
         wv = self.weights[lv].h if self.weights[lv] is not None else None      # several ranks: every dof counts once
-        many = bool(self.rhalos) and not (lv == 0 and self.replicated)
+        many = bool(self.rhalos)
 
         def dot_to(a, b, slot):
             chk(lib.CeedXVectorDotTo(a.h, b.h, wv, sc.h, slot))
@@ -570,17 +539,6 @@ class NewtonPMG:
         w, wc = self.w[lv], self.w[lv - 1]
         self.chebyshev(lv, b, x, self.smooth_its, True)
         self.level_residual(lv, b, x, w["z"])
-        if lv == 1 and self.replicated:     # the coarse level lives in the global numbering, replicated: one all-gather in, a gather out
-            self.p.restrict(lv, w["z"], self.wl0["b"])
-            self._halo_sum(0, self.wl0["b"])
-            self._to_global(self.wl0["b"], wc["b"])
-            self.vcycle(0, wc["b"], wc["x"])
-            self._to_local(wc["x"], self.wl0["x"])
-            self.p.prolong(lv, self.wl0["x"], w["z"])
-            self._halo_sum(lv, w["z"])
-            self.axpby(x, 1.0, w["z"], 1.0)
-            self.chebyshev(lv, b, x, self.smooth_its, False)
-            return
         self.p.restrict(lv, w["z"], wc["b"])                                # Restrict_Ceed
         self._halo_sum(lv - 1, wc["b"])
         self.vcycle(lv - 1, wc["b"], wc["x"])

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(rank, world, initfile, outdir, coarse):
+def run(rank, world, initfile, outdir, coarse, mesh_args=(1, 6, None), max_coarse=1500):
     from ceedpetscsolid_amd import ceed as cd
     from ceedpetscsolid_amd.halo import HaloExchange
     from ceedpetscsolid_amd.mesh import hollow_cylinder_mesh, partition_slabs, submesh
@@ -18,17 +18,23 @@ def run(rank, world, initfile, outdir, coarse):
     dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
     lib = cd.CeedLib(os.path.join(ROOT, "oracle", "liboracle_ceed.so"))   # tests only: the oracle as local operator
     ceed = cd.Ceed(lib, "/cpu/self/oracle")
-    full = hollow_cylinder_mesh(1, 6, 2 * world, z0=-1.0, z1=1.0)
+    nr, nth, nz = mesh_args[:3]
+    zh = mesh_args[3] if len(mesh_args) > 3 else 1.0
+    full = hollow_cylinder_mesh(nr, nth, nz if nz else 2 * world, z0=-zh, z1=zh)
     mesh = submesh(full, partition_slabs(full, world)[rank])
     bc = [s for s in (998, 999) if s in mesh.side_sets and len(mesh.side_sets[s])]
     p = SolidProblem(ceed, mesh, 2, "hyperSS", nu=0.3, E=10.0, bc_sides=bc)
     halos = [HaloExchange(mesh, lv.dofmap, device="cpu") for lv in p.levels]
     clamp = {s: ({"translate": (0.0, -0.05, 0.1)} if s == 998 else {}) for s in bc}
-    s = NewtonPMG(p, clamp=clamp, halo=halos, coarse=coarse, coarse_cheb_its=20, coarse_cheb_ratio=50.0)
+    s = NewtonPMG(p, clamp=clamp, halo=halos, coarse=coarse, coarse_cheb_its=20, coarse_cheb_ratio=50.0, amg_max_coarse_dofs=max_coarse)
     st = s.solve(1)
+    amg_info = s.amg.info if s.amg is not None else {}
     lvf = p.levels[p.fine]
     np.savez(os.path.join(outdir, f"solve_{rank}.npz"), coords=lvf.dofmap.node_coords, U=s.U.to_numpy(),
-             converged=st.converged, newton=st.newton_its, ksp=st.ksp_its)
+             converged=st.converged, newton=st.newton_its, ksp=st.ksp_its,
+             amg_rows=np.array(amg_info.get("rows", []), dtype=np.int64),
+             amg_level0_bytes=np.array([(amg_info.get("per_level") or [{}])[0].get("distributed_bytes", 0)], dtype=np.int64),
+             amg_level0_own_coarse=np.array([(amg_info.get("per_level") or [{}])[0].get("coarse_dofs_of_this_rank", -1)], dtype=np.int64))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -148,6 +148,44 @@ def test_two_rank_solve_matches_single_rank(oracle, coarse):
             assert abs(int(part["ksp"]) - st.ksp_its) <= max(1, round(0.05 * st.ksp_its)), (int(part["ksp"]), st.ksp_its)
 
 
+@pytest.mark.parametrize("world,max_coarse", [(2, 1500), (3, 1500), (2, 40), (3, 40)],
+                         ids=["2 ranks, dense level below", "3 ranks, dense level below", "2 ranks, sparse level below", "3 ranks, sparse level below"])
+def test_distributed_aggregation_hierarchy_matches_single_rank(oracle, world, max_coarse):
+    """The coarse solve on several ranks (round 5; the reference's PCGAMG is parallel, elasticity.c:568-585): every rank assembles its
+    OWN p = 1 matrix, aggregates the nodes it owns, the Galerkin product is formed per rank and summed over the ranks on the union of the
+    patterns (one all-reduce of the coarse values per Newton step), the restricted residual is summed per V-cycle, everything below
+    the first transfer is replicated.  No element matrix leaves its rank.  Against the single-rank solve: the same Newton count, the
+    Krylov count within 2, the same solution; the level's device bytes per rank shrink with the number of ranks."""
+    import _solver_worker
+    from ceedpetscsolid_amd.solver import NewtonPMG
+    margs = (2, 8, 8 * world, 2.0 * world)           # eight element layers per rank, layers 0.5 thick
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_solver_worker.run, args=(world, os.path.join(d, "init"), d, "amg", margs, max_coarse), nprocs=world, join=True)
+        parts = [np.load(os.path.join(d, f"solve_{r}.npz")) for r in range(world)]
+    full = hollow_cylinder_mesh(*margs[:3], z0=-margs[3], z1=margs[3])
+    p = SolidProblem(oracle, full, 2, "hyperSS", nu=0.3, E=10.0, bc_sides=[998, 999])
+    s = NewtonPMG(p, clamp={998: dict(translate=(0.0, -0.05, 0.1)), 999: dict()}, coarse="amg", amg_max_coarse_dofs=max_coarse)
+    st = s.solve(1)
+    assert st.converged
+    X = p.levels[p.fine].dofmap.node_coords
+    key = {tuple(np.round(x, 9)): i for i, x in enumerate(X)}
+    U = s.U.to_numpy().reshape(-1, 3)
+    single_bytes = s.amg.info["per_level"][0]["distributed_bytes"]      # P, P^T and T = A P of the first transfer
+    own = 0
+    for part in parts:
+        assert bool(part["converged"]) and int(part["newton"]) == st.newton_its
+        assert abs(int(part["ksp"]) - st.ksp_its) <= 2, (int(part["ksp"]), st.ksp_its)
+        idx = np.array([key[tuple(np.round(x, 9))] for x in part["coords"]])
+        assert rel_err(part["U"].reshape(-1, 3), U[idx]) < 1e-7
+        assert list(part["amg_rows"][1:]) == list(parts[0]["amg_rows"][1:])        # the levels below the first transfer are the same on every rank
+        print("first transfer, bytes of P, P^T, A P on this rank / on one rank:", int(part["amg_level0_bytes"][0]), single_bytes)
+        assert int(part["amg_level0_bytes"][0]) < (0.8 if world == 2 else 0.62) * single_bytes, (int(part["amg_level0_bytes"][0]), single_bytes)
+        own += int(part["amg_level0_own_coarse"][0])
+    assert own == int(parts[0]["amg_rows"][1])                                      # every coarse dof belongs to exactly one rank
+    if max_coarse < 100:
+        assert len(parts[0]["amg_rows"]) >= 3                                        # a sparse (summed) level and a dense one below it
+
+
 @pytest.mark.parametrize("strict", [1, 0], ids=["strict: every rank raises", "not strict: every rank falls back and says so"])
 def test_failed_bring_up_of_the_library_exchange_is_loud_and_collective(strict):
     """VERDICT r2 item 2 / ADVICE r2: a library exchange that cannot be brought up must be impossible to miss.  Two gloo
