@@ -121,9 +121,9 @@ def test_emulated_rank_has_the_neighbour_lists_of_the_real_job(mode, world):
 @pytest.mark.parametrize("coarse", ["chebyshev", "assembled", "amg"])
 def test_two_rank_solve_matches_single_rank(oracle, coarse):
     """The whole Newton - PCG - pMG solve on two element partitions (halo sums after every operator, ownership-
-    weighted dots, globally counted multiplicity) gives the single-rank solution.  "amg" (round 3): the
-    p = 1 matrix is REPLICATED -- all-gathered element matrices, a global numbering from the node keys -- and the aggregation
-    hierarchy under it runs on every rank alike: the Krylov count of the single-rank solve within 5 %."""
+    weighted dots, globally counted multiplicity) gives the single-rank solution.  "amg": the aggregation hierarchy under the p = 1
+    level is distributed in its first transfer (round 5: test_distributed_aggregation_hierarchy_matches_single_rank looks at it more
+    closely): the Krylov count of the single-rank solve within 5 %."""
     import _solver_worker
     from ceedpetscsolid_amd.solver import NewtonPMG
     world = 2
