@@ -88,6 +88,7 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   o.comm_priority = env_int("CEED_MI355X_COMM_PRIO", o.comm_priority);
   o.comm_inline = env_int("CEED_MI355X_COMM_INLINE", o.comm_inline);
   o.fold_pack = env_int("CEED_MI355X_FOLD_PACK", o.fold_pack);
+  o.spgemm_row = !env_is("CEED_MI355X_SPGEMM", "entry");
   *ceed = c;
   return 0;
 }

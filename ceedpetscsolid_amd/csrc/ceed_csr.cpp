@@ -17,6 +17,7 @@ struct CeedXCsr_private {
   double *d_gj = nullptr;
   int *d_info = nullptr;
   bool dense = false;       // full pattern, columns ascending: vals is a row-major nrows x nrows matrix
+  int max_row = 0;          // longest row of the pattern (products: chooses the kernel of CeedXCsrUpdate)
   int refs = 1;             // an operand is kept alive by the products formed from it
   std::vector<int> h_rowptr, h_cols;      // host copy of the pattern (operand of CeedXCsrCreateProduct)
 };
@@ -193,6 +194,7 @@ extern "C" int CeedXCsrCreateProduct(CeedXCsr Lm, CeedXCsr Rm, int variable, int
   CHK(csr_upload(&A->d_rowptr, rp)); CHK(csr_upload(&A->d_cols, cl)); CHK(csr_upload(&A->d_diag_slot, diag));
   HIPCHK(hipMalloc((void **)&A->d_vals, sizeof(double) * (nnz ? nnz : 1)));
   HIPCHK(hipMemset(A->d_vals, 0, sizeof(double) * (nnz ? nnz : 1)));
+  for (int r = 0; r < nrows; r++) A->max_row = std::max(A->max_row, (int)(rp[(size_t)r + 1] - rp[(size_t)r]));
   A->src = Lm; Lm->refs++;
   A->src2 = Rm; Rm->refs++;
   *csr = A;
@@ -210,7 +212,7 @@ extern "C" int CeedXCsrUpdate(CeedXCsr A) {
   if (!A->src || !A->src2) return ceed_error("CeedXCsrUpdate: not a product (CeedXCsrCreateProduct)");
   CeedXCsr Lm = A->src, Rm = A->src2;
   HIPCHK(launch_csr_spgemm(Lm->d_rowptr, Lm->d_cols, Lm->d_vals, Rm->d_rowptr, Rm->d_cols, Rm->d_vals, A->d_rowptr, A->d_cols, A->d_vals,
-                           A->nrows, A->ceed->stream, A->dense ? A->ncols : 0));
+                           A->nrows, A->ceed->stream, A->dense ? A->ncols : 0, A->ceed->opt.spgemm_row ? A->max_row : 0));
   return 0;
 }
 extern "C" int CeedXCsrGetValues(CeedXCsr A, CeedVector v) {

@@ -300,8 +300,9 @@ hipError_t launch_csr_spmv(const uint32_t *rowptr, const uint32_t *cols, const d
 hipError_t launch_csr_diag(const uint32_t *diag_slot_of_row, const double *vals, double *d, int nrows, hipStream_t s);
 hipError_t launch_csr_spgemm(const uint32_t *l_rowptr, const uint32_t *l_cols, const double *l_vals, const uint32_t *r_rowptr,
                              const uint32_t *r_cols, const double *r_vals, const uint32_t *c_rowptr, const uint32_t *c_cols, double *c_vals,
-                             int nrows, hipStream_t s, int dense_ncols = 0);   // C = L R on fixed patterns (R's columns sorted within each row);
-                             // dense_ncols > 0: C is a dense row-major nrows x dense_ncols matrix (LDS row accumulation)
+                             int nrows, hipStream_t s, int dense_ncols = 0, int max_row_c = 0);   // C = L R on fixed patterns (R's columns sorted within each row);
+                             // dense_ncols > 0: C is a dense row-major nrows x dense_ncols matrix (LDS row accumulation);
+                             // max_row_c > 0: the longest row of C -- up to 4096 entries a wave per row with an LDS accumulator (k_csr_spgemm_row)
 hipError_t launch_dense_spd_inverse(double *A, int n, double *scratch /* 1024 doubles */, int *info, hipStream_t s);
 
 // Vector / restriction utilities.

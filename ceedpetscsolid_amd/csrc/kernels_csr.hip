@@ -195,13 +195,59 @@ __global__ __launch_bounds__(64) void k_csr_spgemm_dense(const uint32_t *l_rowpt
   }
 }
 
+// C = L R on fixed patterns, rows of C with at most `maxc` entries (round 5): ONE WAVE owns a row of C.  Its column list (sorted) and
+// an accumulator per entry live in LDS; for k along L's row IN ORDER the lanes take the entries of R's row l_cols[k], find each entry's
+// column in C's list (binary search in LDS: ~log2 of the row length probes, against ~80 x 5 probes of GLOBAL memory per entry of C in
+// k_csr_spgemm) and add  L[r, k] R[k, c]  to its accumulator.  Columns within a row of R are distinct (no two lanes on one word), one
+// wave's LDS operations execute in order and a barrier separates the k steps: every entry of C is summed in the order of L's row, the
+// same every time -- the values k_csr_spgemm gives, term for term.  Config 4's p = 1 level (330 k rows, 81 per row): T = A P 8.0 -> ~1 ms.
+__global__ __launch_bounds__(64) void k_csr_spgemm_row(const uint32_t *l_rowptr, const uint32_t *l_cols, const double *l_vals,
+                                                      const uint32_t *r_rowptr, const uint32_t *r_cols, const double *r_vals,
+                                                      const uint32_t *c_rowptr, const uint32_t *c_cols, double *c_vals, int nrows, int maxc) {
+  extern __shared__ double sm[];
+  double *acc = sm;                                   // [maxc]
+  uint32_t *ccol = (uint32_t *)(sm + maxc);           // [maxc]
+  const int lane = threadIdx.x;
+  for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const uint32_t s0 = c_rowptr[r], nc = c_rowptr[r + 1] - s0;
+    for (uint32_t s = lane; s < nc; s += 64) { ccol[s] = c_cols[s0 + s]; acc[s] = 0.; }
+    __syncthreads();
+    if (nc) {
+      for (uint32_t k = l_rowptr[r]; k < l_rowptr[r + 1]; k++) {
+        const uint32_t j = l_cols[k];
+        const double a = l_vals[k];
+        for (uint32_t m = r_rowptr[j] + lane; m < r_rowptr[j + 1]; m += 64) {
+          const uint32_t c = r_cols[m];
+          uint32_t lo = 0, hi = nc;                     // invariant: ccol[lo] <= c < ccol[hi] where the column is present
+          while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (ccol[mid] <= c) lo = mid; else hi = mid;
+          }
+          if (ccol[lo] == c) acc[lo] += a * r_vals[m];  // (an entry of the product outside C's pattern is dropped, as in k_csr_spgemm)
+        }
+        __syncthreads();
+      }
+    }
+    for (uint32_t s = lane; s < nc; s += 64) c_vals[s0 + s] = acc[s];
+    __syncthreads();
+  }
+}
+
 hipError_t launch_csr_spgemm(const uint32_t *l_rowptr, const uint32_t *l_cols, const double *l_vals, const uint32_t *r_rowptr,
                              const uint32_t *r_cols, const double *r_vals, const uint32_t *c_rowptr, const uint32_t *c_cols, double *c_vals,
-                             int nrows, hipStream_t s, int dense_ncols) {
+                             int nrows, hipStream_t s, int dense_ncols, int max_row_c) {
   if (nrows <= 0) return hipSuccess;
   if (dense_ncols > 0 && dense_ncols <= CSR_DENSE_MAX_COLS) {
     hipLaunchKernelGGL(k_csr_spgemm_dense, dim3((unsigned)std::min(nrows, 8192)), dim3(64), 0, s, l_rowptr, l_cols, l_vals, r_rowptr, r_cols, r_vals,
                        c_vals, nrows, dense_ncols);
+    return hipGetLastError();
+  }
+  if (max_row_c > 0 && max_row_c <= 4096) {     // rows of C fit an LDS accumulator: a wave per row
+    int maxc = 64;
+    while (maxc < max_row_c) maxc *= 2;
+    const size_t lds = (size_t)maxc * 12;
+    hipLaunchKernelGGL(k_csr_spgemm_row, dim3((unsigned)std::min(nrows, 32768)), dim3(64), lds, s, l_rowptr, l_cols, l_vals, r_rowptr, r_cols, r_vals,
+                       c_rowptr, c_cols, c_vals, nrows, maxc);
     return hipGetLastError();
   }
   const unsigned blocks = (unsigned)std::min<size_t>(((size_t)nrows + 3) / 4, 16384);     // four rows (waves) per workgroup

@@ -158,7 +158,7 @@ def test_config3_readme_load_on_the_device(gpu):
     """BASELINE config 3 at the load SURVEY 8(d) states -- -bc_clamp 998,999 -bc_clamp_998_translate 0,-0.5,1 (README.rst:63) -- with
     hyperSS at degree 4 on the reference's own mesh.  What decides convergence is the size of a load increment, not the line search
     (profiles/r04_config3_readme_load.txt: the first increment of 10, 20 or 40 inverts the first layer of degree-4 elements at the clamp
-    -- det F < 0, tr eps < -1 -- whichever of the three line searches runs, PETSc's never-rejecting SNESLINESEARCHCP included; a
+    -- det F < 0, tr eps < -1 -- whichever of the three line searches runs, a never-rejecting one-step CP search in PETSc's form (restated from memory, unverified: profiles/r05_ab_experiments.txt item 9) included; a
     hundredth of the translation per increment converges with all three).  With -num_steps 100 the whole solve converges: recorded on
     the device 300 Newton / 4 929 Krylov iterations, clamp displacement reached (0.0316, 0.5155, 0.9984)."""
     mesh = load_mesh_npz(os.path.join(GOLDEN, "mesh_cylinder8_5580e_4ss_us.npz"))

@@ -11,7 +11,7 @@ its pole) pins a failure on the physics rather than on the solver.
     python tools/r4_config3_load.py > gpurun_out/r4/config3_load.txt
 """
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))     # (tools/archive/)
 sys.path.insert(0, ROOT)
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 import numpy as np
