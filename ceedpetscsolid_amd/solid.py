@@ -259,6 +259,13 @@ class SolidProblem:
         """Prolong_Ceed (matops.c:115-157), coarse level-1 -> level."""
         self.levels[level].opProlong.apply(xc, yf)
 
+    def prolong_add(self, level: int, xc: cd.Vector, yf: cd.Vector):
+        """yf += Prolong_Ceed(xc): CeedOperatorApplyAdd of opProlong -- the correction of a V-cycle added in place (one rank: no interface
+        sum between the prolongation and the addition).  Every fine node is written by its one owning element: the same bits as
+        prolong into a scratch vector followed by an axpy."""
+        L = self.ceed.L
+        L.chk(L.lib.CeedOperatorApplyAdd(self.levels[level].opProlong.h, xc.h, yf.h, cd.C.c_void_p(L.REQUEST_IMMEDIATE)))
+
     def restrict(self, level: int, xf: cd.Vector, yc: cd.Vector):
         """Restrict_Ceed (matops.c:160-203), level -> level-1."""
         self.levels[level].opRestrict.apply(xf, yc)

@@ -542,9 +542,12 @@ class NewtonPMG:
         self.p.restrict(lv, w["z"], wc["b"])                                # Restrict_Ceed
         self._halo_sum(lv - 1, wc["b"])
         self.vcycle(lv - 1, wc["b"], wc["x"])
-        self.p.prolong(lv, wc["x"], w["z"])                                 # Prolong_Ceed
-        self._halo_sum(lv, w["z"])
-        self.axpby(x, 1.0, w["z"], 1.0)
+        if not self.halos and self.fuse_epilogue:   # one rank: the correction added in place by the prolongation's owners (same bits)
+            self.p.prolong_add(lv, wc["x"], x)
+        else:
+            self.p.prolong(lv, wc["x"], w["z"])                             # Prolong_Ceed
+            self._halo_sum(lv, w["z"])
+            self.axpby(x, 1.0, w["z"], 1.0)
         self.chebyshev(lv, b, x, self.smooth_its, False)
 
     def _autotune_vcycle(self, r, z, reps=2):
