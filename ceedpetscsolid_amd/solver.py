@@ -182,7 +182,7 @@ class NewtonPMG:
         n = prob.lsize()
         top = self.nlev - 1
         self.U, self.R, self.dU, self.Xloc, self.bcv, self.Rtry, self.Utry = (self._vec(n, top) for _ in range(7))
-        self.kp, self.kz, self.kAp, self.kzold = (self._vec(n, top) for _ in range(4))
+        self.kp, self.kz, self.kAp = (self._vec(n, top) for _ in range(3))
         lvf = prob.levels[prob.fine]
         self.free = (lvf.mask == 0)
         self.weights = [None] * self.nlev
@@ -623,7 +623,7 @@ class NewtonPMG:
     def fcg(self, b, x, rtol):
         """Flexible preconditioned CG, natural-norm convergence test (KSP_NORM_NATURAL: sqrt(r'z))."""
         fine = self.nlev - 1
-        r, z, p, Ap, zold = self.w[fine]["b"], self.kz, self.kp, self.kAp, self.kzold
+        r, z, p, Ap = self.w[fine]["b"], self.kz, self.kp, self.kAp
         x.set_value(0.0)
         self.copy(r, b)
         self.precondition(r, z)
@@ -637,14 +637,14 @@ class NewtonPMG:
             self.A(fine, p, Ap)
             alpha = rz / self.dot(p, Ap, True)
             self.axpby(x, alpha, p, 1.0); self.axpby(r, -alpha, Ap, 1.0)
-            self.copy(zold, z)
+            r_zold = self.dot(r, z, True)                    # r_new . z_old, taken BEFORE the preconditioner overwrites z (no copy of z)
             self.precondition(r, z)
             rz_new = self.dot(r, z, True)
             if self.verbose:
                 print(f"      ksp {its:3d}  natural norm {np.sqrt(abs(rz_new)):.3e}")
             if rz_new <= rtol ** 2 * rz0:
                 break
-            beta = (rz_new - self.dot(r, zold, True)) / rz   # Polak-Ribiere: flexible
+            beta = (rz_new - r_zold) / rz                    # Polak-Ribiere: flexible
             self.axpby(p, 1.0, z, beta)
             rz = rz_new
         return its
