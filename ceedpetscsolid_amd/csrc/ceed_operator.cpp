@@ -685,7 +685,10 @@ static int apply_fused_epilogue(CeedOperator op, CeedVector in, CeedVector t, Ep
   *fused = true;
   ep.t = F.py;
   TimerScope ts(op, s);
-  if (c->opt.pipe_segments != 0) {
+  // Serial form by default: with the consumer in the epilogue the rows' launch is no longer light enough to hide beside the next
+  // segment's fused kernel, and the fork / join costs inside a replayed graph -- V-cycle at config 4's size: serial 6.05 ms eager and
+  // replayed, pipelined 6.10 eager / 6.83 replayed (profiles/r05_ab_experiments.txt item 10).  CEED_MI355X_EPI_PIPELINED=1: pipelined (tests).
+  if (c->opt.epi_pipelined && c->opt.pipe_segments != 0) {
     int waves = 0;
     {
       FusedGradArgs aq = F.a;

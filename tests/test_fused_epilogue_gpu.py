@@ -79,7 +79,7 @@ CASES = [
 @pytest.mark.parametrize("name,mk,degree,problem,bc", CASES, ids=[c[0] for c in CASES])
 def test_fused_chebyshev_step_and_residual_equal_the_two_steps_bitwise(product_lib, oracle, form, name, mk, degree, problem, bc):
     mesh = mk()
-    env = {"CEED_MI355X_ASSEMBLE": "serial"} if form == "serial" else {"CEED_MI355X_PIPE_MIN_ROUNDS": "0", "CEED_MI355X_PIPE_SEGMENTS": "3"}
+    env = {"CEED_MI355X_ASSEMBLE": "serial"} if form == "serial" else {"CEED_MI355X_PIPE_MIN_ROUNDS": "0", "CEED_MI355X_PIPE_SEGMENTS": "3", "CEED_MI355X_EPI_PIPELINED": "1"}
     gpu = _ceed_with_env(product_lib, env)
     p = SolidProblem(gpu, mesh, degree, problem, nu=0.3, E=1.0, bc_sides=bc)
     po = SolidProblem(oracle, mesh, degree, problem, nu=0.3, E=1.0, bc_sides=bc)
@@ -115,7 +115,7 @@ def test_fused_chebyshev_step_and_residual_equal_the_two_steps_bitwise(product_l
 def test_fused_chebyshev_sweep_recorded_and_replayed(product_lib):
     """Three fused steps recorded into a hipGraph (pipelined form: fork and join inside the capture) and replayed on new data
     against the eager two-step form."""
-    gpu = _ceed_with_env(product_lib, {"CEED_MI355X_PIPE_MIN_ROUNDS": "0", "CEED_MI355X_PIPE_SEGMENTS": "2"})
+    gpu = _ceed_with_env(product_lib, {"CEED_MI355X_PIPE_MIN_ROUNDS": "0", "CEED_MI355X_PIPE_SEGMENTS": "2", "CEED_MI355X_EPI_PIPELINED": "1"})
     mesh = hollow_cylinder_mesh(4, 16, 8)
     p = SolidProblem(gpu, mesh, 4, "hyperFS", nu=0.3, E=1.0, bc_sides=[998], multigrid="none")
     n = p.lsize()
