@@ -69,7 +69,7 @@ class CeedLib:
         "CeedXVectorPointwiseMult", "CeedXVectorAXPBY", "CeedXVectorDot", "CeedXVectorChebyshevUpdate",
         "CeedXGraphBeginCapture", "CeedXGraphEndCapture", "CeedXGraphLaunch", "CeedXGraphDestroy", "CeedXGraphIsStale",
         "CeedXOperatorApplyChebyshev", "CeedXOperatorApplyResidual", "CeedXClockProbe",
-        "CeedXVectorChebyshevStart", "CeedXVectorWAXPBY", "CeedXVectorDotTo", "CeedXScalarDivide", "CeedXVectorAXPBYScalars",
+        "CeedXVectorChebyshevStart", "CeedXVectorChebyshevStep", "CeedXVectorWAXPBY", "CeedXVectorDotTo", "CeedXScalarDivide", "CeedXVectorAXPBYScalars",
         "CeedXCsrCreate", "CeedXCsrAssemble", "CeedXCsrApply", "CeedXCsrGetDiagonal", "CeedXCsrDestroy",
         "CeedXCsrCreateRect", "CeedXCsrCreateProduct", "CeedXCsrGetPattern", "CeedXCsrUpdate", "CeedXCsrGetValues", "CeedXCsrInvertDenseSPD",
     ]

@@ -447,6 +447,23 @@ extern "C" int CeedXVectorChebyshevStart(CeedVector x, CeedVector d, CeedVector 
   HIPCHK(launch_cheb_update(px, pd, pr, pb, pt, pi, c1, 0., assign_x, (size_t)n, x->ceed->stream));
   return 0;
 }
+// One step with the residual RECOMPUTED from the right-hand side, as KSPCHEBYSHEV does (r = b - A x_k every iteration, not r -= A d):
+// ri = b - t (t may be NULL);  d = c1 dinv ri + c2 d;  x = d or x + d;  ri is stored only if r is given.
+extern "C" int CeedXVectorChebyshevStep(CeedVector x, CeedVector d, CeedVector r, CeedVector b, CeedVector t, CeedVector dinv,
+                                        double c1, double c2, int assign_x) {
+  double *px, *pd, *pr = nullptr, *pb, *pt = nullptr, *pi;
+  const CeedInt n = x->length;
+  const bool has_r = r && r != CEED_VECTOR_NONE, has_t = t && t != CEED_VECTOR_NONE;
+  if (d->length != n || b->length != n || dinv->length != n || (has_r && r->length != n) || (has_t && t->length != n))
+    return ceed_error("CeedXVectorChebyshevStep: vector lengths differ");
+  if (b == x || b == d || (has_r && b == r)) return ceed_error("CeedXVectorChebyshevStep: the right-hand side must be a vector of its own");
+  CHK(vec_dev(dinv, false, &pi)); CHK(vec_dev(b, false, &pb));
+  if (has_t) CHK(vec_dev(t, false, &pt));
+  if (has_r) CHK(vec_dev(r, true, &pr));
+  CHK(vec_dev(d, true, &pd)); CHK(vec_dev(x, true, &px));
+  HIPCHK(launch_cheb_update(px, pd, pr, pb, pt, pi, c1, c2, assign_x, (size_t)n, x->ceed->stream));
+  return 0;
+}
 extern "C" int CeedXVectorWAXPBY(CeedVector w, double a, CeedVector x, double b, CeedVector y) {
   if (x->length != w->length || y->length != w->length) return ceed_error("CeedXVectorWAXPBY: vector lengths differ");
   double *px, *py, *pw;

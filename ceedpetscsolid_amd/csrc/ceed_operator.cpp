@@ -1201,18 +1201,20 @@ static int epi_check(CeedOperator op, CeedVector in, CeedVector t, const char *w
 extern "C" int CeedXOperatorApplyChebyshev(CeedOperator op, CeedVector in, CeedVector t, CeedVector x, CeedVector d, CeedVector r,
                                            CeedVector b, CeedVector dinv, double c1, double c2, int assign_x) {
   CHK(epi_check(op, in, t, "CeedXOperatorApplyChebyshev"));
-  const bool first = b && b != CEED_VECTOR_NONE;
+  const bool first = b && b != CEED_VECTOR_NONE, has_r = r && r != CEED_VECTOR_NONE;
   const CeedInt n = x->length;
-  if (d->length != n || r->length != n || dinv->length != n || t->length != n || in->length != n || (first && b->length != n))
+  if (d->length != n || (has_r && r->length != n) || dinv->length != n || t->length != n || in->length != n || (first && b->length != n))
     return ceed_error("CeedXOperatorApplyChebyshev: vector lengths differ");
-  if (first && (b == r || b == x || b == d || c2 != 0.)) return ceed_error("CeedXOperatorApplyChebyshev: a first step takes a right-hand side of its own and c2 = 0");
-  if (t == x || t == d || t == r || t == dinv || (first && t == b)) return ceed_error("CeedXOperatorApplyChebyshev: the scratch vector t aliases an operand");
+  if (!first && !has_r) return ceed_error("CeedXOperatorApplyChebyshev: a residual vector r or a right-hand side b is needed");
+  if (first && ((has_r && b == r) || b == x || b == d)) return ceed_error("CeedXOperatorApplyChebyshev: the right-hand side must be a vector of its own");
+  if (t == x || t == d || (has_r && t == r) || t == dinv || (first && t == b)) return ceed_error("CeedXOperatorApplyChebyshev: the scratch vector t aliases an operand");
   EpilogueArgs ep{};
   ep.kind = EPI_CHEB;
   double *pb = nullptr, *pi;
   CHK(vec_dev(dinv, false, &pi));
   if (first) CHK(vec_dev(b, false, &pb));
-  CHK(vec_dev(r, true, &ep.r)); CHK(vec_dev(d, true, &ep.d)); CHK(vec_dev(x, true, &ep.x));
+  if (has_r) CHK(vec_dev(r, true, &ep.r));
+  CHK(vec_dev(d, true, &ep.d)); CHK(vec_dev(x, true, &ep.x));
   ep.r0 = pb; ep.dinv = pi; ep.c1 = c1; ep.c2 = c2; ep.assign_x = assign_x;
   const char *kname = "";
   bool fused = false;

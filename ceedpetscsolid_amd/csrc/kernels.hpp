@@ -245,7 +245,8 @@ struct EpilogueArgs {
   const double *t;          // the apply's output vector: holds the ELEMENT-INTERIOR nodes' values (stored by the fused kernel) only
   const uint32_t *int_off;  // node offsets of the element-interior nodes handled by this launch, n_int of them (0: none)
   int n_int;
-  // EPI_CHEB: r = (r0 ? r0 : r) - t;  d = c1 dinv r + c2 d;  x = assign_x ? d : x + d
+  // EPI_CHEB: r = (r0 ? r0 : r) - t (stored if r is given; r0 = the right-hand side b: the residual recomputed, not recurred);
+  //           d = c1 dinv r + c2 d;  x = assign_x ? d : x + d
   double *x, *d, *r;
   const double *r0, *dinv;
   double c1, c2;

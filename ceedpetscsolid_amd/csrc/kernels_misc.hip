@@ -637,7 +637,7 @@ __global__ void k_cheb_update(double *x, double *d, double *r, const double *r0,
                               double c2, int assign_x, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     // r0: the right-hand side of a first step (r = b - t without a copy of b)
-    cheb_dof(r0 ? r0[i] : r[i], t != nullptr, t ? t[i] : 0., t || r0, i, x, d, r, dinv, c1, c2, assign_x);
+    cheb_dof(r0 ? r0[i] : r[i], t != nullptr, t ? t[i] : 0., (t || r0) && r, i, x, d, r, dinv, c1, c2, assign_x);
 }
 __global__ void k_masked_copy(double *dst, const double *src, const unsigned char *mask, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -723,7 +723,7 @@ __global__ void k_assemble_epi(const uint32_t *rowptr, const uint32_t *cols, con
     for (size_t u = ((size_t)blockIdx.x - nb_rows) * blockDim.x + threadIdx.x; u < n; u += ((size_t)gridDim.x - nb_rows) * blockDim.x) {
       const size_t i = (size_t)(ep.int_off[u / 3] & OFF_MASK) + u % 3;
       const double ti = ep.t[i];
-      if (ep.kind == EPI_CHEB) cheb_dof(ep.r0 ? ep.r0[i] : ep.r[i], true, ti, true, i, ep.x, ep.d, ep.r, ep.dinv, ep.c1, ep.c2, ep.assign_x);
+      if (ep.kind == EPI_CHEB) cheb_dof(ep.r0 ? ep.r0[i] : ep.r[i], true, ti, ep.r != nullptr, i, ep.x, ep.d, ep.r, ep.dinv, ep.c1, ep.c2, ep.assign_x);
       else ep.w[i] = ep.b[i] - ti;
     }
     return;
@@ -784,7 +784,7 @@ __global__ void k_assemble_epi(const uint32_t *rowptr, const uint32_t *cols, con
       const double t0 = __shfl(a0, src, 64), t1 = __shfl(a1, src, 64), t2 = __shfl(a2, src, 64);
       const double ti = c == 0 ? t0 : (c == 1 ? t1 : t2);
       if (!ok[q]) continue;
-      if (ep.kind == EPI_CHEB) cheb_dof_regs(s0[q], true, ti, true, idx[q], s1[q], s2[q], s3[q], ep.x, ep.d, ep.r, ep.c1, ep.c2, ep.assign_x);
+      if (ep.kind == EPI_CHEB) cheb_dof_regs(s0[q], true, ti, ep.r != nullptr, idx[q], s1[q], s2[q], s3[q], ep.x, ep.d, ep.r, ep.c1, ep.c2, ep.assign_x);
       else ep.w[idx[q]] = s0[q] - ti;
     }
   }

@@ -308,14 +308,20 @@ CEED_EXTERN int CeedXVectorChebyshevStart(CeedVector x, CeedVector d, CeedVector
                                           CeedVector t /* or NULL */, CeedVector dinv,
                                           double c1, int assign_x);
 CEED_EXTERN int CeedXVectorWAXPBY(CeedVector w, double a, CeedVector x, double b, CeedVector y);
+/* A step with the residual recomputed from the right-hand side (t = A x_k):   */
+/*   ri = b - t (t may be NULL);  d = c1 * dinv .* ri + c2 * d;  x = d or     */
+/*   x + d;  ri is stored only if r is not NULL.                               */
+CEED_EXTERN int CeedXVectorChebyshevStep(CeedVector x, CeedVector d, CeedVector r /* or NULL */, CeedVector b,
+                                         CeedVector t /* or NULL */, CeedVector dinv, double c1, double c2, int assign_x);
 /* The operator apply with its CONSUMER fused behind it (round 5): t = A in is  */
 /* used where it is formed and never stored as a whole (t: scratch L-vector;  */
 /* its contents afterwards are unspecified).  What the smoother and the       */
 /* V-cycle of elasticity.c:539-552, 588-590 do with a Jacobian apply:         */
 /*   ApplyChebyshev: r = (b or r) - A in;  d = c1 * dinv .* r + c2 * d;       */
-/*     x = d if assign_x else x + d.  `in` may be d or x themselves (the      */
-/*     Chebyshev recurrence applies the operator to its own direction).       */
-/*     Same bits as CeedOperatorApply + CeedXVectorChebyshevUpdate / Start.   */
+/*     x = d if assign_x else x + d.  `in` may be d or x themselves.  With b  */
+/*     (and in = x) the residual is RECOMPUTED from the iterate every step,   */
+/*     as KSPCHEBYSHEV does, and r may be NULL (it is then not stored).       */
+/*     Same bits as CeedOperatorApply + CeedXVectorChebyshevStep / Update.    */
 /*   ApplyResidual: w = b - A in.                                             */
 /* Single-rank L-vectors (no interface sum between the apply and its consumer).*/
 CEED_EXTERN int CeedXOperatorApplyChebyshev(CeedOperator op, CeedVector in, CeedVector t, CeedVector x, CeedVector d,

@@ -1123,6 +1123,24 @@ int CeedXVectorChebyshevStart(CeedVector x, CeedVector d, CeedVector r, CeedVect
   }
   return 0;
 }
+int CeedXVectorChebyshevStep(CeedVector x, CeedVector d, CeedVector r, CeedVector b, CeedVector t, CeedVector dinv,
+                             double c1, double c2, int assign_x) {
+  vec_ensure(x); vec_ensure(d); vec_ensure(b); vec_ensure(dinv);
+  const int have_t = t && t != CEED_VECTOR_NONE, have_r = r && r != CEED_VECTOR_NONE;
+  if (have_t) vec_ensure(t);
+  if (have_r) vec_ensure(r);
+  if (b == x || b == d || (have_r && b == r)) return oracle_error("CeedXVectorChebyshevStep: the right-hand side must be a vector of its own");
+  for (CeedInt i = 0; i < x->length; i++) {
+    double ri = b->array[i];
+    if (have_t) ri -= t->array[i];
+    if (have_r) r->array[i] = ri;
+    double di = (c1 * dinv->array[i]) * ri;
+    if (c2 != 0.) di = fma(c2, d->array[i], di);
+    d->array[i] = di;
+    x->array[i] = assign_x ? di : x->array[i] + di;
+  }
+  return 0;
+}
 int CeedXVectorChebyshevUpdate(CeedVector x, CeedVector d, CeedVector r, CeedVector t, CeedVector dinv,
                                double c1, double c2, int assign_x) {
   vec_ensure(x); vec_ensure(d); vec_ensure(r); vec_ensure(dinv);
@@ -1142,10 +1160,7 @@ int CeedXOperatorApplyChebyshev(CeedOperator op, CeedVector in, CeedVector t, Ce
                                 CeedVector dinv, double c1, double c2, int assign_x) {
   int ierr = CeedOperatorApply(op, in, t, CEED_REQUEST_IMMEDIATE);
   if (ierr) return ierr;
-  if (b && b != CEED_VECTOR_NONE) {
-    if (c2 != 0.) return oracle_error("CeedXOperatorApplyChebyshev: a first step (b given) has c2 = 0");
-    return CeedXVectorChebyshevStart(x, d, r, b, t, dinv, c1, assign_x);
-  }
+  if (b && b != CEED_VECTOR_NONE) return CeedXVectorChebyshevStep(x, d, r, b, t, dinv, c1, c2, assign_x);
   return CeedXVectorChebyshevUpdate(x, d, r, t, dinv, c1, c2, assign_x);
 }
 int CeedXOperatorApplyResidual(CeedOperator op, CeedVector in, CeedVector t, CeedVector b, CeedVector w) {

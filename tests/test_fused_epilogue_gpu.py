@@ -36,10 +36,11 @@ def _vectors(c, n, arrs):
 
 
 def _cheb_pair(p, lv, arrs, first, in_place=True):
-    """(unfused, fused) results {x, d, r} of one Chebyshev step on level lv from the same host arrays."""
+    """(unfused, fused) results {x, d, r} of one Chebyshev step on level lv from the same host arrays.  first: False = the recurrence
+    step (r -= A d), True = a first step (r = b - A x, c2 = 0), "recomputed" = the solver's step (r = b - A x with c2 != 0, r not stored)."""
     c, L, op = p.ceed, p.ceed.L, p.levels[lv].opJacob
     n = p.lsize(lv)
-    c1, c2 = C.c_double(0.37), C.c_double(0.0 if first else 0.21)
+    c1, c2 = C.c_double(0.37), C.c_double(0.0 if first is True else 0.21)
     out = []
     for fused in (False, True):
         v = _vectors(c, n, arrs)
@@ -47,11 +48,14 @@ def _cheb_pair(p, lv, arrs, first, in_place=True):
         src = v["x"] if first else v["d"]
         if not in_place:
             src = c.vector(n).set_array(arrs["x"] if first else arrs["d"])
+        r = None if first == "recomputed" else v["r"].h
         if fused:
-            L.chk(L.lib.CeedXOperatorApplyChebyshev(op.h, src.h, t.h, v["x"].h, v["d"].h, v["r"].h, v["b"].h if first else None, v["dinv"].h, c1, c2, 0))
+            L.chk(L.lib.CeedXOperatorApplyChebyshev(op.h, src.h, t.h, v["x"].h, v["d"].h, r, v["b"].h if first else None, v["dinv"].h, c1, c2, 0))
         else:
             op.apply(src, t)
-            if first:
+            if first == "recomputed":
+                L.chk(L.lib.CeedXVectorChebyshevStep(v["x"].h, v["d"].h, None, v["b"].h, t.h, v["dinv"].h, c1, c2, 0))
+            elif first:
                 L.chk(L.lib.CeedXVectorChebyshevStart(v["x"].h, v["d"].h, v["r"].h, v["b"].h, t.h, v["dinv"].h, c1, 0))
             else:
                 L.chk(L.lib.CeedXVectorChebyshevUpdate(v["x"].h, v["d"].h, v["r"].h, t.h, v["dinv"].h, c1, c2, 0))
@@ -90,7 +94,7 @@ def test_fused_chebyshev_step_and_residual_equal_the_two_steps_bitwise(product_l
         q.form_residual(X, Y)                                    # the stored state of the tangent
     for lv in range(len(p.levels)):
         arrs = _arrays(p, lv, 100 + lv)
-        for first in (False, True):
+        for first in (False, True, "recomputed"):
             for in_place in (True, False):
                 a, b = _cheb_pair(p, lv, arrs, first, in_place)
                 for k in ("x", "d", "r"):
