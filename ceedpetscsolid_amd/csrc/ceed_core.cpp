@@ -89,6 +89,7 @@ extern "C" int CeedInit(const char *resource, Ceed *ceed) {
   o.comm_inline = env_int("CEED_MI355X_COMM_INLINE", o.comm_inline);
   o.fold_pack = env_int("CEED_MI355X_FOLD_PACK", o.fold_pack);
   o.spgemm_row = !env_is("CEED_MI355X_SPGEMM", "entry");
+  o.spmv_stream = !env_is("CEED_MI355X_SPMV", "vector");
   o.epi_pipelined = env_int("CEED_MI355X_EPI_PIPELINED", 0) != 0;
   *ceed = c;
   return 0;

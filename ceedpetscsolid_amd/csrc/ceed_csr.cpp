@@ -18,6 +18,8 @@ struct CeedXCsr_private {
   int *d_info = nullptr;
   bool dense = false;       // full pattern, columns ascending: vals is a row-major nrows x nrows matrix
   int max_row = 0;          // longest row of the pattern (products: chooses the kernel of CeedXCsrUpdate)
+  uint32_t *d_row_block = nullptr;   // CSR-stream runs of CeedXCsrApply (launch_csr_spmv_stream), cut at the first apply
+  int n_row_blocks = 0;
   int refs = 1;             // an operand is kept alive by the products formed from it
   std::vector<int> h_rowptr, h_cols;      // host copy of the pattern (operand of CeedXCsrCreateProduct)
 };
@@ -82,11 +84,32 @@ extern "C" int CeedXCsrAssemble(CeedXCsr A, CeedVector coo_values) {
   HIPCHK(launch_csr_sum(A->d_slotptr, A->d_perm, pc, A->d_vals, A->nnz, A->d_unit_slot, A->n_unit, A->ceed->stream));
   return 0;
 }
+// runs of consecutive rows for the CSR-stream SpMV: at most 2048 entries and 256 rows each; a longer row alone
+static int csr_row_blocks(CeedXCsr A) {
+  if (A->d_row_block) return 0;
+  if (A->ceed->capturing) return ceed_error("CeedXCsrApply: first apply of a matrix during graph capture; apply it once before recording");
+  std::vector<uint32_t> rb(1, 0u);
+  int r = 0;
+  while (r < A->nrows) {
+    int r1 = r + 1;
+    long nz = (long)A->h_rowptr[r + 1] - A->h_rowptr[r];
+    while (r1 < A->nrows && r1 - r < 256 && nz + ((long)A->h_rowptr[r1 + 1] - A->h_rowptr[r1]) <= 2048) { nz += (long)A->h_rowptr[r1 + 1] - A->h_rowptr[r1]; r1++; }
+    rb.push_back((uint32_t)r1);
+    r = r1;
+  }
+  A->n_row_blocks = (int)rb.size() - 1;
+  CHK(csr_upload(&A->d_row_block, rb));
+  return 0;
+}
 extern "C" int CeedXCsrApply(CeedXCsr A, CeedVector x, CeedVector y) {
   if (x == y) return ceed_error("CeedXCsrApply: in-place apply is not supported");
   if (x->length < A->ncols || y->length < A->nrows) return ceed_error("CeedXCsrApply: vector shorter than the matrix");
   double *px, *py;
   CHK(vec_dev(x, false, &px)); CHK(vec_dev(y, true, &py));
+  if (A->ceed->opt.spmv_stream) {
+    CHK(csr_row_blocks(A));
+    HIPCHK(launch_csr_spmv_stream(A->d_row_block, A->n_row_blocks, A->d_rowptr, A->d_cols, A->d_vals, px, py, A->ceed->stream));
+  } else
   HIPCHK(launch_csr_spmv(A->d_rowptr, A->d_cols, A->d_vals, px, py, A->nrows, A->ceed->stream));
   return 0;
 }
@@ -245,7 +268,7 @@ extern "C" int CeedXCsrDestroy(CeedXCsr *csr) {
   *csr = nullptr;
   if (--A->refs > 0) return 0;        // still the source of another matrix: freed with the last of those
   (void)hipStreamSynchronize(A->ceed->stream);
-  for (uint32_t *p : {A->d_rowptr, A->d_cols, A->d_slotptr, A->d_perm, A->d_unit_slot, A->d_diag_slot})
+  for (uint32_t *p : {A->d_rowptr, A->d_cols, A->d_slotptr, A->d_perm, A->d_unit_slot, A->d_diag_slot, A->d_row_block})
     if (p) (void)hipFree(p);
   for (double *p : {A->d_vals, A->d_gj}) if (p) (void)hipFree(p);
   if (A->d_info) (void)hipFree(A->d_info);

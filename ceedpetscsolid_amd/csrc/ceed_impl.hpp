@@ -52,6 +52,7 @@ struct CeedOptions {
                                  // sequence); 2 split-phase on two streams (both phases' fused kernels side by side)
   int ovl_groups0 = 1, ovl_groups1 = 0;   // CEED_MI355X_OVL_G0 / _G1: groups per wave of the two phases (0: persistent grid)
   bool epi_pipelined = false;    // CEED_MI355X_EPI_PIPELINED=1: the apply fused with its consumer in the pipelined form too (default: serial, measured faster)
+  bool spmv_stream = true;       // CEED_MI355X_SPMV=vector: CeedXCsrApply a wave per row (rounds 2-4's kernel, A/B) instead of the CSR-stream form
   bool spgemm_row = true;        // CEED_MI355X_SPGEMM=entry: Galerkin products an entry of C per lane with binary searches in global memory (round 3's kernel, A/B)
   int fold_pack = 1;             // CEED_MI355X_FOLD_PACK=0: the exchange's pack as a launch of its own (A/B)
   int comm_inline = 1;           // CEED_MI355X_COMM_INLINE=0: the exchange's sends / receives on a stream of their own (see halo_pack_and_send)

@@ -298,6 +298,10 @@ hipError_t launch_csr_sum(const uint32_t *slotptr, const uint32_t *perm, const d
                           const uint32_t *unit_diag_slot, int n_unit, hipStream_t s);
 hipError_t launch_csr_spmv(const uint32_t *rowptr, const uint32_t *cols, const double *vals, const double *x, double *y,
                            int nrows, hipStream_t s);
+// CSR-stream form: row_block[b] .. row_block[b + 1] are consecutive rows with at most 2048 entries in all (a longer row is a run of its
+// own), at most 256 rows per run; cut by csr_row_blocks() on the host
+hipError_t launch_csr_spmv_stream(const uint32_t *row_block, int nblocks, const uint32_t *rowptr, const uint32_t *cols, const double *vals,
+                                  const double *x, double *y, hipStream_t s);
 hipError_t launch_csr_diag(const uint32_t *diag_slot_of_row, const double *vals, double *d, int nrows, hipStream_t s);
 hipError_t launch_csr_spgemm(const uint32_t *l_rowptr, const uint32_t *l_cols, const double *l_vals, const uint32_t *r_rowptr,
                              const uint32_t *r_cols, const double *r_vals, const uint32_t *c_rowptr, const uint32_t *c_cols, double *c_vals,

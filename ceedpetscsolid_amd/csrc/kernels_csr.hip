@@ -29,6 +29,64 @@ __global__ __launch_bounds__(256) void k_csr_spmv(const uint32_t *rowptr, const 
     if (lane == 0) y[r] = a;
   }
 }
+// y = A x, "CSR-stream" form (round 5): a workgroup owns a run of CONSECUTIVE rows holding at most SPMV_CHUNK entries (row_block[b] ..
+// row_block[b + 1], cut on the host once per pattern).  Its entries are fetched in ONE coalesced sweep that does not wait for rowptr
+// (cols and vals of the run are contiguous), multiplied by the gathered x into LDS, and every row is then summed from LDS by T lanes (T a
+// power of two, the partial sums joined by a butterfly): two dependent memory trips (cols -> x) with up to 24 KB in flight per workgroup,
+// instead of three (rowptr -> cols, vals -> x) with 1.3 KB per wave in the wave-per-row form -- the p = 1 level of config 4 (330 k rows of
+// 81) ran at 2.7 TB/s that way.  A row longer than the chunk is a run of its own, summed by the whole workgroup.  Fixed summation order.
+constexpr int SPMV_CHUNK = 2048, SPMV_BLOCK = 256;
+__global__ __launch_bounds__(SPMV_BLOCK) void k_csr_spmv_stream(const uint32_t *row_block, const uint32_t *rowptr, const uint32_t *cols,
+                                                               const double *vals, const double *x, double *y) {
+  __shared__ double prod[SPMV_CHUNK];
+  const int tid = threadIdx.x;
+  const uint32_t r0 = row_block[blockIdx.x], r1 = row_block[blockIdx.x + 1];
+  const uint32_t k0 = rowptr[r0], k1 = rowptr[r1], n = k1 - k0;
+  const int nrows = (int)(r1 - r0);
+  if (n > (uint32_t)SPMV_CHUNK) {               // one long row: strided partial sums, then a fixed tree over the workgroup
+    double a = 0.;
+    for (uint32_t k = k0 + tid; k < k1; k += SPMV_BLOCK) a += vals[k] * x[cols[k]];
+    prod[tid] = a;
+    __syncthreads();
+    for (int o = SPMV_BLOCK / 2; o > 0; o >>= 1) {
+      if (tid < o) prod[tid] += prod[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) y[r0] = prod[0];
+    return;
+  }
+  // lanes per row: the largest power of two with nrows * T <= SPMV_BLOCK (at most 64: a butterfly inside one wave)
+  int T = 1;
+  while (T < 64 && nrows * (2 * T) <= SPMV_BLOCK) T *= 2;
+  const int row = tid / T, sub = tid % T;
+  uint32_t ra = 0, rb = 0;
+  if (row < nrows) { ra = rowptr[r0 + row] - k0; rb = rowptr[r0 + row + 1] - k0; }     // (requested with the sweep, needed after it)
+  constexpr int TRIPS = SPMV_CHUNK / SPMV_BLOCK;
+  uint32_t cc[TRIPS];
+  double vv[TRIPS];
+#pragma unroll
+  for (int j = 0; j < TRIPS; j++) {
+    const uint32_t i = (uint32_t)tid + j * SPMV_BLOCK, k = k0 + (i < n ? i : 0);
+    cc[j] = cols[k]; vv[j] = vals[k];
+  }
+#pragma unroll
+  for (int j = 0; j < TRIPS; j++) {
+    const uint32_t i = (uint32_t)tid + j * SPMV_BLOCK;
+    const double xv = x[cc[j]];
+    if (i < n) prod[i] = vv[j] * xv;
+  }
+  __syncthreads();
+  double a = 0.;
+  for (uint32_t i = ra + sub; i < rb; i += T) a += prod[i];
+  for (int o = T / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (row < nrows && sub == 0) y[r0 + row] = a;
+}
+hipError_t launch_csr_spmv_stream(const uint32_t *row_block, int nblocks, const uint32_t *rowptr, const uint32_t *cols, const double *vals,
+                                  const double *x, double *y, hipStream_t s) {
+  if (nblocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_csr_spmv_stream, dim3((unsigned)nblocks), dim3(SPMV_BLOCK), 0, s, row_block, rowptr, cols, vals, x, y);
+  return hipGetLastError();
+}
 __global__ void k_csr_diag(const uint32_t *diag_slot_of_row, const double *vals, double *d, int nrows) {
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
     const uint32_t s = diag_slot_of_row[r];

@@ -244,6 +244,17 @@ __global__ __launch_bounds__(64) void k_transfer(const BasisTables tab, const Tr
       double xin[SR];
 #pragma unroll
       for (int r = 0; r < SR; r++) xin[r] = a.x[(offc[r] & OFF_MASK) + (lane + 64 * r) % 3];
+      // ApplyAdd (the V-cycle's correction added in place): the old values of the owned nodes are requested NOW, behind the
+      // owner list that has just landed, so that their latency passes under the three passes instead of in front of the stores
+      double yold[KR][PF];
+      if (a.add) {
+#pragma unroll
+        for (int r = 0; r < KR; r++) {
+          const int c = ((lane + 64 * r) % (3 * F2)) % 3;
+#pragma unroll
+          for (int f = 0; f < PF; f++) yold[r][f] = own[r][f] == XFER_SKIP ? 0. : a.y[(own[r][f] & OFF_MASK) + c];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < SR; r++) {
         const int t = lane + 64 * r, c = t % 3;
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(64) void k_transfer(const BasisTables tab, const Tr
           double *dst = a.y + (off & OFF_MASK) + c;
           if constexpr (WEIGHTED) s *= a.w_f[(off & OFF_MASK) + c];
           if (a.mask_f && ((off >> (OFF_FLAG_SHIFT + c)) & 1u)) s = 0.;
-          *dst = a.add ? *dst + s : s;
+          *dst = a.add ? yold[r][f] + s : s;
         }
       }
     } else {
