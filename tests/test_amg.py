@@ -265,3 +265,49 @@ def test_config3_solve_with_the_aggregation_coarse_solve(gpu):
         res[coarse] = (s.U.to_numpy(), st.ksp_its, st.seconds)
     assert rel_err(res["amg"][0], res["assembled"][0]) < 1e-6
     assert res["amg"][1] < 0.55 * res["assembled"][1], (res["amg"][1], res["assembled"][1])
+
+
+@pytest.mark.gpu
+def test_csr_apply_and_products_on_ragged_patterns(gpu):
+    """CeedXCsrApply in the CSR-stream form (round 5: runs of rows swept into LDS) and CeedXCsrUpdate a wave per row, on patterns that
+    reach every branch: empty rows, rows of one entry, runs cut by the 2 048-entry and the 256-row limits, a row LONGER than a run
+    (3 000 entries: summed by the whole workgroup), product rows beyond the 4 096-entry LDS accumulator (the entry-per-lane kernel)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(3)
+    n, m = 1500, 5000
+    lens = rng.integers(0, 40, n)
+    lens[7], lens[8], lens[400], lens[401:700] = 3000, 0, 2048, 1
+    rows = np.repeat(np.arange(n), lens)
+    cols = np.concatenate([np.sort(rng.choice(m, k, replace=False)) for k in lens]) if lens.sum() else np.zeros(0, dtype=np.int64)
+    A = sp.csr_matrix((rng.uniform(-1, 1, rows.size), (rows, cols)), shape=(n, m))
+    a = cd.Csr.rect(gpu, n, m, A.indptr, A.indices, A.data)
+    x = rng.uniform(-1, 1, m)
+    X, Y = gpu.vector(m).set_array(x), gpu.vector(n).set_value(7.0)
+    a.apply(X, Y)
+    ref = A @ x
+    assert np.abs(Y.to_numpy() - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    assert Y.to_numpy()[8] == 0.0                                     # the empty row is written, not skipped
+    # products: B (m x q) with a few very long rows makes rows of A B longer than 4 096 entries
+    q = 9000
+    blens = rng.integers(1, 6, m)
+    blens[A.indices[A.indptr[7]:A.indptr[7] + 40]] = 150               # the long row of A meets long rows of B
+    brow = np.repeat(np.arange(m), blens)
+    bcol = np.concatenate([np.sort(rng.choice(q, k, replace=False)) for k in blens])
+    B = sp.csr_matrix((rng.uniform(-1, 1, brow.size), (brow, bcol)), shape=(m, q))
+    b = cd.Csr.rect(gpu, m, q, B.indptr, B.indices, B.data)
+    C = cd.Csr.product(a, b, variable=0)
+    C.update()
+    nr, nc, nz, rp, cl = C.pattern()
+    ref = (A @ B).tocsr(); ref.sort_indices()
+    assert int(np.diff(rp).max()) > 4096 and nz == ref.nnz and np.array_equal(rp, ref.indptr) and np.array_equal(cl, ref.indices)
+    assert np.abs(C.values(gpu) - ref.data).max() <= 1e-12 * np.abs(ref.data).max()
+    # the same product with short rows only: the wave-per-row kernel
+    A2 = A[20:390]
+    a2 = cd.Csr.rect(gpu, A2.shape[0], m, A2.indptr, A2.indices, A2.data)
+    C2 = cd.Csr.product(a2, b, variable=0)
+    C2.update()
+    ref2 = (A2 @ B).tocsr(); ref2.sort_indices()
+    assert int(np.diff(C2.pattern()[3]).max()) <= 4096
+    assert np.abs(C2.values(gpu) - ref2.data).max() <= 1e-12 * np.abs(ref2.data).max()
+    for o in (C2, a2, C, b, a):
+        o.destroy()
