@@ -389,6 +389,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=5,
                     help="timed blocks of --steps applies each (every block between a barrier + synchronize on both sides, one hipEvent pair "
                          "each): ms_per_step and value are the MEDIAN block's, the spread over the blocks is reported beside them")
+    ap.add_argument("--no-clock-probe", action="store_true",
+                    help="skip the untimed block of applies with the shader-clock probe beside it (profiling runs: the trace then ends with the timed block)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no device, no operator: the N ranks rendezvous on gloo, partition the mesh as the real run does and time the "
                          "interface sums of a test vector over torch.distributed; the line says \"dry_run\": true and \"value\": null")
@@ -611,14 +613,15 @@ def main():
     # the shader clock WHILE the applies run: one more (untimed) block is queued and a one-wave probe on a stream of its own counts
     # shader cycles against the 100 MHz counter for part of it -- a slow box (clock) is then distinguishable from a slow build
     clock_ghz = None
-    try:
-        for _ in range(args.steps):
-            step()
-        clock_ghz = ceed.clock_probe(int(max(200, min(2000, 0.5e3 * blk_dev[imed]))))
-        torch.cuda.synchronize()
-    except Exception as e:   # noqa: BLE001  (informational)
-        clock_ghz = None
-        print(f"[bench] clock probe failed: {e}", file=sys.stderr)
+    if not args.no_clock_probe:
+        try:
+            for _ in range(args.steps):
+                step()
+            clock_ghz = ceed.clock_probe(int(max(200, min(2000, 0.5e3 * blk_dev[imed]))))
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001  (informational)
+            clock_ghz = None
+            print(f"[bench] clock probe failed: {e}", file=sys.stderr)
     if args.phase_timing:
         pbuf = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
         os.environ["CEED_MI355X_PHASE_BUF"] = hex(pbuf.data_ptr())

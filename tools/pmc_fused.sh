@@ -7,7 +7,7 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
          "SQ_WAVES SQ_INSTS_VMEM SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM" \
          "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT"; do
   i=$((i+1))
-  env "$@" timeout -k 10 150 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$i -- python3 $R/bench.py $BENCH_ARGS --steps 5 --warmup 2 --blocks 1 --prewarm-ms 0 --cold-idle-s 0 --no-cpu-baseline > $R/gpurun_out/pmc_${tag}_$i.log 2>&1 || { echo "pass $i failed"; tail -3 $R/gpurun_out/pmc_${tag}_$i.log; }
+  env "$@" timeout -k 10 150 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$i -- python3 $R/bench.py $BENCH_ARGS --steps 5 --warmup 2 --blocks 1 --no-clock-probe --prewarm-ms 0 --cold-idle-s 0 --no-cpu-baseline > $R/gpurun_out/pmc_${tag}_$i.log 2>&1 || { echo "pass $i failed"; tail -3 $R/gpurun_out/pmc_${tag}_$i.log; }
   f=$(find /tmp/pmc_${tag}_$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp $f $R/gpurun_out/pmc_${tag}_pass$i.csv
 done

@@ -10,10 +10,10 @@ python3 $R/bench.py "$@" > $O/${T}_bench.json 2> $O/${T}_bench.err || { echo ben
 echo "bench done: $(python3 -c "import json; d=json.loads(open('$O/${T}_bench.json').read()); print(d['value'], d['ms_per_step'], d.get('ms_per_step_cold'), d['roofline']['frac'], (d.get('cpu_baseline') or {}).get('value'), (d['roofline'].get('valu_issue') or {}).get('valu_issue_frac'))")"
 for pw in 150 0; do
   rm -rf /tmp/prof_stats_$pw
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats_$pw -- python3 $R/bench.py "$@" --steps 50 --warmup 5 --blocks 1 --prewarm-ms $pw --cold-idle-s 0 --no-cpu-baseline > $O/${T}_stats_run_$pw.log 2>&1 || { echo stats failed; tail -5 $O/${T}_stats_run_$pw.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats_$pw -- python3 $R/bench.py "$@" --steps 50 --warmup 5 --blocks 1 --no-clock-probe --prewarm-ms $pw --cold-idle-s 0 --no-cpu-baseline > $O/${T}_stats_run_$pw.log 2>&1 || { echo stats failed; tail -5 $O/${T}_stats_run_$pw.log; exit 1; }
 done
 rm -rf /tmp/prof_stats_serial
-CEED_MI355X_ASSEMBLE=serial timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats_serial -- python3 $R/bench.py "$@" --steps 50 --warmup 5 --blocks 1 --cold-idle-s 0 --no-cpu-baseline > $O/${T}_stats_run_serial.log 2>&1 || { echo serial stats failed; tail -5 $O/${T}_stats_run_serial.log; exit 1; }
+CEED_MI355X_ASSEMBLE=serial timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats_serial -- python3 $R/bench.py "$@" --steps 50 --warmup 5 --blocks 1 --no-clock-probe --cold-idle-s 0 --no-cpu-baseline > $O/${T}_stats_run_serial.log 2>&1 || { echo serial stats failed; tail -5 $O/${T}_stats_run_serial.log; exit 1; }
 grep '^{"metric"' $O/${T}_stats_run_serial.log > $O/${T}_bench_serial_form.json
 cp $(find /tmp/prof_stats_serial -name "*kernel_stats.csv" | head -1) $O/${T}_kernel_stats_serial_form.csv
 cp $(find /tmp/prof_stats_150 -name "*kernel_stats.csv" | head -1) $O/${T}_kernel_stats.csv
@@ -54,7 +54,7 @@ tail -2 $O/${T}_dispatch_series.txt
 echo "stats done"
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
-  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -- python3 $R/bench.py "$@" --steps 5 --warmup 2 --blocks 1 --prewarm-ms 0 --cold-idle-s 0 --no-cpu-baseline --calibrate-traffic > $O/${T}_pmc_$C.log 2>&1 || { echo pmc $C failed; tail -5 $O/${T}_pmc_$C.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -- python3 $R/bench.py "$@" --steps 5 --warmup 2 --blocks 1 --no-clock-probe --prewarm-ms 0 --cold-idle-s 0 --no-cpu-baseline --calibrate-traffic > $O/${T}_pmc_$C.log 2>&1 || { echo pmc $C failed; tail -5 $O/${T}_pmc_$C.log; exit 1; }
   cp $(find /tmp/pmc_$C -name "*counter_collection.csv" | head -1) $O/${T}_pmc_$C.csv
   echo "pmc $C done"
 done
