@@ -57,8 +57,10 @@ def test_transfer_matches_oracle_and_is_adjoint(oracle, gpu, name, mk, degree, k
             Yf.set_value(5.0); Yc.set_value(5.0)                    # overwrite semantics
             p.prolong(lv, Xc, Yf); p.restrict(lv, Xf, Yc)
             out.append((Yf.to_numpy(), Yc.to_numpy()))
-        assert rel_err(out[1][0], out[0][0]) < TOL, (lv, "prolong")
-        assert rel_err(out[1][1], out[0][1]) < TOL, (lv, "restrict")
+        # the owner form differs from the reference's sum over the sharing elements x 1 / multiplicity by ROUNDING only: held at 1e-13,
+        # three orders inside the parity bar
+        assert rel_err(out[1][0], out[0][0]) < 1e-13, (lv, "prolong", rel_err(out[1][0], out[0][0]))
+        assert rel_err(out[1][1], out[0][1]) < 1e-13, (lv, "restrict", rel_err(out[1][1], out[0][1]))
         assert "prolong<" in pb.levels[lv].opProlong.kernel_name and "restrict<" in pb.levels[lv].opRestrict.kernel_name
         # constrained entries: zero on both sides
         assert np.all(out[1][0][pa.levels[lv].mask != 0] == 0.0) and np.all(out[1][1][pa.levels[lv - 1].mask != 0] == 0.0)
