@@ -834,6 +834,7 @@ static int transfer_weights(CeedOperator op, CeedElemRestriction rf, const doubl
   HIPCHK(hipStreamSynchronize(c->stream));      // set-up time only
   (void)hipFree(d_cnt);
   op->w_unit = cnt == 0; op->w_scale = sc; op->w_version = ver; op->w_ready = true;
+  if (op->w_unit) { ceed_retire(c, op->d_w); op->d_w = nullptr; op->w_len = 0; }     // (not needed again until the scale is rewritten: 8 B per fine dof given back)
   *w = op->w_unit ? nullptr : op->d_w;
   return 0;
 }
