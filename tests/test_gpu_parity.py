@@ -274,6 +274,49 @@ def test_full_size_matches_oracle(oracle, oracle_lib, gpu, which):
         oracle_lib.lib.OracleSetNumThreads(C.c_int(1))
 
 
+def test_full_size_transfers_and_fused_step_config4(oracle, oracle_lib, gpu):
+    """Round 5 at BASELINE config 4's FULL size (99 000 hexes, levels p = 1, 2, 4): Prolong_Ceed / Restrict_Ceed in owner form against
+    the oracle's sum over the sharing elements at 1e-13 on both level pairs (49 500 groups over the eight XCD chunks), Restrict =
+    Prolong^T, and the apply fused with its consumer bitwise equal to the two-pass form on the fine level (19.4 M dofs)."""
+    import ctypes as C
+    mesh = hollow_cylinder_mesh(10, 110, 90)
+    nthreads = max(1, min(16, len(os.sched_getaffinity(0))))
+    oracle_lib.lib.OracleSetNumThreads(C.c_int(nthreads))
+    try:
+        pa, pb = build_pair(oracle, gpu, mesh, 4, "linElas", nu=0.3, E=1.0, bc_sides=[998, 999])
+        rng = np.random.default_rng(8)
+        for lv in (1, 2):
+            nf, nc = pa.lsize(lv), pa.lsize(lv - 1)
+            xc, xf = rng.uniform(-1, 1, nc), rng.uniform(-1, 1, nf)
+            res = []
+            for p in (pa, pb):
+                Xc, Xf, Yf, Yc = p.ceed.vector(nc).set_array(xc), p.ceed.vector(nf).set_array(xf), p.ceed.vector(nf), p.ceed.vector(nc)
+                p.prolong(lv, Xc, Yf); p.restrict(lv, Xf, Yc)
+                res.append((Yf.to_numpy(), Yc.to_numpy()))
+            assert rel_err(res[1][0], res[0][0]) < 1e-13 and rel_err(res[1][1], res[0][1]) < 1e-13, lv
+            lhs, rhs = float(res[1][0] @ xf), float(xc @ res[1][1])
+            assert abs(lhs - rhs) <= 1e-12 * max(abs(lhs), abs(rhs)), (lv, lhs, rhs)
+        # one smoothing step on the fine level, fused and in two passes: same bits
+        L, op, n = gpu.L, pb.levels[pb.fine].opJacob, pb.lsize()
+        free = (pb.levels[pb.fine].mask == 0).astype(np.float64)
+        a = {k: rng.uniform(-1, 1, n) * free for k in ("x", "d", "b")}
+        a["dinv"] = rng.uniform(0.5, 2.0, n) * free
+        out = []
+        for fused in (False, True):
+            v = {k: gpu.vector(n).set_array(a[k]) for k in a}
+            t = gpu.vector(n)
+            c1, c2 = C.c_double(0.3), C.c_double(0.2)
+            if fused:
+                L.chk(L.lib.CeedXOperatorApplyChebyshev(op.h, v["x"].h, t.h, v["x"].h, v["d"].h, None, v["b"].h, v["dinv"].h, c1, c2, 0))
+            else:
+                op.apply(v["x"], t)
+                L.chk(L.lib.CeedXVectorChebyshevStep(v["x"].h, v["d"].h, None, v["b"].h, t.h, v["dinv"].h, c1, c2, 0))
+            out.append((v["x"].to_numpy(), v["d"].to_numpy()))
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    finally:
+        oracle_lib.lib.OracleSetNumThreads(C.c_int(1))
+
+
 def test_device_pointer_use_pointer_roundtrip(gpu):
     """matops.c:40-50 with -memtype device: SetArray(DEVICE, USE_POINTER) / TakeArray on
     buffers owned by the caller (torch tensors standing in for PETSc's device Vecs)."""
