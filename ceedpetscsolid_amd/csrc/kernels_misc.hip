@@ -202,7 +202,11 @@ __global__ __launch_bounds__(64) void k_transfer(const BasisTables tab, const Tr
   using G = XferGeom<PC, PF>;
   constexpr int C3 = G::C3, F2 = G::F2, F3 = G::F3, E = G::E, N0 = G::N0, N1 = G::N1, N2 = G::N2, KR = G::KR;
   constexpr int SR = (E * N0 + 63) / 64;           // rounds of the coarse-side staging (a lane per coarse value)
-  __shared__ double U0[E * N0], U1[E * N1], U2[E * N2];
+  // U0 (the coarse values: read by the first pass of a prolongation, written by the last of a restriction) shares its storage with U2
+  // (written by the j-pass / read by the j^T pass: never live together) -- 5.8 instead of 7.1 KB per wave at (3, 5): 27 instead of 22 waves per CU
+  static_assert(N0 <= N2, "the coarse slab fits the widest intermediate");
+  __shared__ double U1[E * N1], U2[E * N2];
+  double *const U0 = U2;
   const int lane = threadIdx.x;
   // XCD-aware: the groups are cut into 8 contiguous chunks; block b serves chunk b % 8 (blocks b and b + 8 share an XCD under the
   // round-robin placement), so the elements that share coarse and fine nodes meet in one L2 (prolong p2 -> p4 at 99 000 hexes:
