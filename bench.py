@@ -481,8 +481,12 @@ def main():
     use_rccl = world > 1 and args.halo == "rccl" and dist.get_backend() == "nccl"
     chalo, halo_note = None, None
     halo_path = None if world == 1 and not emu else ("rccl" if (use_rccl or emu) else "torch")
+    if world > 1 and os.environ.get("BENCH_TEST_BRING_UP_FAILURE"):   # (rehearsal of the failure record on a box without RCCL peers)
+        use_rccl = True
     if use_rccl:   # brought up with a time limit and checked against the torch exchange; a failure ends the run (exit 4) unless --no-strict-halo
         try:
+            if os.environ.get("BENCH_TEST_BRING_UP_FAILURE"):
+                raise HaloBringUpError("rehearsal: BENCH_TEST_BRING_UP_FAILURE is set")
             chalo, halo_note = checked_rccl_halo(ceed, halo, coord_hash_vector(dofmap.node_coords, np.zeros(n, dtype=np.uint8)), dev,
                                                  strict=not args.no_strict_halo)
         except HaloBringUpError as e:
