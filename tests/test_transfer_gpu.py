@@ -139,3 +139,24 @@ def test_apply_add_of_the_transfers(oracle, gpu):
         res.append((Yf.to_numpy(), Yc.to_numpy()))
     assert rel_err(res[1][0], res[0][0]) < TOL and rel_err(res[1][1], res[0][1]) < TOL
     pa.destroy(); pb.destroy()
+
+
+def test_transfer_on_a_scrambled_mesh(oracle, gpu):
+    """Elements and vertices in random order and every element's local axes rotated at random (mesh.scramble_mesh): neighbours no
+    longer agree on which local direction is which, so a shared face's fine nodes are interpolated along DIFFERENT local directions by
+    the element that owns them and by the ones the reference would also sum -- still one value to rounding."""
+    from ceedpetscsolid_amd.mesh import scramble_mesh
+    mesh = scramble_mesh(hollow_cylinder_mesh(3, 10, 5), 20261005, order=True, orient=True)
+    pa, pb = _pair(oracle, gpu, mesh, 4, bc_sides=[998])
+    rng = np.random.default_rng(2)
+    for lv in range(1, len(pa.levels)):
+        nf, nc = pa.lsize(lv), pa.lsize(lv - 1)
+        xc, xf = rng.uniform(-1, 1, nc), rng.uniform(-1, 1, nf)
+        res = []
+        for p in (pa, pb):
+            c = p.ceed
+            Xc, Xf, Yf, Yc = c.vector(nc).set_array(xc), c.vector(nf).set_array(xf), c.vector(nf), c.vector(nc)
+            p.prolong(lv, Xc, Yf); p.restrict(lv, Xf, Yc)
+            res.append((Yf.to_numpy(), Yc.to_numpy()))
+        assert rel_err(res[1][0], res[0][0]) < 1e-13 and rel_err(res[1][1], res[0][1]) < 1e-13, lv
+    pa.destroy(); pb.destroy()
