@@ -218,10 +218,16 @@ class AggregationAMG:
             return
         d = lv.dd
         d["local"].update()
-        u = np.zeros(d["nnz_union"])
-        u[d["slot"]] = d["local"].values(self.ceed)
-        u = self._allreduce_np(u)
-        d["coo"].set_array(u)
+        # the rank's values into their places of the union pattern, summed over the ranks, assembled: all on the vectors' own memory
+        # (device tensors on a GPU; RCCL through the library where it has a communicator, torch.distributed otherwise)
+        self.L.chk(self.L.lib.CeedXCsrGetValues(d["local"].h, d["vals"].h))
+        if d["vals"].t.device.type == "cuda":
+            self.ceed.synchronize()
+        d["coo"].t.zero_()
+        d["coo"].t.index_copy_(0, d["slot_t"], d["vals"].t[:d["slot_t"].numel()])
+        if d["coo"].t.device.type == "cuda":
+            d["coo"].set_device_pointer(d["coo"].t.data_ptr())
+        self._allreduce(d["coo"])
         lv.Anext.assemble(d["coo"])
 
     def _allreduce_np(self, a: np.ndarray) -> np.ndarray:
@@ -430,7 +436,8 @@ class AggregationAMG:
         wv.t.copy_(torch.from_numpy(w_own * (np.asarray(asm.mask) == 0)).to(wv.t.device))
         if wv.t.device.type == "cuda":
             wv.set_device_pointer(wv.t.data_ptr())
-        lv.dd = {"local": local, "slot": slot, "nnz_union": nnz_u, "coo": c.vector(max(nnz_u, 1)), "w": wv, "rw": c.vector(n).set_value(0.0)}
+        lv.dd = {"local": local, "slot_t": torch.from_numpy(np.ascontiguousarray(slot, dtype=np.int64)).to(h.device), "nnz_union": nnz_u,
+                 "coo": self._dist_vector(max(nnz_u, 1)), "vals": self._dist_vector(max(local.nnz, 1)), "w": wv, "rw": c.vector(n).set_value(0.0)}
         lv.info = dict(rows=int(n), aggregates=int(na), coarse_dofs=int(nc), coarse_dofs_of_this_rank=int(ncr), distributed_over=int(h.world),
                        nodes_per_aggregate=float(fn.size) / max(na, 1), prolongation_entries_per_row=float(P.nnz) / max(n, 1),
                        galerkin_entries=int(lv.T.nnz), lambda_max=lam, next_is_dense=bool(lv.dense_next), seconds=dict(aggregate=t_ag),
@@ -609,7 +616,7 @@ class AggregationAMG:
     def destroy(self):
         for lv in reversed(self.levels):
             dd = getattr(lv, "dd", None) or {}
-            for o in [lv.Anext, dd.get("local"), lv.T, lv.Pt, lv.P, lv.x0, dd.get("coo"), dd.get("w"), dd.get("rw")] + list(lv.v.values()):
+            for o in [lv.Anext, dd.get("local"), lv.T, lv.Pt, lv.P, lv.x0, dd.get("coo"), dd.get("vals"), dd.get("w"), dd.get("rw")] + list(lv.v.values()):
                 if o is not None:
                     o.destroy()
         for o in (self.rc, self.xc, self._scal):
