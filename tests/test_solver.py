@@ -133,6 +133,19 @@ def test_fused_apply_entries_on_the_oracle_are_their_two_steps(oracle):
     p.destroy()
 
 
+def test_auto_form_on_a_backend_without_graph_capture(oracle):
+    """graph="auto" on the CPU oracle (which cannot record): the measurement covers the eager forms only and the solve goes on."""
+    from ceedpetscsolid_amd.mesh import hollow_cylinder_mesh
+    p = SolidProblem(oracle, hollow_cylinder_mesh(1, 6, 4, z0=-1.0, z1=1.0), 2, "hyperSS", nu=0.3, E=10.0, bc_sides=[998, 999])
+    ref = NewtonPMG(p, clamp=CLAMP, coarse="amg", graph=False, fuse_epilogue=False)
+    st0 = ref.solve(1)
+    s = NewtonPMG(p, clamp=CLAMP, coarse="amg", graph="auto", fuse_epilogue="auto")
+    st = s.solve(1)
+    assert st.converged and s.graph is False and set(s.tuning["vcycle_ms"]) == {"fused+eager", "two_pass+eager"}
+    assert (st.newton_its, st.ksp_its) == (st0.newton_its, st0.ksp_its)
+    p.destroy()
+
+
 @pytest.mark.gpu
 def test_vcycle_form_is_chosen_by_measurement_and_does_not_change_the_solve(gpu):
     """graph="auto", fuse_epilogue="auto": the first Newton step times the V-cycle eager / replayed and with the smoother's
